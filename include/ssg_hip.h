@@ -1,0 +1,127 @@
+/*
+ * ssg_hip.h -- C ABI of libssg_hip.so: the MI355X (gfx950) kernels behind the SSG
+ * pseudo-label grouping hot path (extract -> N x N re-rank -> eps -> DBSCAN).
+ *
+ * The reference (SHI-Labs/Self-Similarity-Grouping) has no FFI layer: its boundary for this
+ * path is the Python call surface of selftraining.py / reid/.  This header is what a ctypes
+ * stub in that Python binds (INTEGRATION.md shows the stub); every entry point names the
+ * reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller (PyTorch
+ *     or any HIP allocator) owns all buffers including workspaces;
+ *   - calls are asynchronous on `stream` (a hipStream_t, 0 = default stream), re-entrant,
+ *     and keep no global state;
+ *   - return value: SSG_OK (0) or a negative SSG_ERR_* code; ssg_last_error() gives the
+ *     message (thread-local).  No C++ exception crosses the boundary;
+ *   - "half" = IEEE binary16 stored as uint16_t bit patterns; arithmetic on it follows
+ *     numpy's half loops (float32 op + round-to-nearest-even), see DESIGN.md;
+ *   - row-block arguments (row0, nrows) address rows [row0, row0+nrows) of an N-row
+ *     problem: one GPU of a row-sharded job passes its own block, a single GPU passes
+ *     (0, N).
+ */
+#ifndef SSG_HIP_H
+#define SSG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ssg_stream_t; /* == hipStream_t */
+
+#define SSG_OK 0
+#define SSG_ERR_INVALID (-1)  /* bad argument / shape */
+#define SSG_ERR_HIP (-2)      /* HIP runtime error */
+#define SSG_ERR_OVERFLOW (-3) /* caller-provided capacity exceeded */
+#define SSG_ERR_NAN (-4)
+
+const char* ssg_last_error(void);
+int ssg_version(void);
+/* half(x) with one rounding; used for the weak python scalar (1-lambda) of rerank.py:122 */
+uint16_t ssg_double_to_half_bits(double d);
+
+/* ---- K3/K4 pairwise distance (replaces scipy cdist in reid/rerank.py:36-37,61-62) ------ */
+/* norms[i] = sum_k x[i,k]^2 in float64, accumulated exactly like the Gram kernel.
+ * round_to_half != 0 first rounds x to half (rerank.py:33 feat = astype(float16)). */
+int ssg_row_norms_f64(const float* x, int n, int d, int round_to_half, double* norms, ssg_stream_t stream);
+/* D[il, j] = half(half(sqrt(|f16(x_i) - f16(x_j)|^2))^2) for rows i = row0+il (rerank.py:33,61-62)
+ * rowmax[il] = max_j D[il, j] as half bits in a uint32 (rerank.py:68 max(original_dist, axis=0)).
+ * x [N,d] f32 row-major, d % 4 == 0; norms from ssg_row_norms_f64(x, N, d, 1). */
+int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
+                        ssg_stream_t stream);
+/* rowmin[i] = min_s half(cdist(tgt_i, src_s)^2) as half bits in uint32 (rerank.py:36-37,39) */
+int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const float* src, const double* nsrc, int nrows, int Ns, int d,
+                          uint32_t* rowmin, ssg_stream_t stream);
+/* v = half(1-exp(-rowmin)); *max_bits = max(v); v /= max(v)   (rerank.py:38-40).  A zero
+ * max means the reference would produce NaNs (0/0): the caller must raise. */
+int ssg_source_vec_finish(const uint32_t* rowmin, int N, uint16_t* v, uint32_t* max_bits, ssg_stream_t stream);
+
+/* ---- K5 ranking (replaces np.argsort in reid/rerank.py:68-70) --------------------------- */
+/* rank[il, 0:K] = the K smallest of half(D[il,:]/rowmax[il]) in (value, column) order. K <= 64 */
+int ssg_topk_rank(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, ssg_stream_t stream);
+
+/* ---- K6 k-reciprocal encoding (reid/rerank.py:74-92) ------------------------------------ */
+int ssg_krecip_row_capacity(int k1); /* entries per sparse V row: (k1+1)*(round(k1/2)+2) */
+/* rank is the FULL [N,K] table; D/rowmax and the outputs cover rows [row0,row0+nrows).
+ * Output: sparse rows sorted by column: v_idx/v_val [nrows,cap], v_nnz [nrows]. */
+int ssg_krecip(const uint16_t* D, const uint32_t* rowmax, const int32_t* rank, int N, int row0, int nrows, int K, int k1, int cap,
+               int32_t* v_idx, uint16_t* v_val, int32_t* v_nnz, ssg_stream_t stream);
+
+/* ---- K7 local query expansion (reid/rerank.py:94-99) ------------------------------------ */
+/* v_* are FULL [N,capV] tables; q_* cover rows [row0,row0+nrows), capQ >= k2*capV. */
+int ssg_query_expand(const int32_t* v_idx, const uint16_t* v_val, const int32_t* v_nnz, const int32_t* rank, int N, int row0, int nrows,
+                     int K, int k2, int capV, int capQ, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz, ssg_stream_t stream);
+
+/* ---- K8 inverted index (reid/rerank.py:101-103) ------------------------------------------ */
+/* colcnt [ncols] int32 scratch, colptr [ncols+1] int64, inv_row/inv_val >= sum(q_nnz) entries */
+int ssg_invert_index(const int32_t* q_idx, const uint16_t* q_val, const int32_t* q_nnz, int nrows, int ncols, int capQ, int32_t* colcnt,
+                     int64_t* colptr, int32_t* inv_row, uint16_t* inv_val, ssg_stream_t stream);
+
+/* ---- K9 Jaccard distance (reid/rerank.py:105-122) ---------------------------------------- */
+/* Jp[il,k] = half(clamp(1 - t/(2-t)) * half(1-lambda)); q_* are FULL tables. */
+int ssg_jaccard_rows(const int32_t* q_idx, const uint16_t* q_val, const int32_t* q_nnz, int capQ, const int64_t* colptr,
+                     const int32_t* inv_row, const uint16_t* inv_val, int N, int row0, int nrows, uint16_t one_minus_lambda_half,
+                     uint16_t* Jp, ssg_stream_t stream);
+/* API materialisation of final_dist (rerank.py:122): out[il,k] = f64(Jp) + f64(half(v_i+v_k))*lambda */
+int ssg_final_dist_f64(const uint16_t* Jp, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double* out,
+                       ssg_stream_t stream);
+
+/* ---- K10 epsilon rule (selftraining.py:289-293) ------------------------------------------ */
+/* Matrix view for K10/K11 (M is [nrows,N] row-major): mode 0 = half Jp + v + lambda -> the
+ * final_dist values of rerank.py:122; mode 1 = plain half matrix (no-rerank euclidean_dist);
+ * mode 2 = plain float64 matrix (any precomputed distance, the sklearn drop-in case). */
+/* One radix level over the strict upper triangle, zeros dropped: hist[bin] (uint64[4097]) +=
+ * count of keys whose bits above (shift+width) equal prefix; hist[4096] += non-zero count. */
+int ssg_eps_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, uint64_t prefix,
+                 int shift, int width, int count_nonzero, uint64_t* hist, ssg_stream_t stream);
+/* buf[cursor++] = key for every strict-upper non-zero key <= key_max (writes beyond cap dropped) */
+int ssg_eps_compact(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, uint64_t key_max,
+                    uint64_t* buf, uint64_t cap, uint64_t* cursor, ssg_stream_t stream);
+int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t value, ssg_stream_t stream);
+int ssg_sort_u64(uint64_t* buf, uint64_t n_pow2, ssg_stream_t stream); /* ascending, n = 2^k >= 2048 */
+size_t ssg_eps_mean_workspace_bytes(int64_t top);
+/* out2[0] = mean of the first `top` sorted keys with numpy's pairwise summation (mode 0: f64;
+ * mode 1: float32 sum of half values -> half, out2[1] = its bits) */
+int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, ssg_stream_t stream);
+
+/* ---- K11/K12 DBSCAN (selftraining.py:295,306; sklearn 1.7.2 DBSCAN precomputed) ---------- */
+/* cnt[il] = |{k: d(i,k) <= eps}|; edges[2e],[2e+1] = (i,k) for every hit (cursor counts all) */
+int ssg_region_query(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps,
+                     int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, ssg_stream_t stream);
+size_t ssg_dbscan_cc_workspace_bytes(int N);
+/* cnt is the FULL [N] table, edges the concatenated edge list: labels[N] int64, -1 = noise */
+int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,
+                  int64_t* labels, ssg_stream_t stream);
+
+/* ---- device self-tests used by the parity suite ----------------------------------------- */
+int ssg_selftest_half_table(int which, uint16_t* out65536, ssg_stream_t stream);
+int ssg_selftest_half_binop(int which, const uint16_t* a, const uint16_t* b, int n, uint16_t* out, ssg_stream_t stream);
+int ssg_selftest_d2h(const double* a, int n, uint16_t* out, ssg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSG_HIP_H */

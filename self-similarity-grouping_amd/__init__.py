@@ -1,0 +1,24 @@
+"""ssg_amd -- MI355X-native pseudo-label grouping for Self-Similarity Grouping.
+
+One hot path: ResNet-50 embedding of the target set -> N x N
+k-reciprocal re-rank distance -> epsilon rule -> DBSCAN, behind the reference's Python call
+surface.  Compute = hand-written HIP kernels in csrc/ behind the C ABI of include/ssg_hip.h;
+this package is the thin host-side mirror of the reference interface.
+"""
+from . import _lib  # noqa: F401
+from ._lib import SSGError, available  # noqa: F401
+
+__all__ = ["re_ranking", "re_ranking_device", "DBSCAN", "eps_rule", "compute_dist", "generate_selflabel", "SSGError", "available"]
+
+
+def __getattr__(name):   # lazy: torch import only when the compute surface is touched
+    if name in ("re_ranking", "re_ranking_device", "DistHandle", "ReRankNaNError"):
+        from . import rerank
+        return getattr(rerank, name)
+    if name in ("DBSCAN", "eps_rule", "as_handle"):
+        from . import cluster
+        return getattr(cluster, name)
+    if name in ("compute_dist", "generate_selflabel", "select_labeled"):
+        from . import selftraining
+        return getattr(selftraining, name)
+    raise AttributeError(name)

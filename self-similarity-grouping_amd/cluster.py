@@ -1,0 +1,185 @@
+"""epsilon rule + DBSCAN on MI355X -- host-side mirror of selftraining.py:280-313 and of the
+sklearn estimator it instantiates (`DBSCAN(eps, min_samples=4, metric='precomputed', n_jobs=8)`).
+
+`DBSCAN` is a drop-in for the sklearn 1.7.2 class for metric='precomputed': same constructor
+arguments, `fit`, `fit_predict`, `labels_`, `core_sample_indices_`, same label numbering
+(clusters numbered by their smallest core index; border points take the smallest cluster id
+among their core neighbours; noise = -1).  It accepts a numpy/torch matrix, or the
+`DistHandle` / `DeviceBackedArray` produced by `ssg_amd.rerank` (no re-upload).
+"""
+import math
+import numbers
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+from .rerank import DistHandle
+
+_LEVELS = ((51, 12), (39, 12), (27, 12), (15, 12), (3, 12), (0, 3))   # (shift, width) of the radix digits
+_MAX_COMPACT = 1 << 24
+
+
+def _all_reduce(t, group):
+    if group is not None:
+        import torch.distributed as dist
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def as_handle(X, device=None):
+    """numpy / torch matrix or handle -> DistHandle on the GPU."""
+    if isinstance(X, DistHandle):
+        return X
+    h = getattr(X, "ssg_handle", None)
+    if isinstance(h, DistHandle):
+        return h
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if isinstance(X, np.ndarray):
+        if X.ndim != 2 or X.shape[0] != X.shape[1]:
+            raise ValueError("Precomputed distance matrix must be square, got shape %r" % (X.shape,))
+        if X.dtype == np.float16:
+            return DistHandle(X.shape[0], 1, torch.from_numpy(np.ascontiguousarray(X)).to(device))
+        return DistHandle(X.shape[0], 2, torch.from_numpy(np.ascontiguousarray(X, dtype=np.float64)).to(device))
+    if torch.is_tensor(X):
+        if X.dim() != 2 or X.shape[0] != X.shape[1]:
+            raise ValueError("Precomputed distance matrix must be square")
+        if X.dtype == torch.float16:
+            return DistHandle(X.shape[0], 1, X.to(device).contiguous())
+        return DistHandle(X.shape[0], 2, X.to(device=device, dtype=torch.float64).contiguous())
+    raise TypeError("unsupported distance matrix type %r" % type(X))
+
+
+def eps_rule(X, rho):
+    """selftraining.py:289-293 on device.
+
+    eps = mean of the round(rho*count) smallest non-zero entries of the strict upper triangle.
+    float64 views (mode 0/2) -> python float, bit-identical to numpy's pairwise-sum mean;
+    half matrix (mode 1) -> np.float16 like `tri_mat[:top].mean()` on a float16 array.
+    Returns (eps, count, top_num).
+    """
+    L = _lib.lib()
+    h = as_handle(X)
+    dev, st = h.device, stream()
+    args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
+    prefix, below, count, top = 0, 0, None, None
+    key_max = None
+    for shift, width in _LEVELS:
+        hist = torch.zeros(4097, dtype=torch.int64, device=dev)
+        check(L.ssg_eps_hist(*args, prefix, shift, width, 1 if count is None else 0, ptr(hist), st), "ssg_eps_hist")
+        hist = _all_reduce(hist, h.group).cpu().numpy()
+        if count is None:
+            count = int(hist[4096])
+            top = int(np.round(rho * count))          # np.round: half to even (selftraining.py:292)
+            if top <= 0:
+                # numpy: mean of an empty slice -> nan (+ RuntimeWarning); sklearn then rejects eps
+                return (np.float16(np.nan) if h.mode == 1 else float("nan")), count, top
+        cum = below + np.cumsum(hist[: 1 << width])
+        b = int(np.searchsorted(cum, top, side="left"))   # first digit whose cumulative count reaches top
+        ncand = int(cum[b])
+        if ncand <= _MAX_COMPACT or shift == 0:
+            key_max = (((prefix << width) | b) << shift) | ((1 << shift) - 1)
+            break
+        below = int(cum[b - 1]) if b > 0 else below
+        prefix = (prefix << width) | b
+    # compact every key <= key_max, sort, pairwise mean of the first `top`
+    n_pow2 = max(2048, 1 << (ncand - 1).bit_length())
+    buf = torch.empty(n_pow2, dtype=torch.int64, device=dev)
+    cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+    check(L.ssg_eps_compact(*args, key_max, ptr(buf), n_pow2, ptr(cursor), st), "ssg_eps_compact")
+    if h.group is not None:
+        # sharded rows: gather the (small) candidate sets of every rank
+        import torch.distributed as dist
+        ws = dist.get_world_size(h.group)
+        n_loc = cursor.clone()
+        sizes = [torch.zeros_like(n_loc) for _ in range(ws)]
+        dist.all_gather(sizes, n_loc, group=h.group)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes + [1])
+        pad = torch.full((mx,), -1, dtype=torch.int64, device=dev)
+        pad[: sizes[dist.get_rank(h.group)]] = buf[: sizes[dist.get_rank(h.group)]]
+        parts = [torch.empty_like(pad) for _ in range(ws)]
+        dist.all_gather(parts, pad, group=h.group)
+        buf[: sum(sizes)] = torch.cat([p[:s] for p, s in zip(parts, sizes)])
+        got = sum(sizes)
+    else:
+        got = int(cursor.item())
+    if got != ncand:
+        raise _lib.SSGError("eps_rule: compaction found %d keys, histogram promised %d" % (got, ncand))
+    check(L.ssg_fill_u64(ptr(buf), got, n_pow2, 0xFFFFFFFFFFFFFFFF, st), "ssg_fill_u64")
+    check(L.ssg_sort_u64(ptr(buf), n_pow2, st), "ssg_sort_u64")
+    ws_bytes = int(L.ssg_eps_mean_workspace_bytes(top))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.zeros(2, dtype=torch.float64, device=dev)
+    check(L.ssg_eps_mean(ptr(buf), top, 1 if h.mode == 1 else 0, ptr(ws), ws_bytes, ptr(out), st), "ssg_eps_mean")
+    out = out.cpu().numpy()
+    if h.mode == 1:
+        return np.uint16(int(out[1])).view(np.float16), count, top
+    return float(out[0]), count, top
+
+
+class DBSCAN:
+    """sklearn.cluster.DBSCAN look-alike for metric='precomputed' running on the GPU."""
+
+    def __init__(self, eps=0.5, *, min_samples=5, metric="euclidean", metric_params=None, algorithm="auto", leaf_size=30, p=None,
+                 n_jobs=None):
+        self.eps, self.min_samples, self.metric, self.metric_params = eps, min_samples, metric, metric_params
+        self.algorithm, self.leaf_size, self.p, self.n_jobs = algorithm, leaf_size, p, n_jobs
+
+    def _validate(self):
+        # sklearn raises InvalidParameterError (a ValueError) for these
+        if not isinstance(self.eps, numbers.Real) or isinstance(self.eps, bool) or not (float(self.eps) > 0.0) or math.isnan(float(self.eps)):
+            raise ValueError("The 'eps' parameter of DBSCAN must be a float in the range (0.0, inf). Got %r instead." % (self.eps,))
+        if not isinstance(self.min_samples, numbers.Integral) or self.min_samples < 1:
+            raise ValueError("The 'min_samples' parameter of DBSCAN must be an int in the range [1, inf). Got %r instead." % (self.min_samples,))
+        if self.metric != "precomputed":
+            raise ValueError("ssg_amd.cluster.DBSCAN implements metric='precomputed' only (the SSG grouping path, "
+                             "selftraining.py:295); got metric=%r" % (self.metric,))
+
+    def fit(self, X, y=None, sample_weight=None):
+        self._validate()
+        if sample_weight is not None:
+            raise ValueError("sample_weight is not supported on the precomputed GPU path")
+        L = _lib.lib()
+        h = as_handle(X)
+        dev, st, N = h.device, stream(), h.N
+        eps = float(self.eps)
+        cnt = torch.empty(h.nrows, dtype=torch.int32, device=dev)
+        cap = max(64 * h.nrows, 1 << 16)
+        while True:
+            edges = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+            cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+            check(L.ssg_region_query(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, eps, ptr(cnt), ptr(edges), cap,
+                                     ptr(cursor), st), "ssg_region_query")
+            ne = int(cursor.item())
+            if ne <= cap:
+                break
+            cap = ne   # the cursor counted every hit: retry once with the exact size
+        edges = edges[:ne]
+        if h.group is not None:
+            import torch.distributed as dist
+            ws = dist.get_world_size(h.group)
+            cnt_all = torch.empty(N, dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(cnt_all, cnt, group=h.group)
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
+            dist.all_gather(sizes, torch.tensor([ne], dtype=torch.int64, device=dev), group=h.group)
+            sizes = [int(s.item()) for s in sizes]
+            mx = max(sizes + [1])
+            pad = torch.zeros((mx, 2), dtype=torch.int32, device=dev)
+            pad[:ne] = edges
+            parts = [torch.empty_like(pad) for _ in range(ws)]
+            dist.all_gather(parts, pad, group=h.group)
+            edges = torch.cat([p[:s] for p, s in zip(parts, sizes)]).contiguous()
+            cnt, ne = cnt_all, sum(sizes)
+        ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        labels = torch.empty(N, dtype=torch.int64, device=dev)
+        check(L.ssg_dbscan_cc(ptr(cnt), ptr(edges), ne, N, int(self.min_samples), ptr(ws), ws_bytes, ptr(labels), st), "ssg_dbscan_cc")
+        self.labels_ = labels.cpu().numpy()
+        self.core_sample_indices_ = torch.nonzero(cnt >= int(self.min_samples)).flatten().cpu().numpy()
+        self.n_features_in_ = N
+        return self
+
+    def fit_predict(self, X, y=None, sample_weight=None):
+        return self.fit(X, sample_weight=sample_weight).labels_

@@ -1,0 +1,485 @@
+// cluster.hip -- K10 (epsilon rule), K11 (DBSCAN region query), K12 (connected components).
+//
+// K10 replaces selftraining.py:289-293:
+//   tri = triu(dist, 1); tri = tri[nonzero(tri)]; tri = sort(tri)
+//   eps = tri[:round(rho * tri.size)].mean()
+// as a 12-bit-digit radix select over the monotone u64 patterns of the (positive) float64
+// distances, a compaction of everything at or below the selected digit, a bitonic sort of
+// that small set and numpy's pairwise-summation mean -- bit-identical to np.mean.
+//
+// K11/K12 replace sklearn 1.7.2 DBSCAN(eps, min_samples, metric='precomputed').fit_predict
+// (selftraining.py:295,306): neighbourhood = {k : d[i,k] <= eps} row-wise, core = count >=
+// min_samples, clusters = connected components of core-core edges numbered by their
+// smallest core index (== dbscan_inner's visiting order), border points take the smallest
+// cluster id among their core neighbours, everything else is -1.
+//
+// The matrix is never materialised in f64: mode 0 rebuilds final_dist from the compact
+// half J' and the source vector v (reid/rerank.py:122), mode 1 reads a plain half matrix
+// (the no-rerank euclidean_dist).  All matrix passes are HBM-read-bound (2 bytes/entry).
+#include "ssg_common.h"
+
+namespace ssg {
+
+struct MatView {
+  const void* M;       // [nrows, N] rows of this row block: half (mode 0/1) or double (mode 2)
+  const hbits* v;      // [N] source vector (mode 0) or null
+  int N, row0, nrows, mode;
+  double lambda_value;
+};
+
+// Row streaming shared by the matrix passes: one wave per row, 8 consecutive elements per
+// lane per chunk (16 B of half / 64 B of double), chunks aligned to 8 elements of the block.
+struct RowStream {
+  int64_t total, al; int first, nchunks;
+  __device__ __forceinline__ RowStream(int row, int N, int nrows) {
+    total = (int64_t)nrows * N;
+    const int64_t base = (int64_t)row * N;
+    al = base & ~(int64_t)7; first = (int)(base - al); nchunks = (first + N + 511) / 512;
+  }
+  __device__ __forceinline__ int col0(int c, int lane) const { return c * 512 + lane * 8 - first; }
+};
+
+// d[e] = value of column col0+e of row gi (garbage for columns outside [0,N): callers mask)
+template <int MODE>
+__device__ __forceinline__ void load_vals(const MatView& mv, const RowStream& rs, int c, int lane, int gi, double d[8]) {
+  const int64_t off = rs.al + (int64_t)c * 512 + lane * 8;
+  if (MODE == 2) {
+    const double* M = reinterpret_cast<const double*>(mv.M);
+    if (off + 8 <= rs.total) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) { const double2 t = *reinterpret_cast<const double2*>(M + off + 2 * q); d[2 * q] = t.x; d[2 * q + 1] = t.y; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) d[e] = (off + e < rs.total) ? M[off + e] : 0.0;
+    }
+    return;
+  }
+  const hbits* M = reinterpret_cast<const hbits*>(mv.M);
+  unsigned w[4] = {0, 0, 0, 0};
+  if (off + 8 <= rs.total) { const uint4 x = *reinterpret_cast<const uint4*>(M + off); w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w; }
+  else if (off < rs.total) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) if (off + e < rs.total) w[e >> 1] |= (unsigned)M[off + e] << ((e & 1) * 16);
+  }
+  const int j0 = rs.col0(c, lane);
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const hbits raw = (hbits)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    if (MODE == 0) {
+      const int k = j0 + e;
+      d[e] = final_dist_value(raw, mv.v[gi], mv.v[(k >= 0 && k < mv.N) ? k : 0], mv.lambda_value);
+    } else d[e] = (double)h2f(raw);
+  }
+}
+
+// ------------------------------------------------------------------ K10 histogram level
+// hist[bin] += #{ (i<k), d != 0, (key >> (shift+width)) == prefix }, bin = (key>>shift) & mask.
+// hist[4096] += number of non-zero strict-upper entries (only when count_nonzero != 0).
+template <int MODE>
+__global__ __launch_bounds__(256) void eps_hist_kernel(MatView mv, unsigned long long prefix, int shift, int width, int count_nonzero,
+                                                       unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int lh[4096];
+  __shared__ unsigned long long lnz;
+  for (int b = (int)threadIdx.x; b < 4096; b += 256) lh[b] = 0;
+  if (threadIdx.x == 0) lnz = 0;
+  __syncthreads();
+  const int lane = lane_id();
+  const unsigned mask = (1u << width) - 1u;
+  const bool anyprefix = (shift + width) >= 63;   // top level: no prefix to match
+  unsigned long long nz = 0;
+  for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
+    const int gi = mv.row0 + il;
+    RowStream rs(il, mv.N, mv.nrows);
+    // strict upper triangle: columns k > gi only -> skip leading chunks
+    int c0 = (rs.first + gi + 1) / 512;
+    for (int c = c0; c < rs.nchunks; c++) {
+      double dv[8];
+      load_vals<MODE>(mv, rs, c, lane, gi, dv);
+      const int j0 = rs.col0(c, lane);
+      int pbin = -1; unsigned pcnt = 0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = j0 + e;
+        if (k > gi && k < mv.N) {
+          const double d = dv[e];
+          if (d != 0.0) {
+            nz++;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(d);
+            if (anyprefix || (key >> (shift + width)) == prefix) {
+              const int bin = (int)((key >> shift) & mask);
+              if (bin == pbin) pcnt++;
+              else { if (pcnt) atomicAdd(&lh[pbin], pcnt); pbin = bin; pcnt = 1; }
+            }
+          }
+        }
+      }
+      // the bulk of a row falls into one bin: one add per wave instead of 64
+      const int fb = __shfl(pbin, 0, 64);
+      if (__all(pbin == fb)) {
+        unsigned tot = pcnt;
+        for (int sh = 1; sh < 64; sh <<= 1) tot += (unsigned)__shfl_xor((int)tot, sh, 64);
+        if (lane == 0 && fb >= 0 && tot) atomicAdd(&lh[fb], tot);
+      } else if (pcnt) atomicAdd(&lh[pbin], pcnt);
+    }
+  }
+  for (int sh = 1; sh < 64; sh <<= 1) nz += (unsigned long long)__shfl_xor((long long)nz, sh, 64);
+  if (lane == 0 && nz) atomicAdd(&lnz, nz);
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < 4096; b += 256) if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+  if (threadIdx.x == 0 && count_nonzero && lnz) atomicAdd(&hist[4096], lnz);
+}
+
+// append every strict-upper non-zero key <= key_max to buf (wave-aggregated cursor)
+template <int MODE>
+__global__ __launch_bounds__(256) void eps_compact_kernel(MatView mv, unsigned long long key_max, unsigned long long* __restrict__ buf,
+                                                          unsigned long long cap, unsigned long long* __restrict__ cursor) {
+  const int lane = lane_id();
+  for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
+    const int gi = mv.row0 + il;
+    RowStream rs(il, mv.N, mv.nrows);
+    int c0 = (rs.first + gi + 1) / 512;
+    for (int c = c0; c < rs.nchunks; c++) {
+      double dv[8];
+      load_vals<MODE>(mv, rs, c, lane, gi, dv);
+      const int j0 = rs.col0(c, lane);
+      unsigned long long keys[8]; int n = 0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = j0 + e;
+        keys[e] = ~0ULL;
+        if (k > gi && k < mv.N) {
+          const double d = dv[e];
+          const unsigned long long key = (unsigned long long)__double_as_longlong(d);
+          if (d != 0.0 && key <= key_max) { keys[e] = key; n++; }
+        }
+      }
+      if (!__any(n > 0)) continue;
+      int incl = n;
+      for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
+      const int tot = __shfl(incl, 63, 64);
+      unsigned long long basep = 0;
+      if (lane == 0) basep = atomicAdd(cursor, (unsigned long long)tot);
+      basep = (unsigned long long)__shfl((long long)basep, 0, 64);
+      unsigned long long w = basep + (unsigned long long)(incl - n);
+#pragma unroll
+      for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) { if (w < cap) buf[w] = keys[e]; w++; }
+    }
+  }
+}
+
+__global__ void fill_u64_kernel(unsigned long long* p, unsigned long long n0, unsigned long long n1, unsigned long long v) {
+  for (unsigned long long i = n0 + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n1; i += (unsigned long long)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ------------------------------------------------------------------ bitonic sort (u64, ascending)
+constexpr int SORT_CH = 2048;
+__device__ __forceinline__ void cswap(unsigned long long& a, unsigned long long& b, bool up) {
+  if ((a > b) == up) { const unsigned long long t = a; a = b; b = t; }
+}
+// k_lo..k_hi: run all (k, j) stages with j < SORT_CH inside LDS.  For k <= SORT_CH this is a full
+// local sort; for k > SORT_CH only the tail j = SORT_CH/2 .. 1 of stage k.
+__global__ __launch_bounds__(1024) void bitonic_local_kernel(unsigned long long* __restrict__ a, unsigned long long k_first, unsigned long long k_last) {
+  __shared__ unsigned long long s[SORT_CH];
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * SORT_CH;
+  const int t = (int)threadIdx.x;
+  s[t] = a[g0 + t]; s[t + 1024] = a[g0 + t + 1024];
+  __syncthreads();
+  for (unsigned long long k = k_first; k <= k_last; k <<= 1) {
+    for (unsigned long long j = (k >> 1) < (unsigned long long)(SORT_CH / 2) ? (k >> 1) : (unsigned long long)(SORT_CH / 2); j > 0; j >>= 1) {
+      // thread t handles the pair (i, i^j) with i = the t-th index whose j bit is clear
+      const unsigned long long i = ((unsigned long long)t / j) * (2 * j) + ((unsigned long long)t % j);
+      const bool up = (((g0 + i) & k) == 0);
+      unsigned long long x = s[i], y = s[i + j];
+      cswap(x, y, up);
+      s[i] = x; s[i + j] = y;
+      __syncthreads();
+    }
+  }
+  a[g0 + t] = s[t]; a[g0 + t + 1024] = s[t + 1024];
+}
+__global__ void bitonic_global_kernel(unsigned long long* __restrict__ a, unsigned long long n, unsigned long long k, unsigned long long j) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n / 2) return;
+  const unsigned long long i = (t / j) * (2 * j) + (t % j);
+  const bool up = ((i & k) == 0);
+  unsigned long long x = a[i], y = a[i + j];
+  cswap(x, y, up);
+  a[i] = x; a[i + j] = y;
+}
+
+// ------------------------------------------------------------------ numpy pairwise mean
+struct PwFrame { long long off, n; int state; double left; };
+
+// leaves: consecutive blocks of <= 128 elements in numpy's recursion order
+__device__ int pw_build_leaves(long long n, long long* leaf_off, int* leaf_n) {
+  long long so[64], sn[64]; int sp = 0, nl = 0;
+  so[sp] = 0; sn[sp] = n; sp++;
+  while (sp) {
+    sp--; const long long off = so[sp], m = sn[sp];
+    if (m <= 128) { leaf_off[nl] = off; leaf_n[nl] = (int)m; nl++; continue; }
+    long long n2 = m / 2; n2 -= n2 % 8;
+    so[sp] = off + n2; sn[sp] = m - n2; sp++;    // right pushed first -> left popped first
+    so[sp] = off; sn[sp] = n2; sp++;
+  }
+  return nl;
+}
+template <typename T>
+__device__ T pw_leaf(const unsigned long long* keys, long long off, int n) {
+  auto val = [&](long long i) -> T { return (T)__longlong_as_double((long long)keys[off + i]); };
+  if (n < 8) { T r = (T)0; for (int i = 0; i < n; i++) r += val(i); return r; }
+  T r[8]; int i;
+  for (i = 0; i < 8; i++) r[i] = val(i);
+  for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += val(i + j);
+  T res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; i++) res += val(i);
+  return res;
+}
+// combine leaf sums in recursion order (thread 0)
+template <typename T>
+__device__ T pw_combine(long long n, const T* leaf_sum) {
+  struct F { long long n; int state; T left; } st[64];
+  int sp = 0, nl = 0;
+  st[sp].n = n; st[sp].state = 0; sp++;
+  T value = (T)0; bool have = false;
+  while (sp) {
+    F& f = st[sp - 1];
+    if (!have) {
+      if (f.n <= 128) { value = leaf_sum[nl++]; have = true; sp--; continue; }
+      long long n2 = f.n / 2; n2 -= n2 % 8;
+      f.state = 1; st[sp].n = n2; st[sp].state = 0; sp++;
+    } else {
+      if (f.state == 1) {
+        f.left = value; f.state = 2; have = false;
+        long long n2 = f.n / 2; n2 -= n2 % 8;
+        st[sp].n = f.n - n2; st[sp].state = 0; sp++;
+      } else { value = f.left + value; sp--; }
+    }
+  }
+  return value;
+}
+// out[0] = eps as double; out[1] = half bits of eps (mode 1) as a double-held integer
+__global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long* __restrict__ keys, long long top, int mode,
+                                                        long long* __restrict__ leaf_off, int* __restrict__ leaf_n,
+                                                        double* __restrict__ leaf_sum, double* __restrict__ out) {
+  __shared__ int nleaves;
+  if (threadIdx.x == 0) nleaves = pw_build_leaves(top, leaf_off, leaf_n);
+  __syncthreads();
+  __threadfence_block();
+  for (int l = (int)threadIdx.x; l < nleaves; l += (int)blockDim.x) {
+    if (mode == 0) leaf_sum[l] = pw_leaf<double>(keys, leaf_off[l], leaf_n[l]);
+    else reinterpret_cast<float*>(leaf_sum)[l] = pw_leaf<float>(keys, leaf_off[l], leaf_n[l]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (mode == 0) { out[0] = pw_combine<double>(top, leaf_sum) / (double)top; out[1] = 0.0; }
+    else {
+      const float s = pw_combine<float>(top, reinterpret_cast<const float*>(leaf_sum));
+      const hbits e = d2h((double)s / (double)top);   // np.float32 scalar / np.intp -> float64 -> np.float16
+      out[0] = (double)h2f(e); out[1] = (double)e;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K11 region query
+// cnt[il] = #{k : d(i,k) <= eps} (self included when d(i,i) <= eps);  edges (i,k), k != i.
+template <int MODE>
+__global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
+                                                           unsigned long long cap, unsigned long long* __restrict__ cursor) {
+  const int lane = lane_id();
+  for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
+    const int gi = mv.row0 + il;
+    RowStream rs(il, mv.N, mv.nrows);
+    int rowcnt = 0;
+    for (int c = 0; c < rs.nchunks; c++) {
+      double dv[8];
+      load_vals<MODE>(mv, rs, c, lane, gi, dv);
+      const int j0 = rs.col0(c, lane);
+      unsigned hitmask = 0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = j0 + e;
+        if (k >= 0 && k < mv.N && dv[e] <= eps) hitmask |= 1u << e;
+      }
+      if (!__any(hitmask != 0)) continue;
+      const int n = __popc(hitmask);
+      int incl = n;
+      for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
+      const int tot = __shfl(incl, 63, 64);
+      rowcnt += tot;
+      unsigned long long basep = 0;
+      if (lane == 0) basep = atomicAdd(cursor, (unsigned long long)tot);
+      basep = (unsigned long long)__shfl((long long)basep, 0, 64);
+      unsigned long long w = basep + (unsigned long long)(incl - n);
+#pragma unroll
+      for (int e = 0; e < 8; e++) if (hitmask & (1u << e)) {
+        if (w < cap) { edges[2 * w] = gi; edges[2 * w + 1] = j0 + e; }
+        w++;
+      }
+    }
+    if (lane == 0) cnt[il] = rowcnt;
+  }
+}
+
+// ------------------------------------------------------------------ K12 union-find
+__device__ __forceinline__ int uf_load(int* parent, int x) { return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ int uf_find(int* parent, int x) {
+  for (;;) {
+    const int p = uf_load(parent, x);
+    if (p == x) return x;
+    const int gp = uf_load(parent, p);
+    if (gp != p) atomicMin(&parent[x], gp);   // path halving; parents only ever decrease
+    x = p;
+  }
+}
+__device__ void uf_union(int* parent, int a, int b) {
+  for (;;) {
+    a = uf_find(parent, a); b = uf_find(parent, b);
+    if (a == b) return;
+    if (a > b) { const int t = a; a = b; b = t; }
+    if (atomicCAS(&parent[b], b, a) == b) return;   // hook the larger root under the smaller
+  }
+}
+__global__ void cc_init_kernel(const int32_t* __restrict__ cnt, int N, int min_samples, int* __restrict__ parent, int* __restrict__ lab) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < N) { parent[i] = i; lab[i] = 0x7fffffff; (void)cnt; (void)min_samples; }
+}
+__global__ void cc_union_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const int32_t* __restrict__ cnt, int min_samples,
+                                int* __restrict__ parent) {
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (unsigned long long)gridDim.x * blockDim.x) {
+    const int i = edges[2 * e], k = edges[2 * e + 1];
+    if (i != k && cnt[i] >= min_samples && cnt[k] >= min_samples) uf_union(parent, i, k);
+  }
+}
+// rootflag[i] = 1 iff i is a core point that is the root (= smallest index) of its component
+__global__ void cc_flatten_kernel(const int32_t* __restrict__ cnt, int N, int min_samples, int* __restrict__ parent, int32_t* __restrict__ rootflag) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= N) return;
+  int r = i;
+  if (cnt[i] >= min_samples) { r = uf_find(parent, i); parent[i] = r; }
+  rootflag[i] = (cnt[i] >= min_samples && r == i) ? 1 : 0;
+}
+__global__ void cc_label_core_kernel(const int32_t* __restrict__ cnt, int N, int min_samples, const int* __restrict__ parent,
+                                     const int64_t* __restrict__ rootid, int* __restrict__ lab) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < N && cnt[i] >= min_samples) lab[i] = (int)rootid[parent[i]];
+}
+__global__ void cc_border_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const int32_t* __restrict__ cnt, int min_samples,
+                                 const int* __restrict__ parent, const int64_t* __restrict__ rootid, int* __restrict__ lab) {
+  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (unsigned long long)gridDim.x * blockDim.x) {
+    const int i = edges[2 * e], k = edges[2 * e + 1];
+    if (cnt[i] >= min_samples && cnt[k] < min_samples) atomicMin(&lab[k], (int)rootid[parent[i]]);
+  }
+}
+__global__ void cc_finalize_kernel(const int* __restrict__ lab, int N, int64_t* __restrict__ labels) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < N) labels[i] = lab[i] == 0x7fffffff ? -1 : (int64_t)lab[i];
+}
+
+}  // namespace ssg
+
+using namespace ssg;
+// exscan_kernel (exclusive scan that also clears its input) comes from jaccard.hip: the
+// library is built as one translation unit (ssg_hip.hip).
+
+static MatView make_view(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value) {
+  MatView mv; mv.M = M; mv.v = v; mv.N = N; mv.row0 = row0; mv.nrows = nrows; mv.mode = mode; mv.lambda_value = lambda_value;
+  return mv;
+}
+static int check_view(const char* fn, const void* M, const uint16_t* v, int N, int row0, int nrows, int mode) {
+  if (!M || N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N || mode < 0 || mode > 2 || (mode == 0 && !v)) {
+    ssg_set_error("%s: bad matrix view (N=%d row0=%d nrows=%d mode=%d)", fn, N, row0, nrows, mode);
+    return SSG_ERR_INVALID;
+  }
+  return SSG_OK;
+}
+static int stream_grid(int nrows) { int b = (nrows + 3) / 4; return b < 4096 ? b : 4096; }
+
+extern "C" int ssg_eps_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
+                            uint64_t prefix, int shift, int width, int count_nonzero, uint64_t* hist, hipStream_t stream) {
+  int rc = check_view("ssg_eps_hist", M, v, N, row0, nrows, mode); if (rc) return rc;
+  if (width <= 0 || width > 12 || shift < 0 || shift + width > 64) { ssg_set_error("ssg_eps_hist: bad digit"); return SSG_ERR_INVALID; }
+#define SSG_HIST(MD) hipLaunchKernelGGL(eps_hist_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
+                     (unsigned long long)prefix, shift, width, count_nonzero, (unsigned long long*)hist)
+  if (mode == 0) SSG_HIST(0); else if (mode == 1) SSG_HIST(1); else SSG_HIST(2);
+#undef SSG_HIST
+  SSG_LAUNCH_CHECK("eps_hist_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_eps_compact(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
+                               uint64_t key_max, uint64_t* buf, uint64_t cap, uint64_t* cursor, hipStream_t stream) {
+  int rc = check_view("ssg_eps_compact", M, v, N, row0, nrows, mode); if (rc) return rc;
+#define SSG_COMPACT(MD) hipLaunchKernelGGL(eps_compact_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
+                     (unsigned long long)key_max, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor)
+  if (mode == 0) SSG_COMPACT(0); else if (mode == 1) SSG_COMPACT(1); else SSG_COMPACT(2);
+#undef SSG_COMPACT
+  SSG_LAUNCH_CHECK("eps_compact_kernel");
+  return SSG_OK;
+}
+
+// ascending sort of buf[0..n) (n = power of two >= 2048; pad with ~0)
+extern "C" int ssg_sort_u64(uint64_t* buf, uint64_t n, hipStream_t stream) {
+  if (n < (uint64_t)SORT_CH || (n & (n - 1))) { ssg_set_error("ssg_sort_u64: n must be a power of two >= %d", SORT_CH); return SSG_ERR_INVALID; }
+  unsigned long long* a = (unsigned long long*)buf;
+  hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(n / SORT_CH)), dim3(1024), 0, stream, a, 2ULL, (unsigned long long)SORT_CH);
+  for (unsigned long long k = 2ULL * SORT_CH; k <= n; k <<= 1) {
+    for (unsigned long long j = k >> 1; j >= (unsigned long long)SORT_CH; j >>= 1)
+      hipLaunchKernelGGL(bitonic_global_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, a, (unsigned long long)n, k, j);
+    hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(n / SORT_CH)), dim3(1024), 0, stream, a, k, k);
+  }
+  SSG_LAUNCH_CHECK("bitonic sort");
+  return SSG_OK;
+}
+
+extern "C" int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t value, hipStream_t stream) {
+  if (n1 > n0) hipLaunchKernelGGL(fill_u64_kernel, dim3(256), dim3(256), 0, stream, (unsigned long long*)buf, n0, n1, value);
+  SSG_LAUNCH_CHECK("fill_u64_kernel");
+  return SSG_OK;
+}
+
+// workspace bytes for ssg_eps_mean: leaf tables for `top` summands
+extern "C" size_t ssg_eps_mean_workspace_bytes(int64_t top) { const size_t nl = (size_t)(top / 32 + 64); return nl * (8 + 4 + 8) + 64; }
+
+extern "C" int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
+  if (top <= 0 || ws_bytes < ssg_eps_mean_workspace_bytes(top)) { ssg_set_error("ssg_eps_mean: top=%lld ws too small", (long long)top); return SSG_ERR_INVALID; }
+  const size_t nl = (size_t)(top / 32 + 64);
+  long long* leaf_off = (long long*)ws;
+  double* leaf_sum = (double*)((char*)ws + nl * 8);
+  int* leaf_n = (int*)((char*)ws + nl * 16);
+  hipLaunchKernelGGL(eps_mean_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, mode, leaf_off, leaf_n,
+                     leaf_sum, out2);
+  SSG_LAUNCH_CHECK("eps_mean_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_region_query(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps,
+                                int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
+  int rc = check_view("ssg_region_query", M, v, N, row0, nrows, mode); if (rc) return rc;
+#define SSG_RQ(MD) hipLaunchKernelGGL(region_query_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), eps, \
+                     cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor)
+  if (mode == 0) SSG_RQ(0); else if (mode == 1) SSG_RQ(1); else SSG_RQ(2);
+#undef SSG_RQ
+  SSG_LAUNCH_CHECK("region_query_kernel");
+  return SSG_OK;
+}
+
+// workspace: parent[N] int32 | lab[N] int32 | rootflag[N] int32 | rootid[N+1] int64
+extern "C" size_t ssg_dbscan_cc_workspace_bytes(int N) { return (size_t)N * 12 + ((size_t)N + 1) * 8 + 64; }
+
+extern "C" int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,
+                             int64_t* labels, hipStream_t stream) {
+  if (N <= 0 || ws_bytes < ssg_dbscan_cc_workspace_bytes(N)) { ssg_set_error("ssg_dbscan_cc: workspace too small"); return SSG_ERR_INVALID; }
+  int* parent = (int*)ws; int* lab = parent + N; int32_t* rootflag = lab + N;
+  int64_t* rootid = (int64_t*)(((uintptr_t)(rootflag + N) + 15) & ~(uintptr_t)15);
+  const int nb = (N + 255) / 256;
+  const int eb = nedges ? (int)((nedges + 255) / 256 < 8192 ? (nedges + 255) / 256 : 8192) : 1;
+  hipLaunchKernelGGL(cc_init_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, lab);
+  if (nedges) hipLaunchKernelGGL(cc_union_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, cnt, min_samples, parent);
+  hipLaunchKernelGGL(cc_flatten_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootflag);
+  hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, stream, rootflag, N, rootid);
+  hipLaunchKernelGGL(cc_label_core_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootid, lab);
+  if (nedges) hipLaunchKernelGGL(cc_border_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, cnt, min_samples, parent, rootid, lab);
+  hipLaunchKernelGGL(cc_finalize_kernel, dim3(nb), dim3(256), 0, stream, lab, N, labels);
+  SSG_LAUNCH_CHECK("dbscan_cc");
+  return SSG_OK;
+}

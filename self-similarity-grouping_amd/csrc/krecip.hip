@@ -1,0 +1,270 @@
+// krecip.hip -- K6 + K7: k-reciprocal encoding and local query expansion (sparse).
+//
+// K6 replaces reid/rerank.py:74-92: for every row i the k-reciprocal set R(i,k1), its
+// 1/2-k expansion (rule at :87), np.unique, and the Gaussian weights
+//   V[i, idx] = half(exp(-Dn[i,idx])) / half(sum)            (np.sum = pairwise float32)
+// The reference keeps V as a dense N x N half matrix; here it is a sparse row of at most
+// (k1+1)*(round(k1/2)+2) entries, sorted by column (np.unique order).
+//
+// K7 replaces reid/rerank.py:94-99:  V_qe[i,:] = half(float32 sum_{r<k2} V[rank[i,r],:] / k2),
+// a k2-way merge of sorted sparse rows with the reference's left-to-right float32 sum.
+//
+// Both are latency/LDS-bound, not HBM-bound: the rank lists (N x (k1+1) int32) and V stay
+// L2-resident; one wave per row, all set algebra in LDS with wave ballots (no block
+// barriers, rows of different lengths never wait on each other).
+#include "ssg_common.h"
+
+namespace ssg {
+
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// numpy pairwise summation order (see oracle/ssg_oracle.c pairwise_sum_f32)
+__device__ float pairwise_sum_f32(const float* a, int n) {
+  if (n < 8) { float r = 0.f; for (int i = 0; i < n; i++) r += a[i]; return r; }
+  if (n <= 128) {
+    float r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+      r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]; r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+  }
+  int n2 = n / 2; n2 -= n2 % 8;
+  return pairwise_sum_f32(a, n2) + pairwise_sum_f32(a + n2, n - n2);
+}
+
+// LDS per wave: rec[64] | expn[cap] | flag[cap] | uniq[cap] | wf[cap] (float) | wh[cap] (half)
+__global__ __launch_bounds__(256) void krecip_kernel(const hbits* __restrict__ D, const unsigned* __restrict__ rowmax,
+                                                     const int32_t* __restrict__ rank, int N, int row0, int nrows, int K, int K1,
+                                                     int kh, int cap, int32_t* __restrict__ v_idx, hbits* __restrict__ v_val,
+                                                     int32_t* __restrict__ v_nnz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int il = (int)blockIdx.x * 4 + wave;   // row within this row block
+  const size_t per_wave = 64 * 4 + (size_t)cap * 18;
+  unsigned char* wbase = smem + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
+  int32_t* rec = reinterpret_cast<int32_t*>(wbase);
+  int32_t* expn = rec + 64;
+  int32_t* flag = expn + cap;
+  int32_t* uniq = flag + cap;
+  float* wf = reinterpret_cast<float*>(uniq + cap);
+  hbits* wh = reinterpret_cast<hbits*>(wf + cap);
+  if (il >= nrows) return;
+  const int i = row0 + il;
+  const uint64_t lt = lanemask_lt();
+
+  // (a) k-reciprocal neighbours  (rerank.py:76-79)
+  const int f = lane < K1 ? rank[(int64_t)i * K + lane] : -1;
+  bool hit = false;
+  if (lane < K1) {
+    const int32_t* bw = rank + (int64_t)f * K;
+    for (int b = 0; b < K1; b++) hit |= (bw[b] == i);
+  }
+  const uint64_t rmask = __ballot(hit);
+  const int nrec = __popcll(rmask);
+  if (hit) { const int p = __popcll(rmask & lt); rec[p] = f; expn[p] = f; }
+  int ne = nrec;
+  wave_sync();
+
+  // (b) 1/2-k expansion  (rerank.py:81-88)
+  for (int a = 0; a < nrec; a++) {
+    const int cand = rec[a];
+    const int cf = lane < kh ? rank[(int64_t)cand * K + lane] : -1;
+    bool chit = false;
+    if (lane < kh) {
+      const int32_t* cb = rank + (int64_t)cf * K;
+      for (int c = 0; c < kh; c++) chit |= (cb[c] == cand);
+    }
+    const uint64_t cmask = __ballot(chit);
+    const int nc = __popcll(cmask);
+    bool inrec = false;
+    if (chit) for (int q = 0; q < nrec; q++) inrec |= (rec[q] == cf);
+    const int inter = __popcll(__ballot(inrec));
+    if ((double)inter > (2.0 / 3.0) * (double)nc) {   // len(intersect1d) > 2/3*len(candidate set)
+      if (chit) expn[ne + __popcll(cmask & lt)] = cf;
+      ne += nc;
+    }
+  }
+  wave_sync();
+
+  // (c) np.unique: sorted distinct columns  (rerank.py:90)
+  for (int p = lane; p < ne; p += 64) {
+    const int x = expn[p];
+    bool first = true;
+    for (int q = 0; q < p; q++) first &= (expn[q] != x);
+    flag[p] = first ? 1 : 0;
+  }
+  wave_sync();
+  int nu = 0;
+  for (int p0 = 0; p0 < ne; p0 += 64) {
+    const int p = p0 + lane;
+    bool isf = false;
+    if (p < ne && flag[p]) {
+      isf = true;
+      const int x = expn[p];
+      int pos = 0;
+      for (int q = 0; q < ne; q++) pos += (flag[q] && expn[q] < x);
+      uniq[pos] = x;
+    }
+    nu += __popcll(__ballot(isf));
+  }
+  wave_sync();
+
+  // (d) weights  (rerank.py:91-92); Dn[i,idx] = half(D[i,idx] / rowmax[i]) recomputed on the fly
+  const float fmx = h2f((hbits)rowmax[il]);
+  const hbits* drow = D + (int64_t)il * N;
+  for (int p = lane; p < nu; p += 64) {
+    const hbits dn = f2h(h2f(drow[uniq[p]]) / fmx);
+    const hbits w = h_exp_neg(dn);
+    wh[p] = w; wf[p] = h2f(w);
+  }
+  wave_sync();
+  float s = 0.f;
+  if (lane == 0) s = pairwise_sum_f32(wf, nu);
+  s = __shfl(s, 0, 64);
+  const hbits sum16 = f2h(s);
+  for (int p = lane; p < nu; p += 64) {
+    v_idx[(int64_t)il * cap + p] = uniq[p];
+    v_val[(int64_t)il * cap + p] = h_div(wh[p], sum16);
+  }
+  if (lane == 0) v_nnz[il] = nu;
+}
+
+// ---------------------------------------------------------------------------------- K7
+// lower_bound on a sorted int list in LDS
+__device__ __forceinline__ int lower_bound_i32(const int32_t* a, int n, int x) {
+  int lo = 0, hi = n;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+// LDS per wave: for each of k2 lists: idx[capV] int32 | val[capV] half | hpre[capV+1] int32
+__global__ __launch_bounds__(256) void query_expand_kernel(const int32_t* __restrict__ v_idx, const hbits* __restrict__ v_val,
+                                                           const int32_t* __restrict__ v_nnz, const int32_t* __restrict__ rank,
+                                                           int row0, int nrows, int K, int kk, int capV, int capQ,
+                                                           int32_t* __restrict__ q_idx, hbits* __restrict__ q_val,
+                                                           int32_t* __restrict__ q_nnz) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+  const int il = (int)blockIdx.x * 4 + wave;
+  const size_t per_list = (size_t)capV * 4 + (size_t)(capV + 1) * 4 + (((size_t)capV * 2 + 3) & ~(size_t)3);
+  const size_t per_wave = (per_list * kk + 64 + 15) & ~(size_t)15;
+  unsigned char* wbase = smem + (size_t)wave * per_wave;
+  if (il >= nrows) return;
+  const int i = row0 + il;
+  auto L_idx = [&](int r) { return reinterpret_cast<int32_t*>(wbase + per_list * r); };
+  auto L_pre = [&](int r) { return reinterpret_cast<int32_t*>(wbase + per_list * r) + capV; };
+  auto L_val = [&](int r) { return reinterpret_cast<hbits*>(wbase + per_list * r + (size_t)capV * 4 + (size_t)(capV + 1) * 4); };
+  int32_t* nn = reinterpret_cast<int32_t*>(wbase + per_list * kk);   // list lengths
+
+  // stage the kk source rows (V rows of the first k2 ranked neighbours, rerank.py:97)
+  for (int r = 0; r < kk; r++) {
+    const int src = rank[(int64_t)i * K + r];
+    const int n = v_nnz[src];
+    if (lane == 0) nn[r] = n;
+    for (int p = lane; p < n; p += 64) {
+      L_idx(r)[p] = v_idx[(int64_t)src * capV + p];
+      L_val(r)[p] = v_val[(int64_t)src * capV + p];
+    }
+  }
+  wave_sync();
+  // head flags: element (r,p) is the head of its column iff no earlier list holds the column;
+  // hpre[r][p] = number of heads among list r's first p entries
+  for (int r = 0; r < kk; r++) {
+    const int n = nn[r];
+    int run = 0;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+      const int p = p0 + lane;
+      bool head = false;
+      if (p < n) {
+        const int c = L_idx(r)[p];
+        head = true;
+        for (int r2 = 0; r2 < r; r2++) {
+          const int n2 = nn[r2];
+          const int q = lower_bound_i32(L_idx(r2), n2, c);
+          if (q < n2 && L_idx(r2)[q] == c) head = false;
+        }
+      }
+      const uint64_t hm = __ballot(head);
+      if (p < n) L_pre(r)[p] = run + __popcll(hm & lanemask_lt());
+      // remember head flag in the sign of nothing: recomputed below via hpre differences
+      run += __popcll(hm);
+    }
+    if (lane == 0) L_pre(r)[n] = run;
+  }
+  wave_sync();
+  int total = 0;
+  for (int r = 0; r < kk; r++) total += L_pre(r)[nn[r]];
+  // emit heads: output slot = number of head columns smaller than c; value = sequential
+  // float32 sum over r = 0..k2-1 (np.mean(axis=0) order), / k2, -> half
+  const float fk = (float)kk;
+  for (int r = 0; r < kk; r++) {
+    const int n = nn[r];
+    for (int p = lane; p < n; p += 64) {
+      const bool head = (L_pre(r)[p + 1] - L_pre(r)[p]) != 0;
+      if (!head) continue;
+      const int c = L_idx(r)[p];
+      int pos = 0;
+      float s = 0.f;
+      bool started = false;
+      for (int r2 = 0; r2 < kk; r2++) {
+        const int n2 = nn[r2];
+        const int q = lower_bound_i32(L_idx(r2), n2, c);
+        pos += L_pre(r2)[q];
+        const float x = (q < n2 && L_idx(r2)[q] == c) ? h2f(L_val(r2)[q]) : 0.f;
+        if (!started) { s = x; started = true; } else s += x;
+      }
+      q_idx[(int64_t)il * capQ + pos] = c;
+      q_val[(int64_t)il * capQ + pos] = f2h(s / fk);
+    }
+  }
+  if (lane == 0) q_nnz[il] = total;
+}
+
+}  // namespace ssg
+
+using namespace ssg;
+
+static inline int round_half_even_div2(int k1) { return (k1 % 2 == 0) ? k1 / 2 : ((k1 / 2) % 2 == 0 ? k1 / 2 : k1 / 2 + 1); }
+
+// capacity of one sparse V row for a given k1 (entries): (k1+1) * (round(k1/2) + 2)
+extern "C" int ssg_krecip_row_capacity(int k1) { return (k1 + 1) * (round_half_even_div2(k1) + 2); }
+
+extern "C" int ssg_krecip(const uint16_t* D, const uint32_t* rowmax, const int32_t* rank, int N, int row0, int nrows, int K, int k1,
+                          int cap, int32_t* v_idx, uint16_t* v_val, int32_t* v_nnz, hipStream_t stream) {
+  int K1 = k1 + 1; if (K1 > N) K1 = N; if (K1 > K) K1 = K;
+  int kh = round_half_even_div2(k1) + 1; if (kh > N) kh = N; if (kh > K) kh = K;
+  if (K1 <= 0 || K1 > 64 || cap < K1 + K1 * kh) {
+    ssg_set_error("ssg_krecip: need k1+1 <= 64 and cap >= %d (got %d)", K1 + K1 * kh, cap);
+    return SSG_ERR_INVALID;
+  }
+  const size_t per_wave = ((64 * 4 + (size_t)cap * 18) + 15) & ~(size_t)15;
+  const size_t lds = per_wave * 4;
+  if (lds > 160 * 1024) { ssg_set_error("ssg_krecip: k1=%d needs %zu B LDS", k1, lds); return SSG_ERR_INVALID; }
+  if (lds > 64 * 1024) SSG_HIP(hipFuncSetAttribute((const void*)krecip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(krecip_kernel, dim3((nrows + 3) / 4), dim3(256), lds, stream, D, rowmax, rank, N, row0, nrows, K, K1, kh, cap, v_idx,
+                     v_val, v_nnz);
+  SSG_LAUNCH_CHECK("krecip_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_query_expand(const int32_t* v_idx, const uint16_t* v_val, const int32_t* v_nnz, const int32_t* rank, int N, int row0,
+                                int nrows, int K, int k2, int capV, int capQ, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz,
+                                hipStream_t stream) {
+  int kk = k2; if (kk > N) kk = N; if (kk > K) kk = K;
+  if (kk <= 0 || capQ < kk * capV) { ssg_set_error("ssg_query_expand: capQ (%d) must be >= k2*capV (%d)", capQ, kk * capV); return SSG_ERR_INVALID; }
+  const size_t per_list = (size_t)capV * 4 + (size_t)(capV + 1) * 4 + (((size_t)capV * 2 + 3) & ~(size_t)3);
+  const size_t per_wave = (per_list * kk + 64 + 15) & ~(size_t)15;
+  const size_t lds = per_wave * 4;
+  if (lds > 160 * 1024) { ssg_set_error("ssg_query_expand: k2=%d capV=%d needs %zu B LDS", k2, capV, lds); return SSG_ERR_INVALID; }
+  if (lds > 64 * 1024) SSG_HIP(hipFuncSetAttribute((const void*)query_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(query_expand_kernel, dim3((nrows + 3) / 4), dim3(256), lds, stream, v_idx, v_val, v_nnz, rank, row0, nrows, K, kk, capV,
+                     capQ, q_idx, q_val, q_nnz);
+  SSG_LAUNCH_CHECK("query_expand_kernel");
+  return SSG_OK;
+}

@@ -1,0 +1,238 @@
+// pairwise.hip -- K3/K4: squared-L2 distance blocks on the FP64 matrix cores.
+//
+// Replaces scipy cdist under reid/rerank.py:36-40 (target x source term) and
+// reid/rerank.py:33,61-62 (target x target "original distance").  The reference takes
+// sqrt(sum (x-y)^2) in float64 and rounds to half; to reproduce those half values the
+// Gram form  d2 = (|x|^2 + |y|^2) - 2 x.y  is evaluated in float64 on
+// v_mfma_f64_16x16x4_f64 (MFMA-bound, 2*M*N*d flop).  Row norms are taken from the SAME
+// instruction sequence (norm_kernel) so duplicate rows give d2 == 0 exactly, like cdist.
+//
+// Block tile 128x128, BK=32, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles (16 f64
+// accumulators x4 = 128 VGPRs).  Operands are converted f32 -> (half ->) f64 while being
+// staged into LDS in [k][row] order with a 16-double pad per k-row: fragment reads
+// (ds_read_b64, lane = row + 16*k) are bank-conflict free.
+#include "ssg_common.h"
+
+namespace ssg {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDR = 144;  // LDR: padded rows per k slice
+
+template <bool ROUND16>
+__device__ __forceinline__ double cvt_in(float x) {
+  return ROUND16 ? (double)h2f(f2h(x)) : (double)x;
+}
+
+// block b runs on XCD b%8 (observed); give each XCD a contiguous run of tiles so that
+// neighbouring tiles (same A row-panel) share that XCD's L2.  Bijective for any count.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+  const int nx = 8, q = nwg / nx, r = nwg % nx, x = b % nx, s = b / nx;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+// norms[i] = sum_k x_ik^2 with the accumulation order of gram_kernel (diagonal of the
+// Gram block).  One wave per 16 rows.
+template <bool ROUND16>
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ X, int n, int d, double* __restrict__ norms) {
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = lane_id();
+  const int r0 = wave * 16;
+  if (r0 >= n) return;
+  const int row = r0 + (lane & 15), ko = lane >> 4;
+  const bool ok = row < n;
+  const float* xr = X + (int64_t)row * d;
+  v4d acc = {0., 0., 0., 0.};
+  for (int k0 = 0; k0 < d; k0 += 4) {
+    const int k = k0 + ko;
+    const double x = (ok && k < d) ? cvt_in<ROUND16>(xr[k]) : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+  }
+  // C/D layout of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg
+  const int c = lane & 15;
+  if ((lane >> 4) == (c & 3) && ok) {
+    const int r = c >> 2;
+    norms[row] = r == 0 ? acc[0] : r == 1 ? acc[1] : r == 2 ? acc[2] : acc[3];
+  }
+}
+
+// MODE 0 (self):  A = B-side of the same set, inputs rounded to half; writes
+//                 D[i,j] = half(half(sqrt(d2))^2) and atomicMax rowmax[i].
+// MODE 1 (cross): A = target f32, B = source f32; atomicMin rowmin[i] of half(sqrt(d2)^2).
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      const double* __restrict__ nA, const double* __restrict__ nB,
+                                                      int M, int N, int d, int rowA0, hbits* __restrict__ D,
+                                                      unsigned* __restrict__ rowred) {
+  constexpr bool R16 = (MODE == 0);
+  __shared__ double As[BK * LDR];
+  __shared__ double Bs[BK * LDR];
+  const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
+  const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // staging map: one row per thread, 16 consecutive k (4 x float4)
+  const int srow = tid & 127, shalf = tid >> 7;
+  const int arow = tm * BM + srow, brow = tn * BN + srow;
+  const float* ap = A + (int64_t)(arow < M ? arow : 0) * d;
+  const float* bp = B + (int64_t)(brow < N ? brow : 0) * d;
+  const bool aok = arow < M, bok = brow < N;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0., 0., 0., 0.};
+
+  float4 pa[4], pb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = kt * BK + shalf * 16 + q * 4;
+      pa[q] = (aok && k < d) ? *reinterpret_cast<const float4*>(ap + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[q] = (bok && k < d) ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  const int nk = (d + BK - 1) / BK;
+  gload(0);
+  const int l16 = lane & 15, lk = lane >> 4;
+  for (int kt = 0; kt < nk; kt++) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = shalf * 16 + q * 4;
+      As[(k + 0) * LDR + srow] = cvt_in<R16>(pa[q].x);
+      As[(k + 1) * LDR + srow] = cvt_in<R16>(pa[q].y);
+      As[(k + 2) * LDR + srow] = cvt_in<R16>(pa[q].z);
+      As[(k + 3) * LDR + srow] = cvt_in<R16>(pa[q].w);
+      Bs[(k + 0) * LDR + srow] = cvt_in<R16>(pb[q].x);
+      Bs[(k + 1) * LDR + srow] = cvt_in<R16>(pb[q].y);
+      Bs[(k + 2) * LDR + srow] = cvt_in<R16>(pb[q].z);
+      Bs[(k + 3) * LDR + srow] = cvt_in<R16>(pb[q].w);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);  // next tile's HBM/L2 latency hides under the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+      const int k = kk * 4 + lk;
+      double a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) a[i] = As[k * LDR + wm * 64 + i * 16 + l16];
+#pragma unroll
+      for (int j = 0; j < 4; j++) b[j] = Bs[k * LDR + wn * 64 + j * 16 + l16];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue.  f64 MFMA C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int li = tm * BM + wm * 64 + i * 16 + lk + 4 * r;  // row within this call
+      const bool rok = li < M;
+      const double ni = rok ? nA[li] : 0.0;
+      unsigned red = MODE == 0 ? 0u : 0xffffffffu;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int gj = tn * BN + wn * 64 + j * 16 + l16;
+        if (rok && gj < N) {
+          double s = (ni + nB[gj]) - 2.0 * acc[i][j][r];
+          s = s > 0.0 ? s : 0.0;
+          if (MODE == 0) {
+            if (rowA0 + li == gj) s = 0.0;             // cdist(x, x) diagonal is exactly 0
+            const hbits h = d2h(sqrt(s));               // cdist(...).astype(float16)   rerank.py:61
+            const hbits dd = h_mul(h, h);               // np.power(half, 2)            rerank.py:62
+            D[(int64_t)li * N + gj] = dd;
+            red = red > dd ? red : (unsigned)dd;
+          } else {
+            const double dist = sqrt(s);
+            const hbits h = d2h(dist * dist);           // np.power(cdist, 2).astype(float16)  rerank.py:36-37
+            red = red < h ? red : (unsigned)h;
+          }
+        }
+      }
+#pragma unroll
+      for (int sh = 1; sh < 16; sh <<= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)red, sh, 64);
+        red = MODE == 0 ? (red > o ? red : o) : (red < o ? red : o);
+      }
+      if (l16 == 0 && rok) {
+        if (MODE == 0) atomicMax(&rowred[li], red); else atomicMin(&rowred[li], red);
+      }
+    }
+  }
+}
+
+__global__ void fill_u32_kernel(unsigned* p, int n, unsigned v) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i < n) p[i] = v;
+}
+
+// rerank.py:38-40 tail: v_raw = half(1 - exp(-minh)); v = v_raw / max(v_raw).
+// (1-exp(-x) is monotone in x, so min_s f(x_s) == f(min_s x_s).)  Single block.
+__global__ __launch_bounds__(1024) void source_vec_finish_kernel(const unsigned* __restrict__ rowmin, int N,
+                                                                  hbits* __restrict__ v, unsigned* __restrict__ max_bits) {
+  __shared__ unsigned smax[16];
+  unsigned m = 0;
+  for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) {
+    const hbits o = h_sub(H_ONE, h_exp_neg((hbits)rowmin[i]));
+    v[i] = o;
+    m = m > o ? m : (unsigned)o;  // values are >= 0: bit order == value order
+  }
+  for (int sh = 1; sh < 64; sh <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, sh, 64); m = m > o ? m : o; }
+  if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (int w = 1; w < (int)(blockDim.x >> 6); w++) m = m > smax[w] ? m : smax[w]; smax[0] = m; *max_bits = m; }
+  __syncthreads();
+  const hbits mx = (hbits)smax[0];
+  for (int i = (int)threadIdx.x; i < N; i += (int)blockDim.x) v[i] = h_div(v[i], mx);
+}
+
+}  // namespace ssg
+
+using namespace ssg;
+
+extern "C" int ssg_row_norms_f64(const float* x, int n, int d, int round_to_half, double* norms, hipStream_t stream) {
+  if (n <= 0 || d <= 0) { ssg_set_error("ssg_row_norms_f64: empty input"); return SSG_ERR_INVALID; }
+  const int waves = (n + 15) / 16, blocks = (waves + 3) / 4;
+  if (round_to_half) hipLaunchKernelGGL(norm_kernel<true>, dim3(blocks), dim3(256), 0, stream, x, n, d, norms);
+  else hipLaunchKernelGGL(norm_kernel<false>, dim3(blocks), dim3(256), 0, stream, x, n, d, norms);
+  SSG_LAUNCH_CHECK("norm_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int row0, int nrows, uint16_t* D,
+                                   uint32_t* rowmax, hipStream_t stream) {
+  if (N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N || (d & 3)) {
+    ssg_set_error("ssg_sqdist_self_f16: bad shape N=%d d=%d row0=%d nrows=%d (d must be a multiple of 4)", N, d, row0, nrows);
+    return SSG_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, rowmax, nrows, 0u);
+  const int tiles = ((nrows + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipLaunchKernelGGL(gram_kernel<0>, dim3(tiles), dim3(256), 0, stream, x + (int64_t)row0 * d, x, norms + row0, norms, nrows, N, d,
+                     row0, D, rowmax);
+  SSG_LAUNCH_CHECK("gram_kernel<self>");
+  return SSG_OK;
+}
+
+extern "C" int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const float* src, const double* nsrc, int nrows, int Ns, int d,
+                                     uint32_t* rowmin, hipStream_t stream) {
+  if (nrows <= 0 || Ns <= 0 || (d & 3)) { ssg_set_error("ssg_source_rowmin_f16: bad shape"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(fill_u32_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, rowmin, nrows, 0xffffffffu);
+  const int tiles = ((nrows + BM - 1) / BM) * ((Ns + BN - 1) / BN);
+  hipLaunchKernelGGL(gram_kernel<1>, dim3(tiles), dim3(256), 0, stream, tgt, src, ntgt, nsrc, nrows, Ns, d, 0, (uint16_t*)nullptr, rowmin);
+  SSG_LAUNCH_CHECK("gram_kernel<cross>");
+  return SSG_OK;
+}
+
+extern "C" int ssg_source_vec_finish(const uint32_t* rowmin, int N, uint16_t* v, uint32_t* max_bits, hipStream_t stream) {
+  if (N <= 0) { ssg_set_error("ssg_source_vec_finish: N<=0"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(source_vec_finish_kernel, dim3(1), dim3(1024), 0, stream, rowmin, N, v, max_bits);
+  SSG_LAUNCH_CHECK("source_vec_finish_kernel");
+  return SSG_OK;
+}

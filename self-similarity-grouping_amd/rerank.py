@@ -1,0 +1,208 @@
+"""k-reciprocal re-ranking on MI355X -- host-side mirror of reid/rerank.py.
+
+`re_ranking` keeps the reference signature and return types (reid/rerank.py:27,66,127):
+numpy float32 features in, `(euclidean_dist float16 [N,N], final_dist float64 [N,N] | None)`
+out, three progress prints.  The work runs as hand-written HIP kernels (csrc/*.hip) through
+the C ABI of include/ssg_hip.h; the only N x N objects that live in HBM are the half
+matrices D (original distance) and J' (scaled Jaccard), see DESIGN.md.
+
+`re_ranking_device` is the fused path used by `compute_dist` -> `generate_selflabel`: it
+returns a `DistHandle` that stays on the GPU (no f64 N x N materialisation, no D2H).
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+_PAD = 32  # feature dim is zero-padded to a multiple of the Gram kernel's K step
+
+
+class ReRankNaNError(ValueError):
+    """max(source_dist_vec) == 0: the reference divides 0/0 at reid/rerank.py:40 and silently
+    returns an all-NaN final_dist (sklearn then rejects the NaN eps).  Raised explicitly here."""
+
+
+class DistHandle:
+    """Device-resident result of one re_ranking call (one feature split).
+
+    mode 0: final_dist[i,k] = f64(Jp[i,k]) + f64(half(v[i]+v[k])) * lambda   (rerank.py:122)
+    mode 1: no-rerank: the half euclidean matrix itself (rerank.py:65-66)
+    mode 2: an arbitrary float64 matrix uploaded by the caller (sklearn drop-in case)
+    Rows [row0, row0+nrows) of the N x N problem are held locally (row-block sharding).
+    """
+
+    def __init__(self, N, mode, M, v=None, lambda_value=0.0, euclid=None, row0=0, nrows=None, group=None):
+        self.N, self.mode, self.M, self.v, self.lambda_value = int(N), int(mode), M, v, float(lambda_value)
+        self.euclid = euclid
+        self.row0, self.nrows = int(row0), int(N if nrows is None else nrows)
+        self.group = group   # torch.distributed group when the rows are sharded over ranks
+
+    @property
+    def device(self):
+        return self.M.device
+
+    def final_dist(self):
+        """float64 [nrows, N] device tensor (API materialisation, 8 bytes/entry)."""
+        L = _lib.lib()
+        if self.mode == 2:
+            return self.M
+        if self.mode == 1:
+            return self.M.to(torch.float64)
+        out = torch.empty((self.nrows, self.N), dtype=torch.float64, device=self.device)
+        check(L.ssg_final_dist_f64(ptr(self.M), ptr(self.v), self.N, self.row0, self.nrows, self.lambda_value, ptr(out), stream()),
+              "ssg_final_dist_f64")
+        return out
+
+
+class DeviceBackedArray(np.ndarray):
+    """numpy view of a materialised distance matrix that remembers its device handle, so
+    `DBSCAN.fit_predict(final_dist)` / `generate_selflabel` can skip the re-upload."""
+    ssg_handle = None
+
+    def __array_finalize__(self, obj):
+        self.ssg_handle = getattr(obj, "ssg_handle", None) if (obj is not None and getattr(obj, "shape", None) == self.shape) else None
+
+
+def _as_dev_f32(x, device):
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    x = x.to(device=device, dtype=torch.float32).contiguous()
+    d = x.shape[1]
+    if d % _PAD:
+        x = torch.nn.functional.pad(x, (0, _PAD - d % _PAD))   # zeros add +0.0 exactly to every distance
+    return x
+
+
+def source_vector(src, tgt, row0=0, nrows=None):
+    """reid/rerank.py:35-40 on device -> (rowmin uint32-as-int32 [nrows]) for a row block."""
+    L = _lib.lib()
+    N, d = tgt.shape
+    nrows = N if nrows is None else nrows
+    ntgt = torch.empty(N, dtype=torch.float64, device=tgt.device)
+    nsrc = torch.empty(src.shape[0], dtype=torch.float64, device=tgt.device)
+    check(L.ssg_row_norms_f64(ptr(tgt), N, d, 0, ptr(ntgt), stream()), "ssg_row_norms_f64")
+    check(L.ssg_row_norms_f64(ptr(src), src.shape[0], d, 0, ptr(nsrc), stream()), "ssg_row_norms_f64")
+    rowmin = torch.empty(nrows, dtype=torch.int32, device=tgt.device)
+    tblk = tgt[row0:row0 + nrows]
+    check(L.ssg_source_rowmin_f16(ptr(tblk), ptr(ntgt[row0:]), ptr(src), ptr(nsrc), nrows, src.shape[0], d, ptr(rowmin), stream()),
+          "ssg_source_rowmin_f16")
+    return rowmin
+
+
+def _gather_rows(t, group):
+    """all-gather equally-sized row blocks over the RCCL/gloo group (no-op without a group)."""
+    if group is None:
+        return t
+    import torch.distributed as dist
+    ws = dist.get_world_size(group)
+    out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, keep_euclid=True, row0=0, nrows=None,
+                      group=None, stages=None):
+    """Fused device pipeline K3..K9 for one feature split.
+
+    src [Ns,d], tgt [N,d]: float32 CUDA tensors (replicated on every rank of `group`).
+    With a group, each rank computes rows [row0,row0+nrows) and the small tables (rank
+    lists, sparse V / V_qe, v) are all-gathered; N must divide evenly by the world size.
+    `stages` (dict) receives intermediate tensors for parity tests.
+    """
+    L = _lib.lib()
+    dev = tgt.device
+    N = tgt.shape[0]
+    nrows = N if nrows is None else nrows
+    if N < 2:
+        raise ValueError("re_ranking needs at least 2 target samples")
+    src = _as_dev_f32(src, dev); tgt = _as_dev_f32(tgt, dev)
+    d = tgt.shape[1]
+    st = stream()
+
+    # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
+    norms = torch.empty(N, dtype=torch.float64, device=dev)
+    check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
+    D = torch.empty((nrows, N), dtype=torch.float16, device=dev)
+    rowmax = torch.empty(nrows, dtype=torch.int32, device=dev)
+    check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
+    if no_rerank:
+        return DistHandle(N, 1, D, euclid=D, row0=row0, nrows=nrows, group=group)
+
+    # ---- source-domain term (rerank.py:35-40): v half [N]
+    rowmin = _gather_rows(source_vector(src, tgt, row0, nrows), group)
+    v = torch.empty(N, dtype=torch.float16, device=dev)
+    vmax = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
+
+    # ---- initial ranking (rerank.py:68-70)
+    K = min(k1 + 1, N)
+    rank_blk = torch.empty((nrows, K), dtype=torch.int32, device=dev)
+    check(L.ssg_topk_rank(ptr(D), ptr(rowmax), N, nrows, K, ptr(rank_blk), st), "ssg_topk_rank")
+    rank = _gather_rows(rank_blk, group)
+
+    # ---- k-reciprocal encoding (rerank.py:74-92)
+    capV = int(L.ssg_krecip_row_capacity(k1))
+    v_idx = torch.empty((nrows, capV), dtype=torch.int32, device=dev)
+    v_val = torch.empty((nrows, capV), dtype=torch.float16, device=dev)
+    v_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
+    check(L.ssg_krecip(ptr(D), ptr(rowmax), ptr(rank), N, row0, nrows, K, k1, capV, ptr(v_idx), ptr(v_val), ptr(v_nnz), st), "ssg_krecip")
+    v_idx, v_val, v_nnz = _gather_rows(v_idx, group), _gather_rows(v_val, group), _gather_rows(v_nnz, group)
+
+    # ---- local query expansion (rerank.py:94-99)
+    if k2 != 1:
+        kk = min(k2, N, K)
+        capQ = kk * capV
+        q_idx = torch.empty((nrows, capQ), dtype=torch.int32, device=dev)
+        q_val = torch.empty((nrows, capQ), dtype=torch.float16, device=dev)
+        q_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
+        check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, ptr(q_idx), ptr(q_val),
+                                 ptr(q_nnz), st), "ssg_query_expand")
+        q_idx, q_val, q_nnz = _gather_rows(q_idx, group), _gather_rows(q_val, group), _gather_rows(q_nnz, group)
+    else:
+        capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
+
+    # ---- inverted index + Jaccard rows (rerank.py:101-122)
+    total = int(q_nnz.sum().item())
+    colcnt = torch.empty(N, dtype=torch.int32, device=dev)
+    colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    inv_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+    inv_val = torch.empty(max(total, 1), dtype=torch.float16, device=dev)
+    check(L.ssg_invert_index(ptr(q_idx), ptr(q_val), ptr(q_nnz), N, N, capQ, ptr(colcnt), ptr(colptr), ptr(inv_row), ptr(inv_val), st),
+          "ssg_invert_index")
+    om = L.ssg_double_to_half_bits(1.0 - float(lambda_value))
+    Jp = torch.empty((nrows, N), dtype=torch.float16, device=dev)
+    check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), N, row0, nrows, om, ptr(Jp), st),
+          "ssg_jaccard_rows")
+
+    if int(vmax.item()) & 0x7FFF == 0:
+        raise ReRankNaNError("max(source_dist_vec) == 0: every target->source 1-exp(-d^2) rounds to 0 in float16; the reference "
+                             "(reid/rerank.py:40) would return an all-NaN final_dist")
+    if stages is not None:
+        stages.update(D=D, rowmax=rowmax, v=v, rank=rank, v_idx=v_idx, v_val=v_val, v_nnz=v_nnz, q_idx=q_idx, q_val=q_val, q_nnz=q_nnz,
+                      colptr=colptr, inv_row=inv_row, inv_val=inv_val, Jp=Jp)
+    return DistHandle(N, 0, Jp, v=v, lambda_value=lambda_value, euclid=D if keep_euclid else None, row0=row0, nrows=nrows, group=group)
+
+
+def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.2, MemorySave=False, Minibatch=2000, no_rerank=False,
+               device=None):
+    """Drop-in for reid/rerank.py:27 re_ranking (numpy in, numpy out).
+
+    MemorySave / Minibatch are accepted for signature compatibility; row chunking is not
+    needed on a 288 GB device.  Tie order of the initial ranking is the canonical
+    (value, index) order (numpy argsort kind='stable'), see DESIGN.md "ties".
+    """
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    print('computing source distance...')
+    print('computing original distance...')
+    src = _as_dev_f32(np.asarray(input_feature_source), device)
+    tgt = _as_dev_f32(np.asarray(input_feature), device)
+    if not no_rerank:
+        print('starting re_ranking...')
+    h = re_ranking_device(src, tgt, k1=k1, k2=k2, lambda_value=lambda_value, no_rerank=no_rerank)
+    euclid = h.euclid.cpu().numpy()
+    if no_rerank:
+        return euclid, None
+    final = h.final_dist().cpu().numpy().view(DeviceBackedArray)
+    final.ssg_handle = h
+    return euclid, final

@@ -1,0 +1,79 @@
+"""Host-side mirror of the grouping helpers of selftraining.py (reference :255-313).
+
+`compute_dist` and `generate_selflabel` keep the reference's names, argument order and
+return structure so that selftraining.py can import them instead of its own definitions
+(INTEGRATION.md).  Differences, all deliberate and documented in DESIGN.md:
+  * distances stay on the GPU as `DistHandle`s unless `materialize=True`;
+  * with no_rerank=True the euclidean matrices are kept (the reference discards them at
+    selftraining.py:260-266 and then crashes in generate_selflabel on `[]`);
+  * the cached "cluster" objects are `ssg_amd.cluster.DBSCAN` instances (eps frozen after
+    iteration 0 exactly like selftraining.py:283-298).
+"""
+import numpy as np
+import torch
+
+from .cluster import DBSCAN, as_handle, eps_rule
+from .rerank import DeviceBackedArray, re_ranking_device
+
+
+def _dev():
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def compute_dist(source_features, target_features, lambda_value, no_rerank, num_split=2, materialize=False, group=None):
+    """selftraining.py:255-277.  Features: torch tensors (CPU or CUDA) or numpy arrays,
+    a list of S+1 per-split tensors or a single tensor.  Returns (euclidean_dist_list,
+    rerank_dist_list) with one entry per split."""
+    euclidean_dist_list, rerank_dist_list = [], []
+    if not isinstance(source_features, list):
+        source_features, target_features = [source_features], [target_features]
+    dev = _dev()
+    for s, t in zip(source_features, target_features):
+        s = torch.as_tensor(s).to(dev, torch.float32); t = torch.as_tensor(t).to(dev, torch.float32)
+        row0, nrows = 0, None
+        if group is not None:
+            import torch.distributed as dist
+            ws, rk = dist.get_world_size(group), dist.get_rank(group)
+            if t.shape[0] % ws:
+                raise ValueError("row-block sharding needs N (%d) divisible by the world size (%d)" % (t.shape[0], ws))
+            nrows = t.shape[0] // ws; row0 = rk * nrows
+        h = re_ranking_device(s, t, lambda_value=lambda_value, no_rerank=no_rerank, keep_euclid=no_rerank, row0=row0, nrows=nrows, group=group)
+        if materialize:
+            if no_rerank:
+                euclidean_dist_list.append(h.euclid.cpu().numpy()); rerank_dist_list.append(None)
+            else:
+                f = h.final_dist().cpu().numpy().view(DeviceBackedArray); f.ssg_handle = h
+                euclidean_dist_list.append([]); rerank_dist_list.append(f)
+        else:
+            euclidean_dist_list.append(h if no_rerank else [])
+            rerank_dist_list.append(None if no_rerank else h)
+    return euclidean_dist_list, rerank_dist_list
+
+
+def generate_selflabel(e_dist, r_dist, n_iter, args, cluster_list=[]):   # noqa: B006 (mutable default kept: reference :280)
+    """selftraining.py:280-313: eps rule at iteration 0 (estimator cached, eps frozen), then
+    `cluster.fit_predict` per split.  `args` needs `.no_rerank` and `.rho`."""
+    labels_list = []
+    for s in range(len(r_dist)):
+        tmp_dist = e_dist[s] if args.no_rerank else r_dist[s]
+        if n_iter == 0:
+            eps, _, _ = eps_rule(tmp_dist, args.rho)
+            print('eps in cluster: {:.3f}'.format(eps))
+            cluster = DBSCAN(eps=eps, min_samples=4, metric='precomputed', n_jobs=8)
+            cluster_list.append(cluster)
+        else:
+            cluster = cluster_list[s]
+        print('Clustering and labeling...')
+        labels = cluster.fit_predict(tmp_dist)
+        num_ids = len(set(labels.tolist())) - 1
+        print('Iteration {} have {} training ids'.format(n_iter + 1, num_ids))
+        labels_list.append(labels)
+    return labels_list, cluster_list
+
+
+def select_labeled(labels_list):
+    """selftraining.py:315-324 join: keep sample i iff no split labelled it -1.
+    Returns (kept indices, [per-split label lists])."""
+    lab = np.stack([np.asarray(l) for l in labels_list], axis=1)
+    keep = np.nonzero((lab != -1).all(axis=1))[0]
+    return keep, lab[keep]

@@ -1,0 +1,45 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope="session")
+def ora():
+    from oracle import ssg_oracle
+    ssg_oracle.build()
+    return ssg_oracle
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint16) if a.dtype == np.float16 else a
+
+
+def clustered(N, d, seed, per_id=16, intra=0.5):
+    """Track-G synthetic embeddings, same generator as tools/make_golden.py."""
+    rng = np.random.default_rng(seed)
+    P = max(1, N // per_id)
+    c = rng.standard_normal((P, d)); c /= np.linalg.norm(c, axis=1, keepdims=True)
+    sigma = np.sqrt(intra / 2.0 / d)
+    ids = np.arange(N) % P
+    x = c[ids] + sigma * rng.standard_normal((N, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)

@@ -1,0 +1,69 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/ssg_hip.h declares, and
+its argument validation / host-only helpers work without a GPU (no compute is launched)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import ssg_amd
+from ssg_amd import _lib
+
+
+def test_library_is_built_and_exports_header_symbols():
+    assert os.path.exists(_lib.SO_PATH), "run __graft_entry__.build() first"
+    protos = _lib.parse_header()
+    assert len(protos) >= 25
+    raw = ctypes.CDLL(_lib.SO_PATH)
+    for name in protos:
+        assert hasattr(raw, name), "libssg_hip.so does not export %s" % name
+    assert _lib.lib().ssg_version() >= 100
+
+
+def test_host_helpers():
+    L = _lib.lib()
+    for x in [0.9, 0.7, 1.0, 0.0, 1e-8, 65504.0, 65520.0, 1e9, -0.3, 2.0 ** -25, 2.0 ** -25 * 1.0000001, 0.1 + 0.2]:
+        assert L.ssg_double_to_half_bits(x) == np.float64(x).astype(np.float16).view(np.uint16), x
+    rng = np.random.default_rng(0)
+    for x in rng.standard_normal(2000) * 10.0 ** rng.integers(-9, 6, 2000):
+        assert L.ssg_double_to_half_bits(float(x)) == np.float64(x).astype(np.float16).view(np.uint16)
+    assert L.ssg_krecip_row_capacity(20) == 21 * 12       # (k1+1) * (round(k1/2)+2)
+    assert L.ssg_krecip_row_capacity(5) == 6 * 4           # np.around(2.5) == 2
+
+
+def test_argument_validation_without_gpu():
+    L = _lib.lib()
+    assert L.ssg_topk_rank(None, None, 10, 10, 65, None, None) == -1
+    assert b"K" in L.ssg_last_error()
+    assert L.ssg_sqdist_self_f16(None, None, 8, 6, 0, 8, None, None, None) == -1     # d % 4 != 0
+    assert L.ssg_sort_u64(None, 1000, None) == -1
+    assert L.ssg_krecip(None, None, None, 100, 0, 100, 21, 20, 10, None, None, None, None) == -1   # cap too small
+    assert L.ssg_eps_hist(None, None, 10, 0, 10, 0, 0.1, 0, 51, 12, 1, None, None) == -1
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+
+
+def test_no_cpu_fallback(monkeypatch):
+    """The product path must fail loudly when the HIP extension is missing."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libssg_hip.so")
+    with pytest.raises(ssg_amd.SSGError):
+        _lib.lib()
+
+
+def test_dbscan_parameter_errors():
+    from ssg_amd import DBSCAN
+    for bad in (float("nan"), -1.0, 0.0, "x"):
+        with pytest.raises(ValueError):
+            DBSCAN(eps=bad, min_samples=4, metric="precomputed").fit(np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        DBSCAN(eps=0.5, min_samples=4, metric="euclidean").fit(np.zeros((2, 2)))
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(os.path.abspath(_lib.__file__))
+    for dp, _, files in os.walk(root):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "ssg_oracle" not in txt.replace("oracle/ssg_oracle.c", ""), f

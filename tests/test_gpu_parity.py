@@ -1,0 +1,262 @@
+"""GPU suite (-m gpu): the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors of the reference.  Integer / half / label work is compared BIT-EXACT; there is
+no floating-point tolerance anywhere in this file except where stated."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits, clustered
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ssg_amd import _lib
+    return _lib.lib()
+
+
+def _sparse_to_dense(idx, val, nnz, N):
+    idx = idx.cpu().numpy(); val = val.cpu().numpy().view(np.uint16); nnz = nnz.cpu().numpy()
+    out = np.zeros((idx.shape[0], N), np.uint16)
+    for i in range(idx.shape[0]):
+        n = int(nnz[i])
+        assert np.all(np.diff(idx[i, :n]) > 0), "sparse row %d not sorted by column" % i
+        out[i, idx[i, :n]] = val[i, :n]
+    return out
+
+
+# ------------------------------------------------------------------ exhaustive half functions
+@pytest.mark.parametrize("which", [0, 1, 2, 3, 4])
+def test_half_function_tables(which, L, dev, ora):
+    from ssg_amd._lib import check, ptr, stream
+    out = torch.empty(65536, dtype=torch.int16, device=dev)
+    check(L.ssg_selftest_half_table(which, ptr(out), stream()), "selftest")
+    got = out.cpu().numpy().view(np.uint16)
+    allh = np.arange(65536, dtype=np.uint16).view(np.float16)
+    with np.errstate(all="ignore"):
+        if which == 0:
+            ref = ora.half_exp_table().view(np.uint16)
+        elif which == 1:   # 1 - exp(-x)
+            e = ora.half_exp_table().view(np.uint16)[(np.arange(65536) ^ 0x8000)].view(np.float16)
+            ref = (np.float16(1) - e).view(np.uint16)
+        elif which == 2:
+            ref = np.power(allh, 2).view(np.uint16)
+        elif which == 3:
+            ref = (1 - allh / (2 - allh)).view(np.uint16)
+        else:
+            ref = np.sqrt(allh.astype(np.float64)).astype(np.float16).view(np.uint16)
+    nan = np.isnan(got.view(np.float16)) & np.isnan(ref.view(np.float16))
+    bad = np.nonzero((got != ref) & ~nan)[0]
+    assert len(bad) == 0, [(hex(i), hex(got[i]), hex(ref[i])) for i in bad[:8]]
+
+
+def test_half_binops_and_d2h(L, dev):
+    from ssg_amd._lib import check, ptr, stream
+    rng = np.random.default_rng(0)
+    n = 1 << 20
+    a = rng.integers(0, 0x7C00, n).astype(np.uint16); b = rng.integers(1, 0x7C00, n).astype(np.uint16)
+    ta = torch.from_numpy(a.view(np.int16)).to(dev); tb = torch.from_numpy(b.view(np.int16)).to(dev)
+    out = torch.empty(n, dtype=torch.int16, device=dev)
+    fa, fb = a.view(np.float16), b.view(np.float16)
+    with np.errstate(all="ignore"):
+        refs = [fa + fb, fa / fb, fa * fb, fa - fb]
+    for which, ref in enumerate(refs):
+        check(L.ssg_selftest_half_binop(which, ptr(ta), ptr(tb), n, ptr(out), stream()), "binop")
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), ref.view(np.uint16)), which
+    x = np.concatenate([rng.standard_normal(n) * 10.0 ** rng.integers(-9, 6, n), rng.random(n) * 4,
+                        (rng.integers(0, 0x7C00, n).astype(np.uint16).view(np.float16).astype(np.float64)) * (1 + 2.0 ** -12)])
+    tx = torch.from_numpy(x).to(dev)
+    out = torch.empty(x.size, dtype=torch.int16, device=dev)
+    check(L.ssg_selftest_d2h(ptr(tx), x.size, ptr(out), stream()), "d2h")
+    with np.errstate(all="ignore"):
+        assert np.array_equal(out.cpu().numpy().view(np.uint16), x.astype(np.float16).view(np.uint16))
+
+
+def test_sort_u64(L, dev):
+    from ssg_amd._lib import check, ptr, stream
+    rng = np.random.default_rng(1)
+    for n in (2048, 4096, 1 << 15, 1 << 18):
+        a = rng.integers(0, 2 ** 62, n, dtype=np.int64)
+        a[: n // 4] = a[0]
+        t = torch.from_numpy(a).to(dev)
+        check(L.ssg_sort_u64(ptr(t), n, stream()), "sort")
+        assert np.array_equal(t.cpu().numpy(), np.sort(a))
+
+
+# ------------------------------------------------------------------ pairwise distance (K3/K4)
+@pytest.mark.parametrize("N,Ns,d", [(300, 77, 96), (129, 260, 40), (1024, 512, 256)])
+def test_pairwise_vs_oracle(N, Ns, d, dev, ora):
+    from ssg_amd import rerank
+    tgt = clustered(N, d, 3); src = clustered(Ns, d, 4, intra=0.7)
+    tgt[7] = tgt[2]                                     # exact duplicate rows -> exact zero distance
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), no_rerank=True)
+    D = h.euclid.cpu().numpy()
+    ref = ora.euclid(tgt)
+    assert np.array_equal(bits(D), bits(ref))
+    assert np.array_equal(D, D.T) and np.all(np.diag(D) == 0) and D[7, 2] == 0
+    rowmin = rerank.source_vector(rerank._as_dev_f32(src, dev), rerank._as_dev_f32(tgt, dev))
+    v_raw, v, mx = ora.source_vec(tgt, src)
+    # rowmin holds half(d^2) bits; v_raw = 1-exp(-min) (monotone) -> compare through the finish kernel
+    from ssg_amd._lib import check, ptr, stream, lib
+    vv = torch.empty(N, dtype=torch.float16, device=dev); vm = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().ssg_source_vec_finish(ptr(rowmin), N, ptr(vv), ptr(vm), stream()), "finish")
+    assert np.array_equal(bits(vv.cpu().numpy()), bits(v))
+    assert int(vm.item()) == int(np.float16(mx).view(np.uint16))
+
+
+# ------------------------------------------------------------------ full re-rank, stage by stage
+RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_*_stable.npz")))
+
+
+@pytest.mark.parametrize("name", RERANK)
+def test_rerank_stages_vs_reference_golden(name, golden, dev, ora):
+    """HIP path vs the reference's own outputs (golden, argsort pinned to stable) and vs the
+    oracle at every stage boundary.  Bit-exact."""
+    from ssg_amd import rerank, cluster
+    g = golden(name)
+    src, tgt = g["src"], g["tgt"]
+    k1, k2, lam = int(g["k1"]), int(g["k2"]), float(g["lambda_value"])
+    N = tgt.shape[0]
+    st = {}
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k1=k1, k2=k2, lambda_value=lam, stages=st)
+    oe, of, ost = ora.re_ranking(src, tgt, k1=k1, k2=k2, lambda_value=lam, rank_mode="stable", stages=True)
+    assert np.array_equal(bits(st["D"].cpu().numpy()), bits(oe)), "original distance"
+    assert np.array_equal(bits(st["v"].cpu().numpy()), bits(ost["v"])), "source vector"
+    assert np.array_equal(st["rank"].cpu().numpy(), g["rank"]), "initial rank (golden)"
+    assert np.array_equal(_sparse_to_dense(st["v_idx"], st["v_val"], st["v_nnz"], N), bits(ost["V"])), "V"
+    assert np.array_equal(_sparse_to_dense(st["q_idx"], st["q_val"], st["q_nnz"], N), bits(ost["V_qe"])), "V_qe"
+    assert np.array_equal(bits(st["Jp"].cpu().numpy()), bits(ost["jaccard_scaled"])), "scaled jaccard"
+    final = h.final_dist().cpu().numpy()
+    assert np.array_equal(final, of), "final_dist vs oracle"
+    if "final" in g.files:
+        assert np.array_equal(final, g["final"]), "final_dist vs reference golden"
+        assert np.array_equal(bits(st["D"].cpu().numpy()), bits(g["euclid"]))
+    eps, cnt, top = cluster.eps_rule(h, float(g["rho"]))
+    assert (eps, cnt, top) == (float(g["eps"]), int(g["count"]), int(g["top_num"])), "eps rule"
+    labels = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h)
+    assert np.array_equal(labels, g["labels"]), "DBSCAN labels (incl. numbering)"
+    # the same through the materialised float64 matrix (sklearn drop-in path, mode 2)
+    eps2, cnt2, top2 = cluster.eps_rule(final, float(g["rho"]))
+    assert (eps2, cnt2, top2) == (eps, cnt, top)
+    assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(final), g["labels"])
+
+
+def test_reranking_dropin_signature(golden, dev):
+    """reid/rerank.py:27 call surface: numpy in, (float16 [N,N], float64 [N,N]) out."""
+    from ssg_amd import re_ranking, DBSCAN
+    g = golden("rerank_n256_l03_stable.npz")
+    e, f = re_ranking(g["src"], g["tgt"], k1=20, k2=6, lambda_value=0.3)
+    assert e.dtype == np.float16 and f.dtype == np.float64 and f.shape == (256, 256)
+    assert np.array_equal(np.asarray(f), g["final"]) and np.array_equal(bits(e), bits(g["euclid"]))
+    lab = DBSCAN(eps=float(g["eps"]), min_samples=4, metric="precomputed", n_jobs=8).fit_predict(f)
+    assert np.array_equal(lab, g["labels"])
+    e2, none = re_ranking(g["src"], g["tgt"], no_rerank=True)
+    assert none is None and np.array_equal(bits(e2), bits(e))
+
+
+@pytest.mark.parametrize("name", ["norerank_n256.npz", "norerank_n1024.npz"])
+def test_norerank_path(name, golden, dev):
+    from ssg_amd import rerank, cluster
+    g = golden(name)
+    tgt = torch.from_numpy(g["tgt"]).to(dev)
+    h = rerank.re_ranking_device(tgt[:8], tgt, no_rerank=True)
+    eps, cnt, top = cluster.eps_rule(h, float(g["rho"]))
+    assert np.float16(eps).view(np.uint16) == int(g["eps_bits"]) and cnt == int(g["count"]) and top == int(g["top_num"])
+    lab = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h)
+    assert np.array_equal(lab, g["labels"])
+
+
+def test_dbscan_cases(golden, dev):
+    from ssg_amd import DBSCAN
+    g = golden("dbscan_cases.npz")
+    for D, eps, lab in zip(g["D"], g["eps"], g["labels"]):
+        est = DBSCAN(eps=float(eps), min_samples=4, metric="precomputed").fit(D)
+        assert np.array_equal(est.labels_, lab)
+        counts = (D <= eps).sum(axis=1)
+        assert np.array_equal(est.core_sample_indices_, np.nonzero(counts >= 4)[0])
+
+
+def test_selftraining_surface_and_edge_cases(dev, ora):
+    """compute_dist -> generate_selflabel (selftraining.py:255-313) on the fused device path,
+    3 splits, ragged N (not a multiple of any tile), duplicates; vs the oracle."""
+    from types import SimpleNamespace
+    from ssg_amd import compute_dist, generate_selflabel
+    N, Ns, d = 777, 345, 72
+    tgts = [clustered(N, d, 40 + s) for s in range(3)]
+    srcs = [clustered(Ns, d, 50 + s, intra=0.7) for s in range(3)]
+    tgts[0][11] = tgts[0][10]
+    e_list, r_list = compute_dist([torch.from_numpy(s) for s in srcs], [torch.from_numpy(t) for t in tgts], lambda_value=0.1,
+                                  no_rerank=False, num_split=2)
+    args = SimpleNamespace(no_rerank=False, rho=1.6e-3)
+    labels, clusters = generate_selflabel(e_list, r_list, 0, args, [])
+    oe, orr = ora.compute_dist(srcs, tgts, 0.1, False)
+    olabels, oeps = ora.generate_selflabel(oe, orr, 0, 1.6e-3, False)
+    for s in range(3):
+        assert clusters[s].eps == oeps[s]
+        assert np.array_equal(labels[s], olabels[s])
+    # iteration 1 reuses the cached estimators (eps frozen, selftraining.py:297-298)
+    labels2, clusters2 = generate_selflabel(e_list, r_list, 1, args, clusters)
+    assert clusters2 is clusters and all(np.array_equal(a, b) for a, b in zip(labels, labels2))
+
+
+def test_nan_path_is_raised(dev):
+    """reid/rerank.py:40 divides by max(source_dist_vec)==0 -> NaN; the build raises instead."""
+    from ssg_amd import rerank
+    x = clustered(64, 32, 1)
+    with pytest.raises(rerank.ReRankNaNError):
+        rerank.re_ranking_device(torch.from_numpy(x).to(dev), torch.from_numpy(x).to(dev))   # src == tgt -> every d2 == 0
+
+
+@pytest.mark.parametrize("N", [4096])
+def test_medium_size_vs_oracle(N, dev, ora):
+    """Largest size the oracle finishes in seconds; full pipeline labels + distances bit-exact."""
+    from ssg_amd import rerank, cluster
+    d = 128
+    tgt = clustered(N, d, 77); src = clustered(N // 2, d, 78, intra=0.7)
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), lambda_value=0.1)
+    oe, of = ora.re_ranking(src, tgt, lambda_value=0.1)
+    assert np.array_equal(bits(h.euclid.cpu().numpy()), bits(oe))
+    assert np.array_equal(h.final_dist().cpu().numpy(), of)
+    eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
+    oeps, ocnt, otop = ora.eps_rule(of, 1.6e-3)
+    assert (eps, cnt, top) == (oeps, ocnt, otop)
+    assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h), ora.dbscan(of, oeps, 4))
+
+
+def test_full_size_properties(dev):
+    """BASELINE size N=16000, d=2048: size-independent properties (the oracle cannot run here)."""
+    from ssg_amd import rerank, cluster
+    N, d = 16000, 2048
+    tgt = torch.from_numpy(clustered(N, d, 1)).to(dev); src = torch.from_numpy(clustered(8192, d, 2, intra=0.7)).to(dev)
+    h = rerank.re_ranking_device(src, tgt, lambda_value=0.1)
+    D, Jp = h.euclid, h.M
+    assert torch.equal(D, D.T) and bool((torch.diagonal(D) == 0).all())
+    assert torch.equal(Jp, Jp.T), "J' must be exactly symmetric"
+    assert bool((Jp >= 0).all()) and bool((Jp.float() <= 1.0).all())
+    eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
+    assert top == int(np.round(1.6e-3 * cnt)) and 0 < eps < 1.5
+    est = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit(h)
+    lab = est.labels_
+    # cluster ids are numbered by their smallest core index (dbscan_inner visiting order)
+    ids = lab[lab >= 0]
+    core = est.core_sample_indices_
+    first_core = {}
+    for i in core:
+        first_core.setdefault(int(lab[i]), int(i))
+    order = [first_core[l] for l in sorted(first_core)]
+    assert order == sorted(order) and sorted(first_core) == list(range(len(first_core)))
+    assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h), lab)
+    # synthetic identities (16 per id) are recovered: every cluster is pure
+    truth = np.arange(N) % (N // 16)
+    for l in np.unique(ids)[:200]:
+        assert len(np.unique(truth[lab == l])) == 1

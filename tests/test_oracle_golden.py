@@ -1,0 +1,108 @@
+"""CPU suite: the oracle (oracle/ssg_oracle.c) against the committed golden vectors that were
+produced by importing the reference (tools/make_golden.py).  No GPU, no /root/reference."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, bits
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_*.npz")))
+
+
+@pytest.mark.parametrize("name", RERANK)
+def test_rerank_stages_match_reference(name, golden, ora):
+    g = golden(name)
+    mode = "stable" if bool(g["stable"]) else "introsort"   # 'ref' fixtures = untouched reference incl. unstable ties
+    e, f, st = ora.re_ranking(g["src"], g["tgt"], k1=int(g["k1"]), k2=int(g["k2"]), lambda_value=float(g["lambda_value"]),
+                              rank_mode=mode, stages=True)
+    assert not bool(g["exp_quirk"])
+    assert np.array_equal(st["rank"], g["rank"])
+    assert sha(e) == str(g["sha_euclid"])
+    assert sha(st["V"]) == str(g["sha_V"])
+    assert sha(st["V_qe"]) == str(g["sha_Vqe"])
+    assert sha(st["jaccard"]) == str(g["sha_jaccard"])
+    assert sha(f) == str(g["sha_final"])
+    if "final" in g.files:
+        assert np.array_equal(f, g["final"])
+        assert np.array_equal(bits(e), bits(g["euclid"]))
+    # source term: row 0 of source_dist = half(v + v[0]) (rerank.py:43)
+    v = st["v"]
+    assert np.array_equal((v + v[0]).astype(np.float64), g["v"])
+    eps, cnt, top = ora.eps_rule(f, float(g["rho"]))
+    assert eps == float(g["eps"]) and cnt == int(g["count"]) and top == int(g["top_num"])
+    assert np.array_equal(ora.dbscan(f, eps, 4), g["labels"])
+
+
+@pytest.mark.parametrize("name", ["norerank_n256.npz", "norerank_n1024.npz"])
+def test_norerank_path(name, golden, ora):
+    g = golden(name)
+    e, none = ora.re_ranking(g["tgt"][:8], g["tgt"], no_rerank=True)
+    assert none is None and sha(e) == str(g["sha_euclid"])
+    eps, cnt, top = ora.eps_rule(e, float(g["rho"]))
+    assert np.float16(eps).view(np.uint16) == int(g["eps_bits"]) and cnt == int(g["count"]) and top == int(g["top_num"])
+    assert np.array_equal(ora.dbscan(e.astype(np.float64), float(eps), 4), g["labels"])
+
+
+def test_dbscan_cases(golden, ora):
+    g = golden("dbscan_cases.npz")
+    for D, eps, lab in zip(g["D"], g["eps"], g["labels"]):
+        assert np.array_equal(ora.dbscan(D, float(eps), 4), lab)
+
+
+def test_half_exp_table(golden, ora):
+    """Correctly rounded half exp == this host's numpy table except the recorded quirk inputs."""
+    g = golden("half_exp_table.npz")
+    cr = ora.half_exp_table().view(np.uint16)
+    npx = g["numpy_exp_bits"]
+    allh = np.arange(65536, dtype=np.uint16).view(np.float16)
+    diff = np.nonzero((cr != npx) & ~(np.isnan(cr.view(np.float16)) & np.isnan(npx.view(np.float16))))[0]
+    assert set(diff.tolist()) == set(g["quirk_input_bits"].tolist())
+    assert len(diff) <= 4
+    # every differing entry is a 1-ulp difference
+    assert np.all(np.abs(cr[diff].astype(np.int32) - npx[diff].astype(np.int32)) == 1)
+    assert np.isfinite(allh[diff]).all()
+
+
+def test_numpy_primitives(ora):
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        n = int(rng.integers(1, 900))
+        a = rng.random(n).astype(np.float32)
+        assert np.sum(a) == ora.pairwise_sum(a)
+        b = rng.random(n)
+        assert np.sum(b) == ora.pairwise_sum(b)
+        h = (rng.integers(0, 30, n) / 32.0).astype(np.float16)
+        assert np.array_equal(np.argsort(h), ora.argsort_half(h))
+        assert np.sum(h) == np.float16(ora.pairwise_sum(h.astype(np.float32)))
+
+
+def test_oracle_matches_scipy_cdist(ora):
+    from scipy.spatial.distance import cdist
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((40, 37)).astype(np.float32)
+    f = x.astype(np.float16)
+    ref = np.power(cdist(f, f).astype(np.float16), 2).astype(np.float16)
+    assert np.array_equal(bits(ora.euclid(x)), bits(ref))
+
+
+def test_edge_cases(ora):
+    # duplicates -> exact zeros; tiny N (< k1+1); all-identical source
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((12, 16)).astype(np.float32)
+    x[5] = x[3]
+    e, f = ora.re_ranking(x[:4], x, k1=20, k2=6, lambda_value=0.1)
+    assert e[3, 5] == 0 and e[5, 3] == 0 and np.all(np.diag(e) == 0)
+    assert f.shape == (12, 12) and np.isfinite(f).all()
+    assert np.array_equal(f, f.T)
+    lab = ora.dbscan(f, 10.0, 4)
+    assert (lab == 0).all()
+    lab = ora.dbscan(f, 1e-9, 4)
+    assert (lab == -1).all()
