@@ -116,6 +116,22 @@ size_t ssg_dbscan_cc_workspace_bytes(int N);
 int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,
                   int64_t* labels, ssg_stream_t stream);
 
+/* ---- K1/K2 ResNet-50 embedding forward (reid/models/resnet.py:86-111, reid/evaluators.py:18-60) */
+/* Conv2d with eval-BatchNorm folded into (w, bias) + optional residual add + optional ReLU, NHWC
+ * float32 on the fp32 matrix cores.  in [B,H,W,Cin]; w [Cout][Kpad], k = (r*KW+s)*Cin + c, rows
+ * zero-padded to Kpad (multiple of 32); res/out [B,OH,OW,Cout].  Cin % 32 == 0 or Cin == 4 (stem:
+ * RGB0 pixels, Kpad = 32*ceil(KH*KW/8)); Cout % 64 == 0.  (cuDNN conv+BN+ReLU of base.py:57-93) */
+int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W, int Cin,
+                        int Cout, int KH, int KW, int stride, int pad, int relu, ssg_stream_t stream);
+/* [B,3,H,W] NCHW -> [B,H,W,4] NHWC (4th channel 0); flip != 0 mirrors W (evaluators.py:12-16 fliplr) */
+int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, ssg_stream_t stream);
+/* MaxPool2d(3, stride 2, padding 1) on NHWC (base.py:105) */
+int ssg_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, ssg_stream_t stream);
+/* out[s][b][c]: s=0 global average pool, s=1..S the S horizontal stripes (resnet.py:93-111) */
+int ssg_gap_stripes(const float* in, float* out, int B, int H, int W, int C, int num_split, ssg_stream_t stream);
+/* out = (a+b)/||a+b||_2 per row (evaluators.py:31-35: original + flipped features, L2 norm) */
+int ssg_flip_sum_l2norm(const float* a, const float* b, float* out, int rows, int C, ssg_stream_t stream);
+
 /* ---- device self-tests used by the parity suite ----------------------------------------- */
 int ssg_selftest_half_table(int which, uint16_t* out65536, ssg_stream_t stream);
 int ssg_selftest_half_binop(int which, const uint16_t* a, const uint16_t* b, int n, uint16_t* out, ssg_stream_t stream);

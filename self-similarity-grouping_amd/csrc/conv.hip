@@ -1,0 +1,270 @@
+// conv.hip -- K1/K2: ResNet-50 embedding forward (eval mode) on the FP32 matrix cores.
+//
+// Replaces the cuDNN path under reid/models/resnet.py:86-111 (torchvision ResNet-50 =
+// reid/models/base.py:57-152 Bottleneck x [3,4,6,3]) as driven by
+// reid/feature_extraction/cnn.py:10-22 and reid/evaluators.py:18-60.
+//
+// Every convolution is an implicit GEMM  out[m, n] = sum_k A[m, k] * W[n, k]  with
+//   m = output pixel (b, oh, ow)   -- NHWC activations, so a pixel's channels are contiguous
+//   n = output channel             -- weights stored [Cout][KH*KW*Cin] (k = (r, s, c))
+// on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).  Eval-mode BatchNorm is folded into
+// the weights/bias on the host; bias + residual add + ReLU are fused into the epilogue, so a
+// bottleneck block costs 3 (4 with downsample) launches and no elementwise passes.
+//
+// Tile: BM x BN output tile per 256-thread workgroup, 4 waves of 64x64 (2x2 MFMA tiles, 64
+// accumulator VGPRs), BK = 32.  A and W tiles are staged through LDS as [row][36 floats]
+// (144-byte rows: ds_read_b128 fragment reads and ds_write_b128 staging writes are both
+// bank-conflict free).  Each lane reads 4 consecutive k of its row per ds_read_b128; the k
+// order inside a group of 8 is permuted identically for A and W (lane>>5 selects k0..3 or
+// k4..7), which the reduction does not care about.
+#include "ssg_common.h"
+
+namespace ssg {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+struct ConvParams {
+  const float* in; const float* w; const float* bias; const float* res; float* out;
+  int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu;
+  int M, Kpad;   // M = B*OH*OW, Kpad = weight row length (multiple of 32)
+};
+
+constexpr int CBK = 32, CLD = 36;
+
+__device__ __forceinline__ int conv_xcd_remap(int b, int nwg) {
+  const int nx = 8, q = nwg / nx, r = nwg % nx, x = b % nx, s = b / nx;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+}
+
+// CIN4: stem mode, input has 4 channels (RGB + zero), one float4 = one filter tap.
+template <int BM, int BN, bool CIN4>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
+  constexpr int WROWS = BM / 64;            // waves along m (BM=128 -> 2, BM=256 -> 4)
+  constexpr int WCOLS = 4 / WROWS;          // waves along n
+  static_assert(WCOLS * 64 == BN, "tile/wave layout mismatch");
+  constexpr int AJ = BM / 32, BJ = BN / 32; // float4 loads per thread for the A / W tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // one declaration shared by the unity TU
+  float* As = reinterpret_cast<float*>(smem);
+  float* Bs = As + BM * CLD;
+
+  const int tiles_n = p.Cout / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = conv_xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WCOLS, wn = wave % WCOLS;
+  const int kq = tid & 7, r0 = tid >> 3;
+
+  // per staged A row: input coordinates of filter tap (0,0)
+  int a_b[AJ], a_ih[AJ], a_iw[AJ];
+#pragma unroll
+  for (int j = 0; j < AJ; j++) {
+    const int m = tm * BM + r0 + 32 * j;
+    if (m < p.M) {
+      const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      a_b[j] = b; a_ih[j] = oh * p.stride - p.pad; a_iw[j] = ow * p.stride - p.pad;
+    } else { a_b[j] = -1; a_ih[j] = 0; a_iw[j] = 0; }
+  }
+  const float* wrow[BJ];
+#pragma unroll
+  for (int j = 0; j < BJ; j++) wrow[j] = p.w + (int64_t)(tn * BN + r0 + 32 * j) * p.Kpad + kq * 4;
+
+  float4 pa[AJ], pb[BJ];
+  auto gload = [&](int kt) {
+    int r, s, c;
+    if (CIN4) { const int tap = kt * 8 + kq; r = tap / p.KW; s = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; }
+    else { const int k0 = kt * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; }
+#pragma unroll
+    for (int j = 0; j < AJ; j++) {
+      const int ih = a_ih[j] + r, iw = a_iw[j] + s;
+      const bool ok = a_b[j] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
+      pa[j] = ok ? *reinterpret_cast<const float4*>(p.in + ((int64_t)(a_b[j] * p.H + ih) * p.W + iw) * p.Cin + c)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < BJ; j++) pb[j] = *reinterpret_cast<const float4*>(wrow[j] + kt * CBK);
+  };
+
+  v16f acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int nk = p.Kpad / CBK;
+  const int l32 = lane & 31, h = lane >> 5;
+  gload(0);
+  for (int kt = 0; kt < nk; kt++) {
+#pragma unroll
+    for (int j = 0; j < AJ; j++) *reinterpret_cast<float4*>(As + (r0 + 32 * j) * CLD + kq * 4) = pa[j];
+#pragma unroll
+    for (int j = 0; j < BJ; j++) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * CLD + kq * 4) = pb[j];
+    __syncthreads();
+    if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+    for (int g = 0; g < CBK / 8; g++) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const float4*>(As + (wm * 64 + i * 32 + l32) * CLD + g * 8 + h * 4);
+#pragma unroll
+      for (int j = 0; j < 2; j++) b[j] = *reinterpret_cast<const float4*>(Bs + (wn * 64 + j * 32 + l32) * CLD + g * 8 + h * 4);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int col = tn * BN + wn * 64 + j * 32 + l32;
+    const float bias = p.bias[col];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = tm * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m < p.M) {
+          float v = acc[i][j][r] + bias;
+          if (p.res) v += p.res[(int64_t)m * p.Cout + col];
+          if (p.relu) v = v > 0.f ? v : 0.f;
+          p.out[(int64_t)m * p.Cout + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// NCHW float32 images [B,3,H,W] -> NHWC4 [B,H,W,4] (4th channel 0), optional horizontal flip
+// (reid/evaluators.py:12-16 fliplr fused into the layout change).
+__global__ void nchw_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int flip) {
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(x % W); const int64_t t = x / W; const int hh = (int)(t % H); const int b = (int)(t / H);
+    const int ws = flip ? (W - 1 - w) : w;
+    const int64_t plane = (int64_t)H * W, base = (int64_t)b * 3 * plane + (int64_t)hh * W + ws;
+    reinterpret_cast<float4*>(out)[x] = make_float4(in[base], in[base + plane], in[base + 2 * plane], 0.f);
+  }
+}
+
+// MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (reid/models/base.py:105); C % 4 == 0
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int OH, int OW) {
+  const int C4 = C / 4;
+  const int64_t total = (int64_t)B * OH * OW * C4;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(x % C4); int64_t t = x / C4;
+    const int ow = (int)(t % OW); t /= OW; const int oh = (int)(t % OH); const int b = (int)(t / OH);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int r = 0; r < 3; r++) {
+      const int ih = oh * 2 - 1 + r; if (ih < 0 || ih >= H) continue;
+      for (int s = 0; s < 3; s++) {
+        const int iw = ow * 2 - 1 + s; if (iw < 0 || iw >= W) continue;
+        const float4 v = reinterpret_cast<const float4*>(in + ((int64_t)(b * H + ih) * W + iw) * C)[c4];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    reinterpret_cast<float4*>(out)[x] = m;
+  }
+}
+
+// Global + stripe average pooling (reid/models/resnet.py:93-111): feature map [B,H,W,C] ->
+// out[s][b][c], s = 0: whole map, s = 1..S: rows [H/S*(s-1), H/S*s).  S = 0/1 -> whole only.
+__global__ void gap_stripes_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int S) {
+  const int nsets = S > 1 ? S + 1 : 1;
+  const int64_t total = (int64_t)nsets * B * C;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(x % C); int64_t t = x / C; const int b = (int)(t % B); const int s = (int)(t / B);
+    int h0 = 0, h1 = H;
+    if (s > 0) { const int hs = H / S; h0 = hs * (s - 1); h1 = hs * s; }
+    float acc = 0.f;
+    for (int hh = h0; hh < h1; hh++)
+      for (int w = 0; w < W; w++) acc += in[((int64_t)(b * H + hh) * W + w) * C + c];
+    out[x] = acc / (float)((h1 - h0) * W);
+  }
+}
+
+// out = (a + b) / ||a + b||_2 per row (reid/evaluators.py:31-35); one wave per row
+__global__ __launch_bounds__(256) void flip_sum_l2norm_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                              int rows, int C) {
+  const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (row >= rows) return;
+  const int lane = lane_id();
+  const float* pa = a + (int64_t)row * C; const float* pb = b + (int64_t)row * C;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) { const float s = pa[c] + pb[c]; ss += s * s; }
+  for (int sh = 1; sh < 64; sh <<= 1) ss += __shfl_xor(ss, sh, 64);
+  const float nrm = sqrtf(ss);
+  for (int c = lane; c < C; c += 64) out[(int64_t)row * C + c] = (pa[c] + pb[c]) / nrm;
+}
+
+}  // namespace ssg
+
+using namespace ssg;
+
+template <int BM, int BN, bool CIN4>
+static int launch_conv(const ConvParams& p, hipStream_t stream) {
+  const size_t lds = (size_t)(BM + BN) * CLD * sizeof(float);
+  const int tiles = ((p.M + BM - 1) / BM) * (p.Cout / BN);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, CIN4>), dim3(tiles), dim3(256), lds, stream, p);
+  return ssg_check_hip(hipGetLastError(), "conv_igemm_kernel");
+}
+
+// Conv2d(bias folded from eval BatchNorm) + optional residual add + optional ReLU, NHWC fp32.
+//   in  [B,H,W,Cin]; w [Cout][Kpad] with k = (r*KW + s)*Cin + c, rows zero-padded to Kpad
+//   (multiple of 32); bias [Cout]; res/out [B,OH,OW,Cout].  Cin % 32 == 0, or Cin == 4 (stem:
+//   RGB0 pixels, Kpad = 32*ceil(KH*KW/8)).  Cout % 64 == 0.
+extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, hipStream_t stream) {
+  ConvParams p;
+  p.in = in; p.w = w; p.bias = bias; p.res = res; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
+  p.OH = (H + 2 * pad - KH) / stride + 1; p.OW = (W + 2 * pad - KW) / stride + 1;
+  const int64_t M = (int64_t)B * p.OH * p.OW;
+  if (B <= 0 || M <= 0 || M > 0x7fffffff || (Cout % 64) || !((Cin % 32) == 0 || Cin == 4) || stride < 1) {
+    ssg_set_error("ssg_conv2d_nhwc_f32: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d", B, H, W, Cin, Cout, KH, KW, stride, pad);
+    return SSG_ERR_INVALID;
+  }
+  p.M = (int)M;
+  const bool cin4 = (Cin == 4);
+  p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
+  if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, true>(p, stream) : launch_conv<256, 64, true>(p, stream);
+  return (Cout % 128 == 0) ? launch_conv<128, 128, false>(p, stream) : launch_conv<256, 64, false>(p, stream);
+}
+
+extern "C" int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0) { ssg_set_error("ssg_nchw_to_nhwc4: empty"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(4096), dim3(256), 0, stream, in, out, B, H, W, flip);
+  SSG_LAUNCH_CHECK("nchw_to_nhwc4_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream) {
+  if (B <= 0 || (C & 3)) { ssg_set_error("ssg_maxpool3x3s2_nhwc: C %% 4 != 0"); return SSG_ERR_INVALID; }
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(8192), dim3(256), 0, stream, in, out, B, H, W, C, OH, OW);
+  SSG_LAUNCH_CHECK("maxpool3x3s2_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_gap_stripes(const float* in, float* out, int B, int H, int W, int C, int num_split, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || num_split > H) { ssg_set_error("ssg_gap_stripes: bad shape"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(gap_stripes_kernel, dim3(2048), dim3(256), 0, stream, in, out, B, H, W, C, num_split);
+  SSG_LAUNCH_CHECK("gap_stripes_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_flip_sum_l2norm(const float* a, const float* b, float* out, int rows, int C, hipStream_t stream) {
+  if (rows <= 0 || C <= 0) { ssg_set_error("ssg_flip_sum_l2norm: empty"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(flip_sum_l2norm_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a, b, out, rows, C);
+  SSG_LAUNCH_CHECK("flip_sum_l2norm_kernel");
+  return SSG_OK;
+}

@@ -6,3 +6,4 @@
 #include "krecip.hip"
 #include "jaccard.hip"
 #include "cluster.hip"
+#include "conv.hip"

@@ -1,0 +1,286 @@
+"""ResNet-50 embedder -- host-side mirror of reid/models/resnet.py (wrapper, :17-148) over the
+torchvision ResNet-50 architecture spelled out in reid/models/base.py:57-152.
+
+`create('resnet50', num_classes=0, num_split=S, cluster=False)` returns an object with the
+reference's call surface: `state_dict()` / `load_state_dict()` with the reference's key names
+(`base.conv1.weight`, `base.layer1.0.bn2.running_var`, `feat.weight`, `feat_bn.*` ...),
+`eval()`, `cuda()`, and `model(x, for_eval)` -> `(x1, x2)` where x1 is the list of S+1
+pooled feature sets (or their concatenation when for_eval=True), resnet.py:86-134.
+
+The forward runs on hand-written HIP kernels (csrc/conv.hip) through the C ABI: NHWC fp32,
+eval-mode BatchNorm folded into the convolution weights at load time, bias/residual/ReLU
+fused into the GEMM epilogue.  There is no training path here (fine-tuning is out of scope,
+SURVEY.md section 2 rows 10-11).
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+_LAYERS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+_BN_EPS = 1e-5
+
+
+def _arch(depth):
+    """[(prefix, cin, cout, k, stride, pad)] conv list + block structure of a Bottleneck ResNet."""
+    blocks = []
+    inplanes = 64
+    for li, (planes, n) in enumerate(zip((64, 128, 256, 512), _LAYERS[depth])):
+        for b in range(n):
+            stride = 2 if (b == 0 and li > 0) else 1
+            down = b == 0 and (stride != 1 or inplanes != planes * 4)
+            blocks.append(dict(prefix="base.layer%d.%d" % (li + 1, b), inplanes=inplanes, planes=planes, stride=stride, down=down))
+            inplanes = planes * 4
+    return blocks
+
+
+def synthetic_state_dict(seed=1, depth=50, num_features=2048, randomize_bn=True):
+    """Deterministic random weights with the reference's shapes and key names: Kaiming-normal
+    fan_out convolutions (reid/models/base.py:113-118), BatchNorm statistics drawn at random so
+    that the BN folding is exercised (gamma ~ U(.5,1.5), beta, mean ~ N(0,.1), var ~ U(.5,1.5)).
+    There is no network access for ImageNet checkpoints; benchmarks and parity tests use this."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+
+    def conv(name, cout, cin, k):
+        std = (2.0 / (cout * k * k)) ** 0.5
+        sd[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * std
+
+    def bn(name, c):
+        if randomize_bn:
+            sd[name + ".weight"] = torch.rand(c, generator=g) + 0.5
+            sd[name + ".bias"] = torch.randn(c, generator=g) * 0.1
+            sd[name + ".running_mean"] = torch.randn(c, generator=g) * 0.1
+            sd[name + ".running_var"] = torch.rand(c, generator=g) + 0.5
+        else:
+            sd[name + ".weight"] = torch.ones(c); sd[name + ".bias"] = torch.zeros(c)
+            sd[name + ".running_mean"] = torch.zeros(c); sd[name + ".running_var"] = torch.ones(c)
+        sd[name + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    conv("base.conv1", 64, 3, 7); bn("base.bn1", 64)
+    for blk in _arch(depth):
+        p, ip, pl = blk["prefix"], blk["inplanes"], blk["planes"]
+        conv(p + ".conv1", pl, ip, 1); bn(p + ".bn1", pl)
+        conv(p + ".conv2", pl, pl, 3); bn(p + ".bn2", pl)
+        conv(p + ".conv3", pl * 4, pl, 1); bn(p + ".bn3", pl * 4)
+        if blk["down"]:
+            conv(p + ".downsample.0", pl * 4, ip, 1); bn(p + ".downsample.1", pl * 4)
+    sd["base.fc.weight"] = torch.randn(1000, 2048, generator=g) * 0.01
+    sd["base.fc.bias"] = torch.zeros(1000)
+    if num_features > 0:
+        sd["feat.weight"] = torch.randn(num_features, 2048, generator=g) * 0.001      # init.normal_(std=0.001) resnet.py:67
+        sd["feat_bn.weight"] = torch.ones(num_features); sd["feat_bn.bias"] = torch.zeros(num_features)
+        sd["feat_bn.running_mean"] = torch.zeros(num_features); sd["feat_bn.running_var"] = torch.ones(num_features)
+        sd["feat_bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+    return sd
+
+
+class _FoldedConv:
+    __slots__ = ("w", "bias", "cin", "cout", "k", "stride", "pad")
+
+
+def _fold(sd, conv_name, bn_name, stride, pad, device):
+    """conv + eval BatchNorm -> (w [Cout][Kpad] with k=(r,s,c), bias [Cout]); float64 fold."""
+    w = sd[conv_name + ".weight"].double()
+    gamma, beta = sd[bn_name + ".weight"].double(), sd[bn_name + ".bias"].double()
+    mean, var = sd[bn_name + ".running_mean"].double(), sd[bn_name + ".running_var"].double()
+    scale = gamma / torch.sqrt(var + _BN_EPS)
+    w = w * scale.view(-1, 1, 1, 1)
+    bias = beta - mean * scale
+    cout, cin, k, _ = w.shape
+    w = w.permute(0, 2, 3, 1).contiguous()                     # [Cout, KH, KW, Cin]
+    if cin == 3:                                                 # stem: RGB0 pixels, one tap per float4
+        w = torch.nn.functional.pad(w, (0, 1))
+        cin = 4
+        kpad = 32 * ((k * k + 7) // 8)
+        w = torch.nn.functional.pad(w.reshape(cout, k * k * 4), (0, kpad - k * k * 4))
+    else:
+        w = w.reshape(cout, k * k * cin)
+    f = _FoldedConv()
+    f.w = w.float().contiguous().to(device); f.bias = bias.float().contiguous().to(device)
+    f.cin, f.cout, f.k, f.stride, f.pad = cin, cout, k, stride, pad
+    return f
+
+
+class ResNet:
+    """Mirror of reid.models.resnet.ResNet (resnet.py:17-148), forward only."""
+
+    def __init__(self, depth=50, checkpoint=None, pretrained=True, num_features=2048, dropout=0.1, num_classes=0, num_split=1,
+                 mode='Dissimilarity', cluster=False, seed=1):
+        if depth not in _LAYERS:
+            raise KeyError("Unsupported depth:", depth)
+        if cluster:
+            raise NotImplementedError("cluster=True (DEC head, reid/models/dce.py) is outside the grouping hot path")
+        self.depth, self.num_features, self.dropout, self.num_classes = depth, num_features, dropout, num_classes
+        self.num_split, self.cluster, self.pretrained, self.training = num_split, cluster, pretrained, False
+        self.device = torch.device("cpu")
+        self._sd = synthetic_state_dict(seed, depth, num_features)
+        self._folded = None
+        if checkpoint:
+            self.load_state_dict(torch.load(checkpoint, map_location="cpu")["state_dict"], strict=False)
+
+    # ---- torch.nn.Module-like surface used by selftraining.py / evaluators.py
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._sd.items())
+
+    def load_state_dict(self, state_dict, strict=True):
+        missing = [k for k in self._sd if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in self._sd]
+        if strict and (missing or unexpected):
+            raise RuntimeError("Error(s) in loading state_dict: missing %r unexpected %r" % (missing[:5], unexpected[:5]))
+        for k, v in state_dict.items():
+            if k in self._sd:
+                if tuple(v.shape) != tuple(self._sd[k].shape):
+                    raise RuntimeError("size mismatch for %s: %r vs %r" % (k, tuple(v.shape), tuple(self._sd[k].shape)))
+                self._sd[k] = v.detach().to("cpu").clone()
+        self._folded = None
+        return missing, unexpected
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("ssg_amd.resnet.ResNet is an inference-only embedder")
+        return self.eval()
+
+    def cuda(self, device=None):
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self._folded = None
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device); self._folded = None
+        return self
+
+    @property
+    def module(self):   # nn.DataParallel(model).module compatibility (selftraining.py:135,230)
+        return self
+
+    # ---- weights
+    def _prepare(self):
+        if self._folded is not None:
+            return self._folded
+        if self.device.type != "cuda":
+            raise _lib.SSGError("the embedder runs on the GPU only: call model.cuda() first (no CPU fallback)")
+        sd, dev = self._sd, self.device
+        net = dict(stem=_fold(sd, "base.conv1", "base.bn1", 2, 3, dev), blocks=[])
+        for blk in _arch(self.depth):
+            p = blk["prefix"]
+            net["blocks"].append(dict(
+                c1=_fold(sd, p + ".conv1", p + ".bn1", 1, 0, dev),
+                c2=_fold(sd, p + ".conv2", p + ".bn2", blk["stride"], 1, dev),
+                c3=_fold(sd, p + ".conv3", p + ".bn3", 1, 0, dev),
+                ds=_fold(sd, p + ".downsample.0", p + ".downsample.1", blk["stride"], 0, dev) if blk["down"] else None))
+        self._folded = net
+        return net
+
+    # ---- forward
+    @staticmethod
+    def _conv(L, x, f, res=None, relu=True):
+        B, H, W, _ = x.shape
+        OH = (H + 2 * f.pad - f.k) // f.stride + 1; OW = (W + 2 * f.pad - f.k) // f.stride + 1
+        out = torch.empty((B, OH, OW, f.cout), dtype=torch.float32, device=x.device)
+        check(L.ssg_conv2d_nhwc_f32(ptr(x), ptr(f.w), ptr(f.bias), ptr(res), ptr(out), B, H, W, f.cin, f.cout, f.k, f.k, f.stride, f.pad,
+                                    1 if relu else 0, stream()), "ssg_conv2d_nhwc_f32")
+        return out
+
+    def feature_map(self, x, flip=False):
+        """images [B,3,H,W] float32 (NCHW, any device) -> layer4 map [B,H/32,W/32,2048] NHWC
+        (resnet.py:87-92: every base module up to, not including, avgpool)."""
+        L = _lib.lib()
+        net = self._prepare()
+        x = x.to(self.device, torch.float32).contiguous()
+        B, C, H, W = x.shape
+        if C != 3:
+            raise ValueError("expected RGB images [B,3,H,W]")
+        x4 = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
+        check(L.ssg_nchw_to_nhwc4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4")
+        y = self._conv(L, x4, net["stem"])
+        _, H2, W2, _ = y.shape
+        p = torch.empty((B, (H2 + 1) // 2, (W2 + 1) // 2, 64), dtype=torch.float32, device=self.device)
+        check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
+        y = p
+        for blk in net["blocks"]:
+            o = self._conv(L, y, blk["c1"])
+            o = self._conv(L, o, blk["c2"])
+            res = self._conv(L, y, blk["ds"], relu=False) if blk["ds"] is not None else y
+            y = self._conv(L, o, blk["c3"], res=res, relu=True)
+        return y
+
+    def pooled(self, fmap):
+        """[B,h,w,2048] -> [(S+1), B, 2048] (whole + S stripes) or [1,B,2048] (resnet.py:93-111)."""
+        L = _lib.lib()
+        B, h, w, C = fmap.shape
+        S = self.num_split if self.num_split > 1 else 1
+        nsets = S + 1 if S > 1 else 1
+        out = torch.empty((nsets, B, C), dtype=torch.float32, device=fmap.device)
+        check(L.ssg_gap_stripes(ptr(fmap), ptr(out), B, h, w, C, S, stream()), "ssg_gap_stripes")
+        return out
+
+    def _x2(self, gap):
+        if self.num_features <= 0:
+            return None
+        sd, dev = self._sd, self.device
+        x2 = gap @ sd["feat.weight"].to(dev).t()
+        x2 = (x2 - sd["feat_bn.running_mean"].to(dev)) / torch.sqrt(sd["feat_bn.running_var"].to(dev) + _BN_EPS) * sd["feat_bn.weight"].to(dev) \
+            + sd["feat_bn.bias"].to(dev)
+        return torch.relu(x2)
+
+    def __call__(self, x, for_eval=False):
+        sets = self.pooled(self.feature_map(x))
+        x2 = self._x2(sets[0])
+        if self.num_split > 1:
+            x1 = [sets[s] for s in range(sets.shape[0])]
+            if for_eval:
+                return torch.cat(x1, dim=1), x2
+            return x1, x2
+        return sets[0], x2
+
+    forward = __call__
+
+    def embed_with_flip(self, x, for_eval=False):
+        """Fused reid/evaluators.py:28-35: features of x and fliplr(x) summed and L2-normalised.
+        Returns [(S+1), B, 2048] (per-set norm) or, for_eval / single set, [B, (S+1)*2048]."""
+        L = _lib.lib()
+        x = x.to(self.device, torch.float32)          # one H2D copy for both orientations
+        a = self.pooled(self.feature_map(x, flip=False))
+        b = self.pooled(self.feature_map(x, flip=True))
+        nsets, B, C = a.shape
+        if for_eval or nsets == 1:
+            a = a.permute(1, 0, 2).reshape(B, nsets * C).contiguous(); b = b.permute(1, 0, 2).reshape(B, nsets * C).contiguous()
+            out = torch.empty_like(a)
+            check(L.ssg_flip_sum_l2norm(ptr(a), ptr(b), ptr(out), B, nsets * C, stream()), "ssg_flip_sum_l2norm")
+            return out
+        out = torch.empty_like(a)
+        check(L.ssg_flip_sum_l2norm(ptr(a), ptr(b), ptr(out), nsets * B, C, stream()), "ssg_flip_sum_l2norm")
+        return out
+
+
+def resnet50(**kwargs):
+    return ResNet(50, **kwargs)
+
+
+def resnet101(**kwargs):
+    return ResNet(101, **kwargs)
+
+
+def resnet152(**kwargs):
+    return ResNet(152, **kwargs)
+
+
+_factory = {"resnet50": resnet50, "resnet101": resnet101, "resnet152": resnet152}
+
+
+def names():
+    return sorted(_factory)
+
+
+def create(name, *args, **kwargs):
+    """reid/models/__init__.py create(): models.create('resnet50', num_classes=0, num_split=2, cluster=False)."""
+    if name not in _factory:
+        raise KeyError("Unknown model:", name)
+    return _factory[name](*args, **kwargs)

@@ -260,3 +260,85 @@ def test_full_size_properties(dev):
     truth = np.arange(N) % (N // 16)
     for l in np.unique(ids)[:200]:
         assert len(np.unique(truth[lab == l])) == 1
+
+
+# ------------------------------------------------------------------ embedding (K1/K2), fp32
+# Floating-point kernels: tolerance stated per test (the torch fp32 CPU reference itself is
+# only reproducible to ~1e-6 across BLAS/oneDNN kernel choices).
+@pytest.mark.parametrize("cfg", [
+    # B, H, W, Cin, Cout, k, stride, pad, residual, relu
+    (3, 16, 8, 64, 64, 1, 1, 0, False, True),
+    (2, 16, 8, 64, 256, 1, 1, 0, True, True),
+    (2, 16, 8, 128, 128, 3, 1, 1, False, True),
+    (2, 16, 8, 128, 128, 3, 2, 1, False, True),
+    (2, 16, 8, 256, 512, 1, 2, 0, False, False),
+    (5, 9, 7, 64, 64, 3, 1, 1, False, True),        # ragged M (not a tile multiple)
+    (2, 32, 16, 3, 64, 7, 2, 3, False, True),       # stem
+])
+def test_conv_vs_torch(cfg, L, dev):
+    from ssg_amd._lib import check, ptr, stream
+    B, H, W, Cin, Cout, k, stride, pad, use_res, relu = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride, pad)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    if Cin == 3:
+        xin = torch.cat([x, torch.zeros(B, 1, H, W)], 1).permute(0, 2, 3, 1).contiguous()
+        wk = torch.nn.functional.pad(w.permute(0, 2, 3, 1), (0, 1)).reshape(Cout, k * k * 4)
+        wk = torch.nn.functional.pad(wk, (0, 32 * ((k * k + 7) // 8) - k * k * 4)).contiguous()
+        cin = 4
+    else:
+        xin = x.permute(0, 2, 3, 1).contiguous(); wk = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous(); cin = Cin
+    OH, OW = ref.shape[2], ref.shape[3]
+    out = torch.empty(B, OH, OW, Cout, device=dev)
+    xin, wk, bias_d = xin.to(dev), wk.to(dev), bias.to(dev)
+    res_d = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    check(L.ssg_conv2d_nhwc_f32(ptr(xin), ptr(wk), ptr(bias_d), ptr(res_d), ptr(out), B, H, W, cin, Cout, k, k, stride, pad, int(relu), stream()), "conv")
+    got = out.cpu().permute(0, 3, 1, 2).double()
+    err = (got - ref).abs().max().item()
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()), err     # fp32 accumulation over K <= 1152 terms
+
+
+def test_embedding_vs_reference_golden(golden, dev):
+    """HIP ResNet-50 embed (orig + flip, L2 norm) vs the real reference model's features.
+    Tolerance 5e-6 absolute on unit-norm 2048-d features (fp32 conv accumulation order)."""
+    import ssg_amd
+    g = golden("embed_ref.npz")
+    imgs = torch.randn(4, 3, 256, 128, generator=torch.Generator().manual_seed(int(g["image_seed"])))
+    for S in (2, 1):
+        m = ssg_amd.create("resnet50", num_classes=0, num_split=S, cluster=False, seed=int(g["weight_seed"])).cuda().eval()
+        ref = g["feats_S%d" % S]
+        got = m.embed_with_flip(imgs)
+        got = got.cpu().numpy() if got.dim() == 3 else got.cpu().numpy()[None]
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 5e-6, np.abs(got - ref).max()
+        # plain forward surface: model(x, for_eval)[0] (reid/feature_extraction/cnn.py:16)
+        x1, x2 = m(imgs[:2], False)
+        if S > 1:
+            assert isinstance(x1, list) and len(x1) == S + 1 and x1[0].shape == (2, 2048) and x2.shape == (2, 2048)
+            cat, _ = m(imgs[:2], True)
+            assert cat.shape == (2, (S + 1) * 2048)
+
+
+def test_extract_features_dropin(golden, dev):
+    """reid/evaluators.py:18 call surface: dict fname -> list of S+1 CPU vectors, dict fname -> pid."""
+    import ssg_amd
+    g = golden("embed_ref.npz")
+    imgs = torch.randn(4, 3, 256, 128, generator=torch.Generator().manual_seed(int(g["image_seed"])))
+    m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=int(g["weight_seed"])).cuda()
+    loader = [(imgs[:3], ["a", "b", "c"], [7, 8, 9], [0, 0, 0]), (imgs[3:], ["d"], [5], [1])]
+    feats, labels = ssg_amd.extract_features(m, loader, for_eval=False)
+    assert list(feats.keys()) == ["a", "b", "c", "d"] and labels["d"] == 5
+    assert isinstance(feats["a"], list) and len(feats["a"]) == 3 and feats["a"][0].device.type == "cpu"
+    ref = g["feats_S2"]
+    for i, f in enumerate("abcd"):
+        for s in range(3):
+            assert np.abs(feats[f][s].numpy() - ref[s, i]).max() < 5e-6
+    feats_e, _ = ssg_amd.extract_features(m, loader, for_eval=True)
+    assert feats_e["a"].shape == (3 * 2048,) and abs(float(feats_e["a"].norm()) - 1.0) < 1e-5

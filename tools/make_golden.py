@@ -125,6 +125,59 @@ def exp_quirk_inputs():
     return allh, npx, cr, bad
 
 
+def embed_fixture():
+    """Embedding golden: the REAL reference model (reid.models.create + reid.evaluators.
+    extract_features) under stub torchvision/h5py/metric_learn modules,
+    loaded with the build's seeded synthetic weights, on 4 seeded 256x128 images."""
+    import types
+    import torch
+    import ssg_amd
+    from oracle import embed_oracle
+    spec = importlib.util.spec_from_file_location("ref_base", os.path.join(REF, "reid", "models", "base.py"))
+    base = importlib.util.module_from_spec(spec); spec.loader.exec_module(base)
+    tv = types.ModuleType("torchvision"); tvm = types.ModuleType("torchvision.models"); tvt = types.ModuleType("torchvision.transforms")
+    for n in ("resnet18", "resnet34", "resnet50", "resnet101", "resnet152"):
+        setattr(tvm, n, (lambda f: (lambda pretrained=False, **kw: f(pretrained=False, last_conv_stride=2)))(getattr(base, n)))
+    names = ["Resize", "ToTensor", "Normalize", "Compose", "RandomHorizontalFlip", "TenCrop", "Lambda", "CenterCrop"]
+    for n in names:
+        setattr(tvt, n, type(n, (), {}))
+    tvt.__all__ = names
+    tv.models = tvm; tv.transforms = tvt
+    h5 = types.ModuleType("h5py"); h5.File = object
+    ml = types.ModuleType("metric_learn")
+    for n in ("ITML_Supervised", "LMNN", "LSML_Supervised", "SDML_Supervised", "NCA", "LFDA", "RCA_Supervised"):
+        setattr(ml, n, object)
+    mlb = types.ModuleType("metric_learn.base_metric"); mlb.BaseMetricLearner = object
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.transforms": tvt, "h5py": h5,
+                        "metric_learn": ml, "metric_learn.base_metric": mlb})
+    sys.path.insert(0, REF)
+    import reid
+    torch.manual_seed(0)
+    ok = True
+    rec = {}
+    for S in (2, 1):
+        model = reid.models.create('resnet50', num_classes=0, num_split=S, cluster=False)
+        sd = ssg_amd.synthetic_state_dict(seed=1)
+        missing = model.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys, missing
+        model.eval()
+        g = torch.Generator().manual_seed(1)
+        imgs = torch.randn(4, 3, 256, 128, generator=g)
+        loader = [(imgs, ["f%d" % i for i in range(4)], [0, 1, 2, 3], [0, 0, 0, 0])]
+        feats, _ = reid.evaluators.extract_features(model, loader, for_eval=False)
+        if S > 1:
+            ref = torch.stack([torch.stack(feats["f%d" % i]) for i in range(4)], 1)      # [S+1, 4, 2048]
+        else:
+            ref = torch.stack([feats["f%d" % i] for i in range(4)]).unsqueeze(0)
+        mine = torch.stack(embed_oracle.embed_with_flip(sd, imgs, S))
+        err = (ref - mine).abs().max().item()
+        print("embed S=%d: torch-restatement vs reference max|diff| = %.3e  (feature |max| %.3e)" % (S, err, ref.abs().max().item()))
+        ok = ok and err < 1e-6
+        rec["feats_S%d" % S] = ref.numpy()
+    np.savez_compressed(os.path.join(OUT, "embed_ref.npz"), image_seed=1, weight_seed=1, **rec)
+    return ok
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ora.build(force=True)
@@ -233,6 +286,7 @@ def main():
         mats.append(D); epss.append(eps); labs.append(lab.astype(np.int64))
     np.savez_compressed(os.path.join(OUT, "dbscan_cases.npz"), D=np.stack(mats), eps=np.array(epss), labels=np.stack(labs))
 
+    ok = embed_fixture() and ok
     print("ALL OK" if ok else "ORACLE MISMATCH")
     sys.exit(0 if ok else 1)
 
