@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""bench.py -- one SSG grouping iteration per step on N GPUs of one node.
+
+Step (BASELINE.json configs[1]+[2], N=16 000): embed the source (12 936) and target (16 000)
+sets with ResNet-50 (256x128 synthetic images, original + flipped forward, L2 norm) -> full
+k-reciprocal re-rank distance (k1=20, k2=6, lambda=0.3) incl. the source term -> eps rule ->
+DBSCAN, all through the HIP kernels behind include/ssg_hip.h.  Inputs are resident in HBM when
+the timed region starts.  With N>1 ranks (torchrun) the images and the N x N row blocks are
+sharded and the embeddings / small tables all-gathered over RCCL (strong scaling, N fixed).
+
+Two synthetic tracks: random-init backbone features are degenerate (the
+reference NaNs on them, reid/rerank.py:40), so the grouping leg consumes clustered unit-norm
+embeddings of the same shape that are also HBM-resident; both legs are inside the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the fp32-MFMA implicit
+GEMM convolution); `roofline_kernels` lists the HBM-bound distance / re-rank / DBSCAN kernels
+against their algorithmic bytes; `cpu_baseline` times the CPU oracle (a port
+of the reference algorithm) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_FP64_MFMA_TF = 78.6      # SURVEY.md 8d / BASELINE.md
+PEAK_HBM_GBS = 8000.0         # HBM3E spec
+FLOP_PER_IMAGE = 10.68e9      # 2 forwards x 2 x 2.669 GMAC
+
+
+def clustered(N, d, seed, per_id=16, intra=0.5, device="cpu"):
+    """Track-G embeddings: N/16 unit-norm identity centres + isotropic noise, renormalised."""
+    g = torch.Generator().manual_seed(seed)
+    P = max(1, N // per_id)
+    c = torch.randn(P, d, generator=g, dtype=torch.float64); c /= c.norm(dim=1, keepdim=True)
+    sigma = (intra / 2.0 / d) ** 0.5
+    x = c[torch.arange(N) % P] + sigma * torch.randn(N, d, generator=g, dtype=torch.float64)
+    x /= x.norm(dim=1, keepdim=True)
+    return x.float().to(device)
+
+
+class KernelTimer:
+    """HIP-event timing of individual C-ABI launches on the stream they are launched on."""
+
+    def __init__(self, L):
+        self.L, self.ev, self.on = L, {}, False
+
+    def __getattr__(self, k):
+        fn = getattr(self.L, k)
+        if not self.on or not k.startswith("ssg_") or k in ("ssg_last_error", "ssg_krecip_row_capacity", "ssg_double_to_half_bits",
+                                                            "ssg_eps_mean_workspace_bytes", "ssg_dbscan_cc_workspace_bytes", "ssg_version"):
+            return fn
+
+        def timed(*a):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); rc = fn(*a); e1.record()
+            self.ev.setdefault(k, []).append((e0, e1))
+            return rc
+        return timed
+
+    def totals(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.ev.items()}
+
+
+def cpu_baseline(args):
+    """Oracle ("port" of the reference algorithm, oracle/ssg_oracle.c + oracle/embed_oracle.py)
+    on this box's host cores, bounded sample."""
+    from oracle import ssg_oracle as ora, embed_oracle
+    import ssg_amd
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = ssg_amd.synthetic_state_dict(seed=1)
+    imgs = torch.randn(args.cpu_images, 3, 256, 128, generator=torch.Generator().manual_seed(1))
+    t0 = time.time(); embed_oracle.embed_with_flip(sd, imgs, 1); t_embed = time.time() - t0
+    n = args.cpu_n
+    tgt = clustered(n, 2048, 1).numpy(); src = clustered(n, 2048, 2, intra=0.7).numpy()
+    t0 = time.time()
+    _, final = ora.re_ranking(src, tgt, k1=20, k2=6, lambda_value=0.3)
+    t_rr = time.time() - t0
+    t0 = time.time()
+    eps, _, _ = ora.eps_rule(final, 1.6e-3); ora.dbscan(final, eps, 4)
+    t_cl = time.time() - t0
+    img_s = args.cpu_images / t_embed
+    # extrapolation of the grouping leg to the bench size with the N*(N+Ns)*d cost model
+    scale = (args.N * (args.N + args.Ns)) / float(n * (n + n))
+    est_iter = (args.N + args.Ns) / img_s + (t_rr + t_cl) * scale
+    return {"value": round((args.N + args.Ns) / est_iter, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "embed: %d images 256x128 incl. flip, torch fp32 %d threads (%.2f img/s measured); grouping: oracle re_ranking+eps+DBSCAN at "
+                      "N=Ns=%d d=2048, %d OpenMP threads (%.2f s measured), extrapolated to N=%d,Ns=%d by N*(N+Ns)" % (
+                          args.cpu_images, cores, img_s, n, ora.num_threads(), t_rr + t_cl, args.N, args.Ns),
+            "embed_images_per_s": round(img_s, 3), "rerank_dbscan_s_measured": round(t_rr + t_cl, 3), "rerank_dbscan_N": n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--N", type=int, default=16000)
+    ap.add_argument("--Ns", type=int, default=12936)
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--lambda_value", type=float, default=0.3)
+    ap.add_argument("--rho", type=float, default=1.6e-3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=64)
+    ap.add_argument("--cpu-n", type=int, default=3000)
+    args = ap.parse_args()
+
+    import ssg_amd
+    from ssg_amd import _lib, cluster, dist as sdist, rerank
+    rank, world, group = sdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d, --gpus %d)" % (args.gpus, world, args.gpus))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if args.N % world:
+        raise SystemExit("N must be divisible by the number of GPUs")
+    timer = KernelTimer(_lib.lib())
+    _lib._lib = timer
+
+    # ---- inputs resident in HBM before the timed region
+    model = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1).cuda(local).eval()
+    t_lo, t_hi = sdist.shard_bounds(args.N, rank, world)
+    s_lo, s_hi = sdist.shard_bounds(args.Ns, rank, world)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    tgt_imgs = torch.randn(t_hi - t_lo, 3, 256, 128, generator=g, device=dev)
+    src_imgs = torch.randn(s_hi - s_lo, 3, 256, 128, generator=g, device=dev)
+    tgt_emb = clustered(args.N, 2048, 1, device=dev)
+    src_emb = clustered(args.Ns, 2048, 2, intra=0.7, device=dev)
+    nrows = args.N // world
+    row0 = rank * nrows
+
+    def embed(imgs):
+        out = []
+        for i in range(0, imgs.shape[0], args.batch):
+            out.append(model.embed_with_flip(imgs[i:i + args.batch]))
+        return torch.cat(out, 0)
+
+    def step():
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        f_src = sdist.gather_varlen(embed(src_imgs), group)      # C1: all-gather of the embeddings over xGMI
+        f_tgt = sdist.gather_varlen(embed(tgt_imgs), group)
+        ev[1].record()
+        assert f_tgt.shape == (args.N, 2048) and f_src.shape == (args.Ns, 2048)
+        h = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False,
+                                     row0=row0, nrows=nrows, group=group)
+        ev[2].record()
+        eps, cnt, top = cluster.eps_rule(h, args.rho)
+        labels = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h)
+        ev[3].record()
+        return ev, eps, labels
+
+    def sync_barrier():
+        torch.cuda.synchronize()
+        sdist.barrier(group)
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_barrier()
+    timer.on = True
+    legs = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev, eps, labels = step()
+        legs.append(ev)
+    sync_barrier()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    if group is not None:
+        import torch.distributed as tdist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX, group=group)
+        elapsed = float(t.item())
+    ms_step = elapsed * 1e3 / args.steps
+    t_embed = sum(e[0].elapsed_time(e[1]) for e in legs) / args.steps
+    t_rerank = sum(e[1].elapsed_time(e[2]) for e in legs) / args.steps
+    t_cluster = sum(e[2].elapsed_time(e[3]) for e in legs) / args.steps
+    tot = timer.totals()
+
+    if rank != 0:
+        return
+    n_img = args.N + args.Ns
+    # ---- roofline of the dominant kernel: implicit-GEMM convolution on the fp32 matrix cores
+    n_conv, ms_conv = tot.get("ssg_conv2d_nhwc_f32", (1, float("nan")))
+    imgs_rank = (t_hi - t_lo) + (s_hi - s_lo)
+    conv_tf = imgs_rank * args.steps * FLOP_PER_IMAGE / (ms_conv * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2, 53 convs x 2 orientations per image)",
+            "achieved": round(conv_tf, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s", "frac": round(conv_tf / PEAK_FP32_MFMA_TF, 4),
+            "traffic": None, "launches": n_conv, "avg_launch_ms": round(ms_conv / max(n_conv, 1), 4),
+            "algorithmic": "10.68 GFLOP per image (2 forwards x 5.34 GFLOP) x %d images per rank-step" % imgs_rank}
+    nn2 = 2.0 * nrows * args.N   # bytes of one half row block
+    hbm = []
+    for k, byt, what in (("ssg_topk_rank", nn2, "reads D (2*N^2 B)"), ("ssg_jaccard_rows", nn2, "writes J' (2*N^2 B)"),
+                         ("ssg_eps_hist", nn2 / 2, "reads upper triangle of J' (N^2 B) per level"),
+                         ("ssg_eps_compact", nn2 / 2, "reads upper triangle of J' (N^2 B)"),
+                         ("ssg_region_query", nn2, "reads J' (2*N^2 B)")):
+        if k in tot:
+            n, ms = tot[k]
+            gbs = byt * n / (ms * 1e-3) / 1e9
+            hbm.append({"kernel": k, "bound": "hbm", "what": what, "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(gbs, 1),
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    for k, flop in (("ssg_sqdist_self_f16", 2.0 * nrows * args.N * 2048), ("ssg_source_rowmin_f16", 2.0 * nrows * args.Ns * 2048)):
+        if k in tot:
+            n, ms = tot[k]
+            tf = flop * n / (ms * 1e-3) / 1e12
+            hbm.append({"kernel": k, "bound": "mfma", "what": "fp64 Gram (v_mfma_f64_16x16x4)", "launches": n, "avg_launch_ms": round(ms / n, 4),
+                        "achieved": round(tf, 2), "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_MFMA_TF, 4)})
+    hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
+                                    "ssg_eps_compact", "ssg_sort_u64", "ssg_eps_mean", "ssg_region_query", "ssg_dbscan_cc") if k in tot) / args.steps
+    k5_12 = 8.0 * nrows * args.N / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else float("nan")
+    out = {
+        "metric": "images/s embed + s/iter for NxN rerank+DBSCAN, N=16k, 1/2/4/8 GPU",
+        "value": round(n_img / (ms_step * 1e-3), 2), "unit": "images/s (embedded + grouped per wall second, whole iteration)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32 (embed, fp32 MFMA) / f64+f16 (distance, re-rank: fp64 MFMA, half semantics)",
+        "data": "synthetic: N(0,1) 256x128 images + seeded Kaiming ResNet-50 weights for the embed leg; clustered unit-norm 2048-d embeddings "
+                "(16 per identity) for the grouping leg (random-init backbone features are degenerate: reid/rerank.py:40 NaN path)",
+        "config": {"workload": "BASELINE configs[1]+[2]: N=%d target + Ns=%d source images -> ResNet-50 2048-d embed (orig+flip) -> "
+                               "k-reciprocal re-rank (k1=20,k2=6,lambda=%.1f) -> eps rule (rho=%.1e) -> DBSCAN(min_samples=4), 1 feature split"
+                               % (args.N, args.Ns, args.lambda_value, args.rho),
+                   "N": args.N, "Ns": args.Ns, "d": 2048, "embed_batch": args.batch, "parallelism": "images + NxN row blocks sharded over %d GPU(s)" % world},
+        "embed_images_per_s": round(n_img / (t_embed * 1e-3), 1), "embed_ms": round(t_embed, 2),
+        "rerank_dbscan_s_per_iter": round((t_rerank + t_cluster) * 1e-3, 5), "rerank_ms": round(t_rerank, 3), "eps_dbscan_ms": round(t_cluster, 3),
+        "labels": {"clusters": int(labels.max() + 1), "noise": int((labels < 0).sum()), "eps": eps},
+        "roofline": roof, "roofline_kernels": hbm,
+        "roofline_k5_k12": {"bound": "hbm", "achieved": round(k5_12, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k5_12 / PEAK_HBM_GBS, 4),
+                            "algorithmic": "8*N^2 bytes per split over all K5..K12 kernel time (SURVEY.md 8d)", "kernel_ms": round(hbm_ms, 3)},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        _lib._lib = timer.L
+        out["cpu_baseline"] = cpu_baseline(args)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

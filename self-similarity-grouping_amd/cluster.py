@@ -21,11 +21,7 @@ _LEVELS = ((51, 12), (39, 12), (27, 12), (15, 12), (3, 12), (0, 3))   # (shift, 
 _MAX_COMPACT = 1 << 24
 
 
-def _all_reduce(t, group):
-    if group is not None:
-        import torch.distributed as dist
-        dist.all_reduce(t, group=group)
-    return t
+from .dist import all_reduce_sum as _all_reduce, gather_rows, gather_varlen  # noqa: E402
 
 
 def as_handle(X, device=None):
@@ -88,23 +84,12 @@ def eps_rule(X, rho):
     buf = torch.empty(n_pow2, dtype=torch.int64, device=dev)
     cursor = torch.zeros(1, dtype=torch.int64, device=dev)
     check(L.ssg_eps_compact(*args, key_max, ptr(buf), n_pow2, ptr(cursor), st), "ssg_eps_compact")
+    got = int(cursor.item())
     if h.group is not None:
         # sharded rows: gather the (small) candidate sets of every rank
-        import torch.distributed as dist
-        ws = dist.get_world_size(h.group)
-        n_loc = cursor.clone()
-        sizes = [torch.zeros_like(n_loc) for _ in range(ws)]
-        dist.all_gather(sizes, n_loc, group=h.group)
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(sizes + [1])
-        pad = torch.full((mx,), -1, dtype=torch.int64, device=dev)
-        pad[: sizes[dist.get_rank(h.group)]] = buf[: sizes[dist.get_rank(h.group)]]
-        parts = [torch.empty_like(pad) for _ in range(ws)]
-        dist.all_gather(parts, pad, group=h.group)
-        buf[: sum(sizes)] = torch.cat([p[:s] for p, s in zip(parts, sizes)])
-        got = sum(sizes)
-    else:
-        got = int(cursor.item())
+        allk = gather_varlen(buf[:got], h.group)
+        got = int(allk.shape[0])
+        buf[:got] = allk
     if got != ncand:
         raise _lib.SSGError("eps_rule: compaction found %d keys, histogram promised %d" % (got, ncand))
     check(L.ssg_fill_u64(ptr(buf), got, n_pow2, 0xFFFFFFFFFFFFFFFF, st), "ssg_fill_u64")
@@ -158,20 +143,9 @@ class DBSCAN:
             cap = ne   # the cursor counted every hit: retry once with the exact size
         edges = edges[:ne]
         if h.group is not None:
-            import torch.distributed as dist
-            ws = dist.get_world_size(h.group)
-            cnt_all = torch.empty(N, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(cnt_all, cnt, group=h.group)
-            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(ws)]
-            dist.all_gather(sizes, torch.tensor([ne], dtype=torch.int64, device=dev), group=h.group)
-            sizes = [int(s.item()) for s in sizes]
-            mx = max(sizes + [1])
-            pad = torch.zeros((mx, 2), dtype=torch.int32, device=dev)
-            pad[:ne] = edges
-            parts = [torch.empty_like(pad) for _ in range(ws)]
-            dist.all_gather(parts, pad, group=h.group)
-            edges = torch.cat([p[:s] for p, s in zip(parts, sizes)]).contiguous()
-            cnt, ne = cnt_all, sum(sizes)
+            cnt = gather_rows(cnt, h.group)
+            edges = gather_varlen(edges, h.group).contiguous()
+            ne = int(edges.shape[0])
         ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         labels = torch.empty(N, dtype=torch.int64, device=dev)

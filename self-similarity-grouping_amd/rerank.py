@@ -90,15 +90,7 @@ def source_vector(src, tgt, row0=0, nrows=None):
     return rowmin
 
 
-def _gather_rows(t, group):
-    """all-gather equally-sized row blocks over the RCCL/gloo group (no-op without a group)."""
-    if group is None:
-        return t
-    import torch.distributed as dist
-    ws = dist.get_world_size(group)
-    out = torch.empty((ws * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
-    return out
+from .dist import gather_rows as _gather_rows  # noqa: E402
 
 
 def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, keep_euclid=True, row0=0, nrows=None,
@@ -158,6 +150,12 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
         q_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
         check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, ptr(q_idx), ptr(q_val),
                                  ptr(q_nnz), st), "ssg_query_expand")
+        if group is not None:
+            # ship only the used part of the fixed-capacity rows over xGMI
+            import torch.distributed as dist
+            m = q_nnz.max().clone(); dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+            capQ = max(int(m.item()), 1)
+            q_idx, q_val = q_idx[:, :capQ].contiguous(), q_val[:, :capQ].contiguous()
         q_idx, q_val, q_nnz = _gather_rows(q_idx, group), _gather_rows(q_val, group), _gather_rows(q_nnz, group)
     else:
         capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
