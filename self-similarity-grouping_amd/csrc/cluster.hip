@@ -129,11 +129,32 @@ __global__ __launch_bounds__(256) void eps_hist_kernel(MatView mv, unsigned long
   if (threadIdx.x == 0 && count_nonzero && lnz) atomicAdd(&hist[4096], lnz);
 }
 
-// append every strict-upper non-zero key <= key_max to buf (wave-aggregated cursor)
+// Per-wave staging buffer in LDS: results are appended with ballot prefix sums and flushed to a
+// global list with ONE cursor atomic per ~512 entries (a per-chunk atomic on one word saturates
+// at ~90 ops/us and was the bottleneck of the first version).
+constexpr int STAGE_CAP = 1024;
+template <typename T>
+struct WaveStage {
+  T* buf; int n;
+  __device__ __forceinline__ void flush(T* __restrict__ out, unsigned long long cap, unsigned long long* __restrict__ cursor, int lane) {
+    if (n == 0) return;
+    unsigned long long basep = 0;
+    if (lane == 0) basep = atomicAdd(cursor, (unsigned long long)n);
+    basep = (unsigned long long)__shfl((long long)basep, 0, 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int x = lane; x < n; x += 64) if (basep + x < cap) out[basep + x] = buf[x];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    n = 0;
+  }
+};
+
+// append every strict-upper non-zero key <= key_max to buf
 template <int MODE>
 __global__ __launch_bounds__(256) void eps_compact_kernel(MatView mv, unsigned long long key_max, unsigned long long* __restrict__ buf,
                                                           unsigned long long cap, unsigned long long* __restrict__ cursor) {
+  __shared__ unsigned long long sbuf[4][STAGE_CAP];
   const int lane = lane_id();
+  WaveStage<unsigned long long> st{sbuf[threadIdx.x >> 6], 0};
   for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
     const int gi = mv.row0 + il;
     RowStream rs(il, mv.N, mv.nrows);
@@ -157,14 +178,14 @@ __global__ __launch_bounds__(256) void eps_compact_kernel(MatView mv, unsigned l
       int incl = n;
       for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
       const int tot = __shfl(incl, 63, 64);
-      unsigned long long basep = 0;
-      if (lane == 0) basep = atomicAdd(cursor, (unsigned long long)tot);
-      basep = (unsigned long long)__shfl((long long)basep, 0, 64);
-      unsigned long long w = basep + (unsigned long long)(incl - n);
+      int w = st.n + incl - n;
 #pragma unroll
-      for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) { if (w < cap) buf[w] = keys[e]; w++; }
+      for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) st.buf[w++] = keys[e];
+      st.n += tot;
+      if (st.n > STAGE_CAP - 512) st.flush(buf, cap, cursor, lane);
     }
   }
+  st.flush(buf, cap, cursor, lane);
 }
 
 __global__ void fill_u64_kernel(unsigned long long* p, unsigned long long n0, unsigned long long n1, unsigned long long v) {
@@ -281,11 +302,15 @@ __global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long
 }
 
 // ------------------------------------------------------------------ K11 region query
-// cnt[il] = #{k : d(i,k) <= eps} (self included when d(i,i) <= eps);  edges (i,k), k != i.
+// cnt[il] = #{k : d(i,k) <= eps} (self included when d(i,i) <= eps);  edges (i,k) incl. self hits.
+struct Edge { int i, k; };
 template <int MODE>
 __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
                                                            unsigned long long cap, unsigned long long* __restrict__ cursor) {
+  __shared__ Edge sbuf[4][STAGE_CAP];
   const int lane = lane_id();
+  WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
+  Edge* eout = reinterpret_cast<Edge*>(edges);
   for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
     const int gi = mv.row0 + il;
     RowStream rs(il, mv.N, mv.nrows);
@@ -306,18 +331,15 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
       for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
       const int tot = __shfl(incl, 63, 64);
       rowcnt += tot;
-      unsigned long long basep = 0;
-      if (lane == 0) basep = atomicAdd(cursor, (unsigned long long)tot);
-      basep = (unsigned long long)__shfl((long long)basep, 0, 64);
-      unsigned long long w = basep + (unsigned long long)(incl - n);
+      int w = st.n + incl - n;
 #pragma unroll
-      for (int e = 0; e < 8; e++) if (hitmask & (1u << e)) {
-        if (w < cap) { edges[2 * w] = gi; edges[2 * w + 1] = j0 + e; }
-        w++;
-      }
+      for (int e = 0; e < 8; e++) if (hitmask & (1u << e)) { st.buf[w].i = gi; st.buf[w].k = j0 + e; w++; }
+      st.n += tot;
+      if (st.n > STAGE_CAP - 512) st.flush(eout, cap, cursor, lane);
     }
     if (lane == 0) cnt[il] = rowcnt;
   }
+  st.flush(eout, cap, cursor, lane);
 }
 
 // ------------------------------------------------------------------ K12 union-find

@@ -11,8 +11,8 @@
 // the weights/bias on the host; bias + residual add + ReLU are fused into the epilogue, so a
 // bottleneck block costs 3 (4 with downsample) launches and no elementwise passes.
 //
-// Tile: BM x BN output tile per 256-thread workgroup, 4 waves of 64x64 (2x2 MFMA tiles, 64
-// accumulator VGPRs), BK = 32.  A and W tiles are staged through LDS as [row][36 floats]
+// Tile: 128x128 (128x64 when Cout = 64) output tile per 256-thread workgroup, 4 waves of 64x64
+// (64x32) = 2x2 (2x1) MFMA tiles, BK = 32, double-buffered LDS.  A and W tiles are staged through LDS as [row][36 floats]
 // (144-byte rows: ds_read_b128 fragment reads and ds_write_b128 staging writes are both
 // bank-conflict free).  Each lane reads 4 consecutive k of its row per ds_read_b128; the k
 // order inside a group of 8 is permuted identically for A and W (lane>>5 selects k0..3 or
@@ -37,15 +37,21 @@ __device__ __forceinline__ int conv_xcd_remap(int b, int nwg) {
 }
 
 // CIN4: stem mode, input has 4 channels (RGB + zero), one float4 = one filter tap.
-template <int BM, int BN, bool CIN4>
+// Workgroup tile BM x BN, 4 waves in a (BM/WM) x (BN/WN) grid, each wave WM x WN = MT x NT MFMA
+// tiles of 32x32.  LDS is double buffered: the next K tile is fetched into registers while the
+// current one is multiplied and written to the other buffer afterwards -> one barrier per K tile.
+// The MFMA is issued as D = W_tile * A_tile^T (weights are the A operand), so a lane ends up
+// with 4 consecutive output channels of one pixel per accumulator quad: bias/residual/output
+// move as float4.
+template <int BM, int BN, int WM, int WN, bool CIN4>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
-  constexpr int WROWS = BM / 64;            // waves along m (BM=128 -> 2, BM=256 -> 4)
-  constexpr int WCOLS = 4 / WROWS;          // waves along n
-  static_assert(WCOLS * 64 == BN, "tile/wave layout mismatch");
+  constexpr int WCOLS = BN / WN;
+  static_assert((BM / WM) * WCOLS == 4, "4 waves per workgroup");
+  constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int AJ = BM / 32, BJ = BN / 32; // float4 loads per thread for the A / W tile
+  constexpr int STAGE = (BM + BN) * CLD;    // floats per LDS stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // one declaration shared by the unity TU
-  float* As = reinterpret_cast<float*>(smem);
-  float* Bs = As + BM * CLD;
+  float* lds = reinterpret_cast<float*>(smem);
 
   const int tiles_n = p.Cout / BN, tiles_m = (p.M + BM - 1) / BM;
   const int tile = conv_xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
@@ -84,61 +90,72 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < BJ; j++) pb[j] = *reinterpret_cast<const float4*>(wrow[j] + kt * CBK);
   };
+  auto lstore = [&](int buf) {
+    float* As = lds + buf * STAGE;
+    float* Bs = As + BM * CLD;
+#pragma unroll
+    for (int j = 0; j < AJ; j++) *reinterpret_cast<float4*>(As + (r0 + 32 * j) * CLD + kq * 4) = pa[j];
+#pragma unroll
+    for (int j = 0; j < BJ; j++) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * CLD + kq * 4) = pb[j];
+  };
 
-  v16f acc[2][2];
+  v16f acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < MT; i++)
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NT; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int nk = p.Kpad / CBK;
   const int l32 = lane & 31, h = lane >> 5;
   gload(0);
+  lstore(0);
+  __syncthreads();
   for (int kt = 0; kt < nk; kt++) {
-#pragma unroll
-    for (int j = 0; j < AJ; j++) *reinterpret_cast<float4*>(As + (r0 + 32 * j) * CLD + kq * 4) = pa[j];
-#pragma unroll
-    for (int j = 0; j < BJ; j++) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * CLD + kq * 4) = pb[j];
-    __syncthreads();
-    if (kt + 1 < nk) gload(kt + 1);
+    if (kt + 1 < nk) gload(kt + 1);          // HBM/L2 latency hides under this tile's MFMAs
+    const float* As = lds + (kt & 1) * STAGE;
+    const float* Bs = As + BM * CLD;
 #pragma unroll
     for (int g = 0; g < CBK / 8; g++) {
-      float4 a[2], b[2];
+      float4 a[MT], b[NT];
 #pragma unroll
-      for (int i = 0; i < 2; i++) a[i] = *reinterpret_cast<const float4*>(As + (wm * 64 + i * 32 + l32) * CLD + g * 8 + h * 4);
+      for (int i = 0; i < MT; i++) a[i] = *reinterpret_cast<const float4*>(As + (wm * WM + i * 32 + l32) * CLD + g * 8 + h * 4);
 #pragma unroll
-      for (int j = 0; j < 2; j++) b[j] = *reinterpret_cast<const float4*>(Bs + (wn * 64 + j * 32 + l32) * CLD + g * 8 + h * 4);
+      for (int j = 0; j < NT; j++) b[j] = *reinterpret_cast<const float4*>(Bs + (wn * WN + j * 32 + l32) * CLD + g * 8 + h * 4);
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+      for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].x, a[i].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].y, a[i].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
         }
     }
+    if (kt + 1 < nk) lstore((kt + 1) & 1);   // other buffer: its readers finished before the last barrier
     __syncthreads();
   }
 
-  // epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue.  D = W * A^T: C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // -> channel; accumulator quad q holds channels 8q + 4h + {0,1,2,3} of one pixel.
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int col = tn * BN + wn * 64 + j * 32 + l32;
-    const float bias = p.bias[col];
+  for (int i = 0; i < MT; i++) {
+    const int m = tm * BM + wm * WM + i * 32 + l32;
+    if (m >= p.M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int j = 0; j < NT; j++) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = tm * BM + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m < p.M) {
-          float v = acc[i][j][r] + bias;
-          if (p.res) v += p.res[(int64_t)m * p.Cout + col];
-          if (p.relu) v = v > 0.f ? v : 0.f;
-          p.out[(int64_t)m * p.Cout + col] = v;
+      for (int q = 0; q < 4; q++) {
+        const int col = tn * BN + wn * WN + j * 32 + 8 * q + 4 * h;
+        const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
+        float4 v = make_float4(acc[i][j][4 * q] + bias.x, acc[i][j][4 * q + 1] + bias.y, acc[i][j][4 * q + 2] + bias.z, acc[i][j][4 * q + 3] + bias.w);
+        if (p.res) {
+          const float4 rr = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.Cout + col);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
+        if (p.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+        *reinterpret_cast<float4*>(p.out + (int64_t)m * p.Cout + col) = v;
       }
     }
   }
@@ -210,11 +227,18 @@ __global__ __launch_bounds__(256) void flip_sum_l2norm_kernel(const float* __res
 
 using namespace ssg;
 
-template <int BM, int BN, bool CIN4>
+template <int BM, int BN, int WM, int WN, bool CIN4>
 static int launch_conv(const ConvParams& p, hipStream_t stream) {
-  const size_t lds = (size_t)(BM + BN) * CLD * sizeof(float);
+  const size_t lds = 2 * (size_t)(BM + BN) * CLD * sizeof(float);
   const int tiles = ((p.M + BM - 1) / BM) * (p.Cout / BN);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, CIN4>), dim3(tiles), dim3(256), lds, stream, p);
+  static bool attr_set = false;
+  if (lds > 64 * 1024 && !attr_set) {
+    int rc = ssg_check_hip(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, CIN4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                           "hipFuncSetAttribute(conv)");
+    if (rc) return rc;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, CIN4>), dim3(tiles), dim3(256), lds, stream, p);
   return ssg_check_hip(hipGetLastError(), "conv_igemm_kernel");
 }
 
@@ -236,8 +260,8 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
   p.M = (int)M;
   const bool cin4 = (Cin == 4);
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
-  if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, true>(p, stream) : launch_conv<256, 64, true>(p, stream);
-  return (Cout % 128 == 0) ? launch_conv<128, 128, false>(p, stream) : launch_conv<256, 64, false>(p, stream);
+  if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);
+  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
 extern "C" int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, hipStream_t stream) {
