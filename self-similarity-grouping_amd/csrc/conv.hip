@@ -18,6 +18,7 @@
 // order inside a group of 8 is permuted identically for A and W (lane>>5 selects k0..3 or
 // k4..7), which the reduction does not care about.
 #include "ssg_common.h"
+#include <cstdlib>
 
 namespace ssg {
 
@@ -27,6 +28,7 @@ struct ConvParams {
   const float* in; const float* w; const float* bias; const float* res; float* out;
   int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu;
   int M, Kpad;   // M = B*OH*OW, Kpad = weight row length (multiple of 32)
+  int variant;   // tuning knob (SSG_CONV_VARIANT), 0 = default
 };
 
 constexpr int CBK = 32, CLD = 36;
@@ -60,44 +62,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   const int wm = wave / WCOLS, wn = wave % WCOLS;
   const int kq = tid & 7, r0 = tid >> 3;
 
-  // per staged A row: input coordinates of filter tap (0,0)
-  int a_b[AJ], a_ih[AJ], a_iw[AJ];
-#pragma unroll
-  for (int j = 0; j < AJ; j++) {
-    const int m = tm * BM + r0 + 32 * j;
-    if (m < p.M) {
-      const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
-      a_b[j] = b; a_ih[j] = oh * p.stride - p.pad; a_iw[j] = ow * p.stride - p.pad;
-    } else { a_b[j] = -1; a_ih[j] = 0; a_iw[j] = 0; }
+  // Staging state is kept in NAMED scalars, not arrays: hipcc left `float4 pb[BJ]` in scratch
+  // memory (the prefetch then waited on every load to bounce it through the stack).
+  static_assert(AJ == 4 && (BJ == 4 || BJ == 2), "staging code is written for BM=128, BN in {64,128}");
+  int ab0, ab1, ab2, ab3, ah0, ah1, ah2, ah3, aw0, aw1, aw2, aw3;
+#define SSG_ROW_INIT(J)                                                            \
+  {                                                                                \
+    const int m = tm * BM + r0 + 32 * J;                                           \
+    if (m < p.M) {                                                                 \
+      const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);                \
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;                             \
+      ab##J = b; ah##J = oh * p.stride - p.pad; aw##J = ow * p.stride - p.pad;     \
+    } else { ab##J = -1; ah##J = 0; aw##J = 0; }                                   \
   }
-  const float* wrow[BJ];
-#pragma unroll
-  for (int j = 0; j < BJ; j++) wrow[j] = p.w + (int64_t)(tn * BN + r0 + 32 * j) * p.Kpad + kq * 4;
+  SSG_ROW_INIT(0) SSG_ROW_INIT(1) SSG_ROW_INIT(2) SSG_ROW_INIT(3)
+#undef SSG_ROW_INIT
+  const float* wbase = p.w + (int64_t)(tn * BN + r0) * p.Kpad + kq * 4;
+  const int64_t wstep = (int64_t)32 * p.Kpad;
+  float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
+  pb2 = pb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float4 pa[AJ], pb[BJ];
-  auto gload = [&](int kt) {
-    int r, s, c;
-    if (CIN4) { const int tap = kt * 8 + kq; r = tap / p.KW; s = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; }
-    else { const int k0 = kt * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; }
-#pragma unroll
-    for (int j = 0; j < AJ; j++) {
-      const int ih = a_ih[j] + r, iw = a_iw[j] + s;
-      const bool ok = a_b[j] >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;
-      pa[j] = ok ? *reinterpret_cast<const float4*>(p.in + ((int64_t)(a_b[j] * p.H + ih) * p.W + iw) * p.Cin + c)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < BJ; j++) pb[j] = *reinterpret_cast<const float4*>(wrow[j] + kt * CBK);
-  };
-  auto lstore = [&](int buf) {
-    float* As = lds + buf * STAGE;
-    float* Bs = As + BM * CLD;
-#pragma unroll
-    for (int j = 0; j < AJ; j++) *reinterpret_cast<float4*>(As + (r0 + 32 * j) * CLD + kq * 4) = pa[j];
-#pragma unroll
-    for (int j = 0; j < BJ; j++) *reinterpret_cast<float4*>(Bs + (r0 + 32 * j) * CLD + kq * 4) = pb[j];
-  };
+  // unconditional loads from a clamped in-bounds address + select: a load under a branch makes
+  // hipcc wait for it on the spot
+#define SSG_LOAD_A(J)                                                                                   \
+  {                                                                                                     \
+    const int ih = ah##J + r, iw = aw##J + s_;                                                          \
+    const bool ok = ab##J >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                           \
+    const int64_t off = ok ? ((int64_t)(ab##J * p.H + ih) * p.W + iw) * p.Cin + c : 0;                  \
+    const float4 v = *reinterpret_cast<const float4*>(p.in + off);                                      \
+    pa##J = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+  }
+#define SSG_GLOAD(KT)                                                                                   \
+  {                                                                                                     \
+    int r, s_, c;                                                                                       \
+    if (CIN4) { const int tap = (KT) * 8 + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; } \
+    else { const int k0 = (KT) * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s_ = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; } \
+    SSG_LOAD_A(0) SSG_LOAD_A(1) SSG_LOAD_A(2) SSG_LOAD_A(3)                                             \
+    pb0 = *reinterpret_cast<const float4*>(wbase + (KT) * CBK);                                         \
+    pb1 = *reinterpret_cast<const float4*>(wbase + wstep + (KT) * CBK);                                 \
+    if (BJ == 4) {                                                                                      \
+      pb2 = *reinterpret_cast<const float4*>(wbase + 2 * wstep + (KT) * CBK);                           \
+      pb3 = *reinterpret_cast<const float4*>(wbase + 3 * wstep + (KT) * CBK);                           \
+    }                                                                                                   \
+  }
+#define SSG_LSTORE(BUF)                                                                                 \
+  {                                                                                                     \
+    float* As_ = lds + (BUF) * STAGE;                                                                   \
+    float* Bs_ = As_ + BM * CLD;                                                                        \
+    *reinterpret_cast<float4*>(As_ + (r0 + 0) * CLD + kq * 4) = pa0;                                    \
+    *reinterpret_cast<float4*>(As_ + (r0 + 32) * CLD + kq * 4) = pa1;                                   \
+    *reinterpret_cast<float4*>(As_ + (r0 + 64) * CLD + kq * 4) = pa2;                                   \
+    *reinterpret_cast<float4*>(As_ + (r0 + 96) * CLD + kq * 4) = pa3;                                   \
+    *reinterpret_cast<float4*>(Bs_ + (r0 + 0) * CLD + kq * 4) = pb0;                                    \
+    *reinterpret_cast<float4*>(Bs_ + (r0 + 32) * CLD + kq * 4) = pb1;                                   \
+    if (BJ == 4) {                                                                                      \
+      *reinterpret_cast<float4*>(Bs_ + (r0 + 64) * CLD + kq * 4) = pb2;                                 \
+      *reinterpret_cast<float4*>(Bs_ + (r0 + 96) * CLD + kq * 4) = pb3;                                 \
+    }                                                                                                   \
+  }
 
   v16f acc[MT][NT];
 #pragma unroll
@@ -109,11 +131,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 
   const int nk = p.Kpad / CBK;
   const int l32 = lane & 31, h = lane >> 5;
-  gload(0);
-  lstore(0);
+  // co-resident workgroups start in lockstep and would hit their non-MFMA phases together;
+  // distinct static priorities de-phase them so one wave's MFMAs cover the other's staging.
+  if (p.variant & 1) {
+    const int pr = ((int)blockIdx.x >> 8) & 3;
+    if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+  }
+  SSG_GLOAD(0)
+  SSG_LSTORE(0)
   __syncthreads();
   for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk) gload(kt + 1);          // HBM/L2 latency hides under this tile's MFMAs
+    if (kt + 1 < nk) SSG_GLOAD(kt + 1)        // HBM/L2 latency hides under this tile's MFMAs
     const float* As = lds + (kt & 1) * STAGE;
     const float* Bs = As + BM * CLD;
 #pragma unroll
@@ -133,10 +161,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
         }
     }
-    if (kt + 1 < nk) lstore((kt + 1) & 1);   // other buffer: its readers finished before the last barrier
+    if (kt + 1 < nk) SSG_LSTORE((kt + 1) & 1) // other buffer: its readers finished before the last barrier
     __syncthreads();
   }
 
+#undef SSG_LOAD_A
+#undef SSG_GLOAD
+#undef SSG_LSTORE
   // epilogue.  D = W * A^T: C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   // -> channel; accumulator quad q holds channels 8q + 4h + {0,1,2,3} of one pixel.
 #pragma unroll
@@ -258,6 +289,9 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
     return SSG_ERR_INVALID;
   }
   p.M = (int)M;
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("SSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
+  p.variant = variant;
   const bool cin4 = (Cin == 4);
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
   if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);

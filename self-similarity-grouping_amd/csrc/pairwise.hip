@@ -89,9 +89,13 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
   auto gload = [&](int kt) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
+      // unconditional loads (clamped address) + select: loads under a branch are waited for on the spot
       const int k = kt * BK + shalf * 16 + q * 4;
-      pa[q] = (aok && k < d) ? *reinterpret_cast<const float4*>(ap + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-      pb[q] = (bok && k < d) ? *reinterpret_cast<const float4*>(bp + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool kin = k < d;
+      const float4 va = *reinterpret_cast<const float4*>(ap + (kin ? k : 0));
+      const float4 vb = *reinterpret_cast<const float4*>(bp + (kin ? k : 0));
+      pa[q] = (aok && kin) ? va : make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[q] = (bok && kin) ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   const int nk = (d + BK - 1) / BK;
