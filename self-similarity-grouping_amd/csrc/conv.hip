@@ -23,12 +23,14 @@
 namespace ssg {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 
 struct ConvParams {
   const float* in; const float* w; const float* bias; const float* res; float* out;
   int B, H, W, Cin, OH, OW, Cout, KH, KW, stride, pad, relu;
   int M, Kpad;   // M = B*OH*OW, Kpad = weight row length (multiple of 32)
   int variant;   // tuning knob (SSG_CONV_VARIANT), 0 = default
+  unsigned in_bytes;   // size of the input tensor (buffer-resource bound)
 };
 
 constexpr int CBK = 32, CLD = 36;
@@ -82,20 +84,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
   pb2 = pb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // unconditional loads from a clamped in-bounds address + select: a load under a branch makes
-  // hipcc wait for it on the spot
+  // A tile through a buffer resource: padding taps / rows beyond M get an out-of-range offset and
+  // the hardware bounds check returns zeros -- no branch, no select (a load under a branch makes
+  // hipcc wait for it on the spot and serialises the prefetch).
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
 #define SSG_LOAD_A(J)                                                                                   \
   {                                                                                                     \
     const int ih = ah##J + r, iw = aw##J + s_;                                                          \
     const bool ok = ab##J >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                           \
-    const int64_t off = ok ? ((int64_t)(ab##J * p.H + ih) * p.W + iw) * p.Cin + c : 0;                  \
-    const float4 v = *reinterpret_cast<const float4*>(p.in + off);                                      \
-    pa##J = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+    const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1), bc = max(ab##J, 0);       \
+    /* always-valid offset from clamped coordinates, then poisoned past the 2 GiB bound when !ok */     \
+    const unsigned off = (unsigned)((((bc * p.H + ihc) * p.W + iwc) * p.Cin + c) * 4) + (ok ? 0u : 0x80000000u); \
+    const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);                          \
+    pa##J = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
   }
 #define SSG_GLOAD(KT)                                                                                   \
   {                                                                                                     \
     int r, s_, c;                                                                                       \
-    if (CIN4) { const int tap = (KT) * 8 + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; } \
+    if (CIN4) { const int tap = (KT) * 8 + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; /* -> !ok */ } \
     else { const int k0 = (KT) * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s_ = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; } \
     SSG_LOAD_A(0) SSG_LOAD_A(1) SSG_LOAD_A(2) SSG_LOAD_A(3)                                             \
     pb0 = *reinterpret_cast<const float4*>(wbase + (KT) * CBK);                                         \
@@ -144,22 +150,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     if (kt + 1 < nk) SSG_GLOAD(kt + 1)        // HBM/L2 latency hides under this tile's MFMAs
     const float* As = lds + (kt & 1) * STAGE;
     const float* Bs = As + BM * CLD;
+    // fragments for k-group g+1 are fetched from LDS while the MFMAs of group g run
+    float4 a[2][MT], b[2][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) a[0][i] = *reinterpret_cast<const float4*>(As + (wm * WM + i * 32 + l32) * CLD + h * 4);
+#pragma unroll
+    for (int j = 0; j < NT; j++) b[0][j] = *reinterpret_cast<const float4*>(Bs + (wn * WN + j * 32 + l32) * CLD + h * 4);
 #pragma unroll
     for (int g = 0; g < CBK / 8; g++) {
-      float4 a[MT], b[NT];
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < CBK / 8) {
 #pragma unroll
-      for (int i = 0; i < MT; i++) a[i] = *reinterpret_cast<const float4*>(As + (wm * WM + i * 32 + l32) * CLD + g * 8 + h * 4);
+        for (int i = 0; i < MT; i++) a[nxt][i] = *reinterpret_cast<const float4*>(As + (wm * WM + i * 32 + l32) * CLD + (g + 1) * 8 + h * 4);
 #pragma unroll
-      for (int j = 0; j < NT; j++) b[j] = *reinterpret_cast<const float4*>(Bs + (wn * WN + j * 32 + l32) * CLD + g * 8 + h * 4);
+        for (int j = 0; j < NT; j++) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + (wn * WN + j * 32 + l32) * CLD + (g + 1) * 8 + h * 4);
+      }
+      // consecutive MFMAs hit different accumulators (each one is revisited every MT*NT issues)
 #pragma unroll
       for (int i = 0; i < MT; i++)
 #pragma unroll
-        for (int j = 0; j < NT; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].x, a[i].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].y, a[i].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].z, a[i].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j].w, a[i].w, acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].x, a[cur][i].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].y, a[cur][i].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].z, a[cur][i].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].w, a[cur][i].w, acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) SSG_LSTORE((kt + 1) & 1) // other buffer: its readers finished before the last barrier
     __syncthreads();
@@ -289,6 +311,9 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
     return SSG_ERR_INVALID;
   }
   p.M = (int)M;
+  const int64_t in_bytes = (int64_t)B * H * W * Cin * 4;
+  if (in_bytes > 0x7fffffffLL) { ssg_set_error("ssg_conv2d_nhwc_f32: input tensor of %lld bytes exceeds the 2 GiB buffer-resource range of this kernel; use a smaller batch", (long long)in_bytes); return SSG_ERR_INVALID; }
+  p.in_bytes = (unsigned)in_bytes;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("SSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
   p.variant = variant;
