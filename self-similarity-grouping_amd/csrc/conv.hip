@@ -192,10 +192,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #undef SSG_LSTORE
   // epilogue.  D = W * A^T: C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   // -> channel; accumulator quad q holds channels 8q + 4h + {0,1,2,3} of one pixel.
+  // All residual loads are issued first (one round trip), then bias/add/ReLU/stores: the stores
+  // may alias the residual as far as the compiler knows, so an interleaved loop would serialise
+  // 16 load->use->store round trips per wave.
+  const float* __restrict__ resp = p.res;
+  float* __restrict__ outp = p.out;
+  float4 rr[MT][NT][4];
+  if (resp) {
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int m = tm * BM + wm * WM + i * 32 + l32;
+      const int64_t mrow = (int64_t)(m < p.M ? m : 0) * p.Cout;
+#pragma unroll
+      for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) rr[i][j][q] = *reinterpret_cast<const float4*>(resp + mrow + tn * BN + wn * WN + j * 32 + 8 * q + 4 * h);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MT; i++) {
     const int m = tm * BM + wm * WM + i * 32 + l32;
-    if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < NT; j++) {
 #pragma unroll
@@ -203,12 +219,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         const int col = tn * BN + wn * WN + j * 32 + 8 * q + 4 * h;
         const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
         float4 v = make_float4(acc[i][j][4 * q] + bias.x, acc[i][j][4 * q + 1] + bias.y, acc[i][j][4 * q + 2] + bias.z, acc[i][j][4 * q + 3] + bias.w);
-        if (p.res) {
-          const float4 rr = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.Cout + col);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
+        if (resp) { v.x += rr[i][j][q].x; v.y += rr[i][j][q].y; v.z += rr[i][j][q].z; v.w += rr[i][j][q].w; }
         if (p.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-        *reinterpret_cast<float4*>(p.out + (int64_t)m * p.Cout + col) = v;
+        if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
       }
     }
   }
