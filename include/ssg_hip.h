@@ -81,10 +81,11 @@ int ssg_invert_index(const int32_t* q_idx, const uint16_t* q_val, const int32_t*
                      int64_t* colptr, int32_t* inv_row, uint16_t* inv_val, ssg_stream_t stream);
 
 /* ---- K9 Jaccard distance (reid/rerank.py:105-122) ---------------------------------------- */
-/* Jp[il,k] = half(clamp(1 - t/(2-t)) * half(1-lambda)); q_* are FULL tables. */
+/* Jp[il,k] = half(clamp(1 - t/(2-t)) * half(1-lambda)); q_* are FULL tables; inv_nnz = colptr[N];
+ * colmeta = caller workspace of 2*nrows*capQ int32. */
 int ssg_jaccard_rows(const int32_t* q_idx, const uint16_t* q_val, const int32_t* q_nnz, int capQ, const int64_t* colptr,
-                     const int32_t* inv_row, const uint16_t* inv_val, int N, int row0, int nrows, uint16_t one_minus_lambda_half,
-                     uint16_t* Jp, ssg_stream_t stream);
+                     const int32_t* inv_row, const uint16_t* inv_val, int64_t inv_nnz, int32_t* colmeta, int N, int row0, int nrows,
+                     uint16_t one_minus_lambda_half, uint16_t* Jp, ssg_stream_t stream);
 /* API materialisation of final_dist (rerank.py:122): out[il,k] = f64(Jp) + f64(half(v_i+v_k))*lambda */
 int ssg_final_dist_f64(const uint16_t* Jp, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double* out,
                        ssg_stream_t stream);

@@ -17,6 +17,9 @@
 // half J' and the source vector v (reid/rerank.py:122), mode 1 reads a plain half matrix
 // (the no-rerank euclidean_dist).  All matrix passes are HBM-read-bound (2 bytes/entry).
 #include "ssg_common.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 namespace ssg {
 
@@ -229,21 +232,10 @@ __global__ void bitonic_global_kernel(unsigned long long* __restrict__ a, unsign
 }
 
 // ------------------------------------------------------------------ numpy pairwise mean
-struct PwFrame { long long off, n; int state; double left; };
-
-// leaves: consecutive blocks of <= 128 elements in numpy's recursion order
-__device__ int pw_build_leaves(long long n, long long* leaf_off, int* leaf_n) {
-  long long so[64], sn[64]; int sp = 0, nl = 0;
-  so[sp] = 0; sn[sp] = n; sp++;
-  while (sp) {
-    sp--; const long long off = so[sp], m = sn[sp];
-    if (m <= 128) { leaf_off[nl] = off; leaf_n[nl] = (int)m; nl++; continue; }
-    long long n2 = m / 2; n2 -= n2 % 8;
-    so[sp] = off + n2; sn[sp] = m - n2; sp++;    // right pushed first -> left popped first
-    so[sp] = off; sn[sp] = n2; sp++;
-  }
-  return nl;
-}
+// np.mean(x[:top]) = pairwise_sum(x, top) / top with numpy's recursion (blocks <= 128 summed
+// with 8 accumulators, halves split at a multiple of 8).  The recursion tree depends on `top`
+// only, so the host enumerates it once (leaves + internal nodes grouped by height) and one
+// workgroup evaluates it: all leaves in parallel, then one tree level per barrier.
 template <typename T>
 __device__ T pw_leaf(const unsigned long long* keys, long long off, int n) {
   auto val = [&](long long i) -> T { return (T)__longlong_as_double((long long)keys[off + i]); };
@@ -255,46 +247,23 @@ __device__ T pw_leaf(const unsigned long long* keys, long long off, int n) {
   for (; i < n; i++) res += val(i);
   return res;
 }
-// combine leaf sums in recursion order (thread 0)
-template <typename T>
-__device__ T pw_combine(long long n, const T* leaf_sum) {
-  struct F { long long n; int state; T left; } st[64];
-  int sp = 0, nl = 0;
-  st[sp].n = n; st[sp].state = 0; sp++;
-  T value = (T)0; bool have = false;
-  while (sp) {
-    F& f = st[sp - 1];
-    if (!have) {
-      if (f.n <= 128) { value = leaf_sum[nl++]; have = true; sp--; continue; }
-      long long n2 = f.n / 2; n2 -= n2 % 8;
-      f.state = 1; st[sp].n = n2; st[sp].state = 0; sp++;
-    } else {
-      if (f.state == 1) {
-        f.left = value; f.state = 2; have = false;
-        long long n2 = f.n / 2; n2 -= n2 % 8;
-        st[sp].n = f.n - n2; st[sp].state = 0; sp++;
-      } else { value = f.left + value; sp--; }
-    }
-  }
-  return value;
-}
 // out[0] = eps as double; out[1] = half bits of eps (mode 1) as a double-held integer
-__global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long* __restrict__ keys, long long top, int mode,
-                                                        long long* __restrict__ leaf_off, int* __restrict__ leaf_n,
-                                                        double* __restrict__ leaf_sum, double* __restrict__ out) {
-  __shared__ int nleaves;
-  if (threadIdx.x == 0) nleaves = pw_build_leaves(top, leaf_off, leaf_n);
+template <typename T>
+__global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long* __restrict__ keys, long long top, int nleaves, int nlevels,
+                                                        const long long* __restrict__ leaf_off, const int* __restrict__ leaf_n,
+                                                        const int* __restrict__ node_l, const int* __restrict__ node_r,
+                                                        const int* __restrict__ level_ptr, T* __restrict__ val, double* __restrict__ out) {
+  for (int l = (int)threadIdx.x; l < nleaves; l += (int)blockDim.x) val[l] = pw_leaf<T>(keys, leaf_off[l], leaf_n[l]);
   __syncthreads();
-  __threadfence_block();
-  for (int l = (int)threadIdx.x; l < nleaves; l += (int)blockDim.x) {
-    if (mode == 0) leaf_sum[l] = pw_leaf<double>(keys, leaf_off[l], leaf_n[l]);
-    else reinterpret_cast<float*>(leaf_sum)[l] = pw_leaf<float>(keys, leaf_off[l], leaf_n[l]);
+  for (int h = 0; h < nlevels; h++) {
+    for (int x = level_ptr[h] + (int)threadIdx.x; x < level_ptr[h + 1]; x += (int)blockDim.x) val[nleaves + x] = val[node_l[x]] + val[node_r[x]];
+    __syncthreads();
   }
-  __syncthreads();
   if (threadIdx.x == 0) {
-    if (mode == 0) { out[0] = pw_combine<double>(top, leaf_sum) / (double)top; out[1] = 0.0; }
+    const int ninternal = level_ptr[nlevels];
+    const T s = val[ninternal ? nleaves + ninternal - 1 : 0];   // the root is the last node of the last level
+    if (sizeof(T) == 8) { out[0] = (double)s / (double)top; out[1] = 0.0; }
     else {
-      const float s = pw_combine<float>(top, reinterpret_cast<const float*>(leaf_sum));
       const hbits e = d2h((double)s / (double)top);   // np.float32 scalar / np.intp -> float64 -> np.float16
       out[0] = (double)h2f(e); out[1] = (double)e;
     }
@@ -459,17 +428,62 @@ extern "C" int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t va
   return SSG_OK;
 }
 
-// workspace bytes for ssg_eps_mean: leaf tables for `top` summands
-extern "C" size_t ssg_eps_mean_workspace_bytes(int64_t top) { const size_t nl = (size_t)(top / 32 + 64); return nl * (8 + 4 + 8) + 64; }
+// workspace bytes for ssg_eps_mean: recursion tables + node values for `top` summands
+extern "C" size_t ssg_eps_mean_workspace_bytes(int64_t top) { const size_t nl = (size_t)(top / 32 + 64); return nl * 64 + 1024; }
+
+namespace {
+struct PwTree {
+  std::vector<long long> leaf_off; std::vector<int> leaf_n, node_l, node_r, node_h, level_ptr;
+  // returns node id (leaves: index; internal: nleaves + index) -- internal ids are remapped after sorting by height
+  int build(long long off, long long n, std::vector<int>& il, std::vector<int>& ir, std::vector<int>& ih, int& height) {
+    if (n <= 128) { leaf_off.push_back(off); leaf_n.push_back((int)n); height = 0; return -(int)leaf_off.size(); }   // leaf id = -(idx+1)
+    long long n2 = n / 2; n2 -= n2 % 8;
+    int hl, hr;
+    const int l = build(off, n2, il, ir, ih, hl), r = build(off + n2, n - n2, il, ir, ih, hr);
+    height = (hl > hr ? hl : hr) + 1;
+    il.push_back(l); ir.push_back(r); ih.push_back(height);
+    return (int)il.size() - 1;
+  }
+};
+}  // namespace
 
 extern "C" int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
   if (top <= 0 || ws_bytes < ssg_eps_mean_workspace_bytes(top)) { ssg_set_error("ssg_eps_mean: top=%lld ws too small", (long long)top); return SSG_ERR_INVALID; }
-  const size_t nl = (size_t)(top / 32 + 64);
-  long long* leaf_off = (long long*)ws;
-  double* leaf_sum = (double*)((char*)ws + nl * 8);
-  int* leaf_n = (int*)((char*)ws + nl * 16);
-  hipLaunchKernelGGL(eps_mean_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, mode, leaf_off, leaf_n,
-                     leaf_sum, out2);
+  PwTree t; std::vector<int> il, ir, ih; int hroot = 0;
+  t.build(0, top, il, ir, ih, hroot);
+  const int L = (int)t.leaf_off.size(), I = (int)il.size();
+  // order internal nodes by height (stable), remap child references
+  std::vector<int> order(I), pos(I);
+  for (int i = 0; i < I; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ih[a] < ih[b]; });
+  for (int i = 0; i < I; i++) pos[order[i]] = i;
+  t.node_l.resize(I); t.node_r.resize(I); t.level_ptr.assign(hroot + 1, 0);
+  auto ref = [&](int c) { return c < 0 ? (-c - 1) : (L + pos[c]); };
+  for (int i = 0; i < I; i++) { const int o = order[i]; t.node_l[i] = ref(il[o]); t.node_r[i] = ref(ir[o]); t.level_ptr[ih[o]]++; }
+  // level_ptr[h] currently counts nodes of height h (h>=1) at index h; turn into prefix offsets over levels 1..hroot
+  std::vector<int> lp(hroot + 1, 0);
+  for (int h = 1; h <= hroot; h++) lp[h] = lp[h - 1] + t.level_ptr[h];
+  // pack tables: leaf_off[L] i64 | leaf_n[L] | node_l[I] | node_r[I] | level_ptr[hroot+1] | val[(L+I)] (8 B each)
+  const size_t o_off = 0, o_n = o_off + (size_t)L * 8, o_l = o_n + (size_t)L * 4, o_r = o_l + (size_t)I * 4, o_lp = o_r + (size_t)I * 4;
+  size_t o_val = o_lp + (size_t)(hroot + 1) * 4; o_val = (o_val + 15) & ~(size_t)15;
+  const size_t need = o_val + (size_t)(L + I) * 8;
+  if (need > ws_bytes) { ssg_set_error("ssg_eps_mean: workspace %zu < %zu", ws_bytes, need); return SSG_ERR_INVALID; }
+  std::vector<char> host(o_val);
+  memcpy(host.data() + o_off, t.leaf_off.data(), (size_t)L * 8);
+  memcpy(host.data() + o_n, t.leaf_n.data(), (size_t)L * 4);
+  if (I) { memcpy(host.data() + o_l, t.node_l.data(), (size_t)I * 4); memcpy(host.data() + o_r, t.node_r.data(), (size_t)I * 4); }
+  memcpy(host.data() + o_lp, lp.data(), (size_t)(hroot + 1) * 4);
+  SSG_HIP(hipMemcpyAsync(ws, host.data(), o_val, hipMemcpyHostToDevice, stream));
+  SSG_HIP(hipStreamSynchronize(stream));   // `host` is a local buffer
+  char* w = (char*)ws;
+  if (mode == 0)
+    hipLaunchKernelGGL(eps_mean_kernel<double>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
+                       (const long long*)(w + o_off), (const int*)(w + o_n), (const int*)(w + o_l), (const int*)(w + o_r), (const int*)(w + o_lp),
+                       (double*)(w + o_val), out2);
+  else
+    hipLaunchKernelGGL(eps_mean_kernel<float>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
+                       (const long long*)(w + o_off), (const int*)(w + o_n), (const int*)(w + o_l), (const int*)(w + o_r), (const int*)(w + o_lp),
+                       (float*)(w + o_val), out2);
   SSG_LAUNCH_CHECK("eps_mean_kernel");
   return SSG_OK;
 }

@@ -79,57 +79,136 @@ __device__ __forceinline__ hbits jaccard_scaled(hbits t, hbits om) {
   return h_mul(j, om);
 }
 
-__global__ __launch_bounds__(64) void jaccard_rows_kernel(const int32_t* __restrict__ q_idx, const hbits* __restrict__ q_val,
-                                                          const int32_t* __restrict__ q_nnz, int capQ,
-                                                          const int64_t* __restrict__ colptr, const int32_t* __restrict__ inv_row,
-                                                          const hbits* __restrict__ inv_val, int N, int row0, int nrows, hbits om,
-                                                          hbits* __restrict__ Jp) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  hbits* t = reinterpret_cast<hbits*>(smem);
+// per (row, column slot): base offset into the inverted lists and (len << 16 | V[i,c] bits);
+// len = 0 for zero-valued entries.  Lets the row kernel prefetch with one-level loads.
+__global__ void colmeta_kernel(const int32_t* __restrict__ q_idx, const hbits* __restrict__ q_val, const int32_t* __restrict__ q_nnz, int capQ,
+                               const int64_t* __restrict__ colptr, int row0, int nrows, int32_t* __restrict__ meta_base,
+                               uint32_t* __restrict__ meta_lv) {
   const int il = (int)blockIdx.x;
   if (il >= nrows) return;
-  const int i = row0 + il, lane = lane_id();
-  const int n = q_nnz[i];
-  const int32_t* ci = q_idx + (int64_t)i * capQ;
-  const hbits* cv = q_val + (int64_t)i * capQ;
-  const hbits jp0 = jaccard_scaled(0, om);   // rows that share no column with i
-  for (int cbase = 0; cbase < N; cbase += JCHUNK) {
-    const int cw = (N - cbase) < JCHUNK ? (N - cbase) : JCHUNK;
-    for (int x = lane * 8; x < cw; x += 512) *reinterpret_cast<uint4*>(t + x) = make_uint4(0, 0, 0, 0);
-    wave_sync2();
-    for (int p = 0; p < n; p++) {              // ascending columns of row i  (:110-114)
-      const hbits vic = cv[p];
-      if (!(vic & 0x7fffu)) continue;
-      const int c = ci[p];
-      const int64_t e0 = colptr[c], e1 = colptr[c + 1];
-      for (int64_t e = e0 + lane; e < e1; e += 64) {
-        const int k = inv_row[e] - cbase;
-        if (k >= 0 && k < cw) {
-          const hbits vkc = inv_val[e];
-          const hbits mn = h2f(vkc) < h2f(vic) ? vkc : vic;
-          t[k] = h_add(t[k], mn);
-        }
+  const int i = row0 + il, n = q_nnz[i];
+  for (int p = (int)threadIdx.x; p < n; p += (int)blockDim.x) {
+    const hbits v = q_val[(int64_t)i * capQ + p];
+    const int c = q_idx[(int64_t)i * capQ + p];
+    const int64_t e0 = colptr[c], e1 = colptr[c + 1];
+    int len = (v & 0x7fffu) ? (int)(e1 - e0) : 0;
+    meta_base[(int64_t)il * capQ + p] = (int32_t)e0;
+    meta_lv[(int64_t)il * capQ + p] = ((uint32_t)(len > 0xffff ? 0xffff : len) << 16) | v;   // len >= 65535 handled by the slow path below
+  }
+}
+
+typedef unsigned int jv4u __attribute__((ext_vector_type(4)));
+
+constexpr int TCAP = 3072;   // touched-column list per wave (uint16 offsets inside the chunk)
+
+// Persistent waves: each wave walks rows il, il+grid, ...  The dense half accumulator t[] stays
+// in LDS and is kept all-zero between rows by resetting only the touched entries, so a row costs
+// O(nnz) LDS traffic + one streaming constant fill of its J' row + a sparse patch.
+__global__ __launch_bounds__(64) void jaccard_rows_kernel(const int32_t* __restrict__ q_nnz, int capQ, const int64_t* __restrict__ colptr,
+                                                          const int32_t* __restrict__ q_idx, const int32_t* __restrict__ inv_row,
+                                                          const hbits* __restrict__ inv_val, int64_t inv_nnz,
+                                                          const int32_t* __restrict__ meta_base, const uint32_t* __restrict__ meta_lv, int N,
+                                                          int row0, int nrows, hbits om, hbits* __restrict__ Jp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int cwmax = N < JCHUNK ? N : JCHUNK;
+  hbits* t = reinterpret_cast<hbits*>(smem);
+  unsigned short* touched = reinterpret_cast<unsigned short*>(smem + (((size_t)cwmax * 2 + 15) & ~(size_t)15) + 16);
+  for (int x = lane * 8; x < cwmax; x += 512) *reinterpret_cast<uint4*>(t + x) = make_uint4(0, 0, 0, 0);
+  wave_sync2();
+  // inverted lists through buffer resources: lanes beyond a list's length read a poisoned
+  // offset and get zeros from the bounds check -- no branch around any load
+  const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(inv_row), 0, (int)(inv_nnz * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rval = __builtin_amdgcn_make_buffer_rsrc(const_cast<hbits*>(inv_val), 0, (int)(inv_nnz * 2), 0x00020000);
+  const hbits jp0 = jaccard_scaled(0, om);   // columns that share nothing with row i
+  const unsigned jp0x2 = (unsigned)jp0 | ((unsigned)jp0 << 16);
+  const uint64_t lt = lanemask_lt();
+
+  for (int il = (int)blockIdx.x; il < nrows; il += (int)gridDim.x) {
+    const int i = row0 + il;
+    const int n = q_nnz[i];
+    const int32_t* mb = meta_base + (int64_t)il * capQ;
+    const uint32_t* ml = meta_lv + (int64_t)il * capQ;
+    for (int cbase = 0; cbase < N; cbase += JCHUNK) {
+      const int cw = (N - cbase) < JCHUNK ? (N - cbase) : JCHUNK;
+      int ntouched = 0;          // > TCAP => overflow, dense epilogue
+      // Ascending columns of row i (:110-114), software pipelined: metadata 8 columns ahead,
+      // list entries 4 columns ahead of the LDS read-modify-write (named slots, no arrays).
+      int mb0, mb1, mb2, mb3, k0, k1, k2, k3, ab0, ab1, ab2, ab3;
+      uint32_t ml0, ml1, ml2, ml3, al0, al1, al2, al3;
+      hbits v0, v1, v2, v3;
+#define SSG_META(P, MB, ML) { const int pp_ = (P) < n ? (P) : (n > 0 ? n - 1 : 0); MB = mb[pp_]; ML = ((P) < n && n > 0) ? ml[pp_] : 0u; }
+#define SSG_ENTRIES(MB, ML, K, V, AB, AL)                                                                \
+      {                                                                                                 \
+        AB = MB; AL = ML;                                                                               \
+        const bool in_ = lane < (int)(ML >> 16);                                                        \
+        const unsigned o_ = (unsigned)(MB + lane);                                                      \
+        K = __builtin_amdgcn_raw_buffer_load_b32(rrow, in_ ? o_ * 4u : 0xfffffff0u, 0, 0);             \
+        V = (hbits)__builtin_amdgcn_raw_buffer_load_b16(rval, in_ ? o_ * 2u : 0xfffffff0u, 0, 0);      \
+      }
+#define SSG_RMW(KK, VV, VIC)                                                                            \
+      {                                                                                                 \
+        const int kk = (KK) - cbase;                                                                    \
+        const bool hit_ = kk >= 0 && kk < cw;                                                           \
+        bool first_ = false;                                                                            \
+        if (hit_) { const hbits old_ = t[kk]; first_ = (old_ == 0); t[kk] = h_add(old_, h2f(VV) < h2f(VIC) ? (VV) : (VIC)); } \
+        const uint64_t fm_ = __ballot(first_);                                                          \
+        if (first_) { const int w_ = ntouched + __popcll(fm_ & lt); if (w_ < TCAP) touched[w_] = (unsigned short)kk; } \
+        ntouched += __popcll(fm_);                                                                      \
+      }
+#define SSG_APPLY(K, V, AB, AL)                                                                         \
+      {                                                                                                 \
+        const int len_ = (int)(AL >> 16);                                                               \
+        const hbits vic_ = (hbits)(AL & 0xffffu);                                                       \
+        if (len_ > 0) {                                                                                 \
+          { const int kq_ = lane < len_ ? K : -1; SSG_RMW(kq_ < 0 ? cbase - 1 : kq_, V, vic_) }         \
+          if (len_ > 64) {                                                                              \
+            const int c_ = q_idx[(int64_t)i * capQ + pcur_];                                            \
+            const int64_t e1_ = colptr[c_ + 1];                                                         \
+            for (int64_t eb = (int64_t)AB + 64; eb < e1_; eb += 64) {                                   \
+              const int64_t e = eb + lane;                                                              \
+              const int kr_ = e < e1_ ? inv_row[e] : cbase - 1;                                         \
+              const hbits vk_ = e < e1_ ? inv_val[e] : (hbits)0;                                        \
+              SSG_RMW(kr_, vk_, vic_)                                                                   \
+            }                                                                                           \
+          }                                                                                             \
+          wave_sync2();                                                                                 \
+        }                                                                                               \
+      }
+      SSG_META(0, mb0, ml0) SSG_META(1, mb1, ml1) SSG_META(2, mb2, ml2) SSG_META(3, mb3, ml3)
+      SSG_ENTRIES(mb0, ml0, k0, v0, ab0, al0) SSG_ENTRIES(mb1, ml1, k1, v1, ab1, al1)
+      SSG_ENTRIES(mb2, ml2, k2, v2, ab2, al2) SSG_ENTRIES(mb3, ml3, k3, v3, ab3, al3)
+      SSG_META(4, mb0, ml0) SSG_META(5, mb1, ml1) SSG_META(6, mb2, ml2) SSG_META(7, mb3, ml3)
+      for (int p = 0; p < n; p += 4) {
+        int pcur_ = p;
+        SSG_APPLY(k0, v0, ab0, al0) SSG_ENTRIES(mb0, ml0, k0, v0, ab0, al0) SSG_META(p + 8, mb0, ml0)
+        pcur_ = p + 1;
+        SSG_APPLY(k1, v1, ab1, al1) SSG_ENTRIES(mb1, ml1, k1, v1, ab1, al1) SSG_META(p + 9, mb1, ml1)
+        pcur_ = p + 2;
+        SSG_APPLY(k2, v2, ab2, al2) SSG_ENTRIES(mb2, ml2, k2, v2, ab2, al2) SSG_META(p + 10, mb2, ml2)
+        pcur_ = p + 3;
+        SSG_APPLY(k3, v3, ab3, al3) SSG_ENTRIES(mb3, ml3, k3, v3, ab3, al3) SSG_META(p + 11, mb3, ml3)
+      }
+#undef SSG_META
+#undef SSG_ENTRIES
+#undef SSG_RMW
+#undef SSG_APPLY
+      hbits* out = Jp + (int64_t)il * N + cbase;
+      const int64_t eoff = (int64_t)il * N + cbase;
+      if (ntouched <= TCAP) {
+        // (1) stream the constant over the whole chunk, (2) wait for the stores, (3) patch the touched columns
+        const int head = (int)((8 - (eoff & 7)) & 7);          // scalar elements before the first 16-byte boundary
+        for (int x = lane; x < head && x < cw; x += 64) out[x] = jp0;
+        const int nvec = cw > head ? (cw - head) / 8 : 0;
+        for (int q = lane; q < nvec; q += 64) *reinterpret_cast<uint4*>(out + head + q * 8) = make_uint4(jp0x2, jp0x2, jp0x2, jp0x2);
+        for (int x = head + nvec * 8 + lane; x < cw; x += 64) out[x] = jp0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int q = lane; q < ntouched; q += 64) { const int kk = touched[q]; out[kk] = jaccard_scaled(t[kk], om); t[kk] = 0; }
+      } else {
+        for (int x = lane; x < cw; x += 64) { const hbits tv = t[x]; out[x] = tv ? jaccard_scaled(tv, om) : jp0; t[x] = 0; }
       }
       wave_sync2();
     }
-    // epilogue: accumulator -> J' row chunk
-    hbits* out = Jp + (int64_t)il * N + cbase;
-    const bool vec = (((int64_t)il * N + cbase) & 7) == 0;
-    for (int x = lane * 8; x < cw; x += 512) {
-      hbits r[8];
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const hbits tv = (x + e < cw) ? t[x + e] : (hbits)0;
-        r[e] = tv ? jaccard_scaled(tv, om) : jp0;
-      }
-      if (vec && x + 8 <= cw) {
-        *reinterpret_cast<uint4*>(out + x) = make_uint4(r[0] | ((unsigned)r[1] << 16), r[2] | ((unsigned)r[3] << 16),
-                                                        r[4] | ((unsigned)r[5] << 16), r[6] | ((unsigned)r[7] << 16));
-      } else {
-        for (int e = 0; e < 8; e++) if (x + e < cw) out[x + e] = r[e];
-      }
-    }
-    wave_sync2();
   }
 }
 
@@ -160,15 +239,21 @@ extern "C" int ssg_invert_index(const int32_t* q_idx, const uint16_t* q_val, con
   return SSG_OK;
 }
 
+// colmeta: caller workspace of 2 * nrows * capQ int32 (column metadata of this row block)
 extern "C" int ssg_jaccard_rows(const int32_t* q_idx, const uint16_t* q_val, const int32_t* q_nnz, int capQ, const int64_t* colptr,
-                                const int32_t* inv_row, const uint16_t* inv_val, int N, int row0, int nrows, uint16_t one_minus_lambda_half,
-                                uint16_t* Jp, hipStream_t stream) {
-  if (N <= 0 || nrows <= 0) { ssg_set_error("ssg_jaccard_rows: empty"); return SSG_ERR_INVALID; }
+                                const int32_t* inv_row, const uint16_t* inv_val, int64_t inv_nnz, int32_t* colmeta, int N, int row0, int nrows,
+                                uint16_t one_minus_lambda_half, uint16_t* Jp, hipStream_t stream) {
+  if (N <= 0 || nrows <= 0 || inv_nnz < 0 || inv_nnz > 0x3ffffff0LL) { ssg_set_error("ssg_jaccard_rows: bad shape (N=%d nrows=%d nnz=%lld)", N, nrows, (long long)inv_nnz); return SSG_ERR_INVALID; }
+  int32_t* meta_base = colmeta;
+  uint32_t* meta_lv = reinterpret_cast<uint32_t*>(colmeta + (int64_t)nrows * capQ);
+  hipLaunchKernelGGL(colmeta_kernel, dim3(nrows), dim3(64), 0, stream, q_idx, q_val, q_nnz, capQ, colptr, row0, nrows, meta_base, meta_lv);
   const int cw = N < JCHUNK ? N : JCHUNK;
-  const size_t lds = (((size_t)cw * 2 + 1023) / 1024) * 1024 + 16;
+  const size_t lds = (((size_t)cw * 2 + 15) & ~(size_t)15) + 16 + (size_t)TCAP * 2 + 64;
   if (lds > 64 * 1024) SSG_HIP(hipFuncSetAttribute((const void*)jaccard_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(jaccard_rows_kernel, dim3(nrows), dim3(64), lds, stream, q_idx, q_val, q_nnz, capQ, colptr, inv_row, inv_val, N, row0, nrows,
-                     one_minus_lambda_half, Jp);
+  const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;
+  const int grid = nrows < 256 * per_cu ? nrows : 256 * per_cu;   // persistent waves, one per LDS slot
+  hipLaunchKernelGGL(jaccard_rows_kernel, dim3(grid), dim3(64), lds, stream, q_nnz, capQ, colptr, q_idx, inv_row, inv_val, inv_nnz, meta_base, meta_lv,
+                     N, row0, nrows, one_minus_lambda_half, Jp);
   SSG_LAUNCH_CHECK("jaccard_rows_kernel");
   return SSG_OK;
 }

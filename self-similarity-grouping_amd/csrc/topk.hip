@@ -20,6 +20,19 @@ __device__ __forceinline__ uint64_t make_comp(hbits key, int col, hbits raw) {
   return ((uint64_t)key << 48) | ((uint64_t)(uint32_t)col << 16) | (uint64_t)raw;
 }
 
+// 64-bit lane exchange helpers: broadcast from a wave-uniform lane via v_readlane (SALU path, no
+// LDS permute), shift-by-one via DPP wave_shr:1.
+__device__ __forceinline__ uint64_t bcast64(uint64_t v, int src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shr1_64(uint64_t v) {   // lane l gets lane l-1 (lane 0 keeps its own)
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, 0x138, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), 0x138, 0xf, 0xf, false);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(256) void topk_rank_kernel(const hbits* __restrict__ D, const unsigned* __restrict__ rowmax, int N,
                                                         int nrows, int K, int32_t* __restrict__ rank) {
   const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -35,7 +48,7 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const hbits* __restrict_
 
   uint64_t mine = ~0ULL;       // lane r holds the r-th smallest composite seen so far
   uint64_t tau = ~0ULL;        // composite at lane K-1 (the current K-th smallest)
-  unsigned raw_hi = 0xffffu;   // raw values above this cannot beat tau
+  unsigned raw_hi = 0xffffu;   // raw values above this cannot beat tau (superset prefilter)
 
   auto load_chunk = [&](int c) -> uint4 {
     const int64_t off = al + (int64_t)c * 512 + lane * 8;
@@ -50,45 +63,52 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const hbits* __restrict_
     return x;
   };
 
-  uint4 nxt = load_chunk(0);
+  uint4 nxt = load_chunk(0), nxt2 = nchunks > 1 ? load_chunk(1) : nxt;
   for (int c = 0; c < nchunks; c++) {
     const uint4 cur = nxt;
-    if (c + 1 < nchunks) nxt = load_chunk(c + 1);
+    nxt = nxt2;
+    if (c + 2 < nchunks) nxt2 = load_chunk(c + 2);
     const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
     const int j0 = c * 512 + lane * 8 - first;   // row-relative column of element 0
-    // quick reject: does any lane hold an in-row element with raw <= raw_hi ?
-    bool anyc = false;
+    const bool interior = (c > 0) && (c + 1 < nchunks);   // every lane's 8 columns are inside the row
+    if (interior) {
+      // fast reject: packed 16-bit min of the lane's 8 raw values against the prefilter bound
+      unsigned lo = 0xffffu, hi = 0xffffu;
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      const unsigned r = (w[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-      const int j = j0 + e;
-      anyc |= (j >= 0 && j < N && r <= raw_hi);
+      for (int q = 0; q < 4; q++) { const unsigned a0 = w[q] & 0xffffu, a1 = w[q] >> 16; lo = a0 < lo ? a0 : lo; hi = a1 < hi ? a1 : hi; }
+      const unsigned mn = lo < hi ? lo : hi;
+      if (!__any(mn <= raw_hi)) continue;
     }
-    if (!__any(anyc)) continue;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const hbits r = (hbits)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
       const int j = j0 + e;
+      const bool pre = (interior || (j >= 0 && j < N)) && r <= raw_hi;
+      if (!__any(pre)) continue;
       uint64_t comp = ~0ULL;
-      if (j >= 0 && j < N && r <= raw_hi) comp = make_comp(f2h(h2f(r) / fmx), j, r);
+      if (pre) comp = make_comp(f2h(h2f(r) / fmx), j, r);
       bool cand = comp < tau;
       uint64_t mask = __ballot(cand);
       while (mask) {
         const int src = __ffsll((long long)mask) - 1;
-        const uint64_t cc = __shfl(comp, src, 64);
+        const uint64_t cc = bcast64(comp, src);
         // sorted insert of cc into the 64-lane list
         const bool lt = mine < cc;
-        const uint64_t up = __shfl_up(mine, 1, 64);
+        const uint64_t up = shr1_64(mine);
         const int pos = __popcll(__ballot(lt));
         mine = lt ? mine : (lane == pos ? cc : up);
-        const uint64_t ntau = __shfl(mine, K - 1, 64);
-        if (ntau != tau) {
-          tau = ntau;
-          if (tau != ~0ULL && !degenerate) {
-            // widest raw value whose normalised key still equals tau's key (division merges
-            // neighbouring raw values; equal keys are then ordered by column)
-            const hbits ktau = (hbits)(tau >> 48);
-            unsigned rr = (unsigned)(tau & 0xffffu);
+        tau = bcast64(mine, K - 1);
+        if (tau != ~0ULL && !degenerate) {
+          const hbits ktau = (hbits)(tau >> 48);
+          unsigned rr = (unsigned)(tau & 0xffffu);
+          if (rr >= 0x7c00u) raw_hi = 0xffffu;
+          else if (ktau >= 0x0400u) {
+            // normal-range key: the two half grids have a spacing ratio in (1/2, 2], so at most 3
+            // neighbouring raw values share a key; +4 keeps the prefilter a superset and the
+            // exact (key, column) compare decides.
+            raw_hi = rr + 4u < 0x7c00u ? rr + 4u : 0x7c00u;
+          } else {
+            // subnormal key: arbitrarily many raw values can collapse onto it -> exact bound
             while (rr < 0x7c00u && f2h(h2f((hbits)(rr + 1)) / fmx) == ktau) rr++;
             raw_hi = rr;
           }

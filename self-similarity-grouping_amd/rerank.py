@@ -170,8 +170,9 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
           "ssg_invert_index")
     om = L.ssg_double_to_half_bits(1.0 - float(lambda_value))
     Jp = torch.empty((nrows, N), dtype=torch.float16, device=dev)
-    check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), N, row0, nrows, om, ptr(Jp), st),
-          "ssg_jaccard_rows")
+    colmeta = torch.empty((2, nrows, capQ), dtype=torch.int32, device=dev)
+    check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
+                             om, ptr(Jp), st), "ssg_jaccard_rows")
 
     if int(vmax.item()) & 0x7FFF == 0:
         raise ReRankNaNError("max(source_dist_vec) == 0: every target->source 1-exp(-d^2) rounds to 0 in float16; the reference "
