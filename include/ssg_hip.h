@@ -71,9 +71,10 @@ int ssg_krecip(const uint16_t* D, const uint32_t* rowmax, const int32_t* rank, i
                int32_t* v_idx, uint16_t* v_val, int32_t* v_nnz, ssg_stream_t stream);
 
 /* ---- K7 local query expansion (reid/rerank.py:94-99) ------------------------------------ */
-/* v_* are FULL [N,capV] tables; q_* cover rows [row0,row0+nrows), capQ >= k2*capV. */
+/* v_* are FULL [N,capV] tables; max_nnz = max(v_nnz) (sizes the LDS staging); q_* cover rows
+ * [row0,row0+nrows) with row stride capQ >= k2*max_nnz. */
 int ssg_query_expand(const int32_t* v_idx, const uint16_t* v_val, const int32_t* v_nnz, const int32_t* rank, int N, int row0, int nrows,
-                     int K, int k2, int capV, int capQ, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz, ssg_stream_t stream);
+                     int K, int k2, int capV, int capQ, int max_nnz, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz, ssg_stream_t stream);
 
 /* ---- K8 inverted index (reid/rerank.py:101-103) ------------------------------------------ */
 /* colcnt [ncols] int32 scratch, colptr [ncols+1] int64, inv_row/inv_val >= sum(q_nnz) entries */

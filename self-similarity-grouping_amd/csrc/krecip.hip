@@ -146,20 +146,21 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t* a, int n, int x) {
 // LDS per wave: for each of k2 lists: idx[capV] int32 | val[capV] half | hpre[capV+1] int32
 __global__ __launch_bounds__(256) void query_expand_kernel(const int32_t* __restrict__ v_idx, const hbits* __restrict__ v_val,
                                                            const int32_t* __restrict__ v_nnz, const int32_t* __restrict__ rank,
-                                                           int row0, int nrows, int K, int kk, int capV, int capQ,
+                                                           int row0, int nrows, int K, int kk, int capV, int capQ, int capL,
                                                            int32_t* __restrict__ q_idx, hbits* __restrict__ q_val,
                                                            int32_t* __restrict__ q_nnz) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int il = (int)blockIdx.x * 4 + wave;
-  const size_t per_list = (size_t)capV * 4 + (size_t)(capV + 1) * 4 + (((size_t)capV * 2 + 3) & ~(size_t)3);
+  // capL = longest source row actually present (LDS is sized for it, not for the worst-case capV)
+  const size_t per_list = (size_t)capL * 4 + (size_t)(capL + 1) * 4 + (((size_t)capL * 2 + 3) & ~(size_t)3);
   const size_t per_wave = (per_list * kk + 64 + 15) & ~(size_t)15;
   unsigned char* wbase = smem + (size_t)wave * per_wave;
   if (il >= nrows) return;
   const int i = row0 + il;
   auto L_idx = [&](int r) { return reinterpret_cast<int32_t*>(wbase + per_list * r); };
-  auto L_pre = [&](int r) { return reinterpret_cast<int32_t*>(wbase + per_list * r) + capV; };
-  auto L_val = [&](int r) { return reinterpret_cast<hbits*>(wbase + per_list * r + (size_t)capV * 4 + (size_t)(capV + 1) * 4); };
+  auto L_pre = [&](int r) { return reinterpret_cast<int32_t*>(wbase + per_list * r) + capL; };
+  auto L_val = [&](int r) { return reinterpret_cast<hbits*>(wbase + per_list * r + (size_t)capL * 4 + (size_t)(capL + 1) * 4); };
   int32_t* nn = reinterpret_cast<int32_t*>(wbase + per_list * kk);   // list lengths
 
   // stage the kk source rows (V rows of the first k2 ranked neighbours, rerank.py:97)
@@ -254,17 +255,21 @@ extern "C" int ssg_krecip(const uint16_t* D, const uint32_t* rowmax, const int32
 }
 
 extern "C" int ssg_query_expand(const int32_t* v_idx, const uint16_t* v_val, const int32_t* v_nnz, const int32_t* rank, int N, int row0,
-                                int nrows, int K, int k2, int capV, int capQ, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz,
+                                int nrows, int K, int k2, int capV, int capQ, int max_nnz, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz,
                                 hipStream_t stream) {
   int kk = k2; if (kk > N) kk = N; if (kk > K) kk = K;
-  if (kk <= 0 || capQ < kk * capV) { ssg_set_error("ssg_query_expand: capQ (%d) must be >= k2*capV (%d)", capQ, kk * capV); return SSG_ERR_INVALID; }
-  const size_t per_list = (size_t)capV * 4 + (size_t)(capV + 1) * 4 + (((size_t)capV * 2 + 3) & ~(size_t)3);
+  const int capL = max_nnz < 1 ? 1 : max_nnz;
+  if (kk <= 0 || capL > capV || capQ < kk * capL) {
+    ssg_set_error("ssg_query_expand: need max_nnz (%d) <= capV (%d) and capQ (%d) >= k2*max_nnz (%d)", max_nnz, capV, capQ, kk * capL);
+    return SSG_ERR_INVALID;
+  }
+  const size_t per_list = (size_t)capL * 4 + (size_t)(capL + 1) * 4 + (((size_t)capL * 2 + 3) & ~(size_t)3);
   const size_t per_wave = (per_list * kk + 64 + 15) & ~(size_t)15;
   const size_t lds = per_wave * 4;
-  if (lds > 160 * 1024) { ssg_set_error("ssg_query_expand: k2=%d capV=%d needs %zu B LDS", k2, capV, lds); return SSG_ERR_INVALID; }
+  if (lds > 160 * 1024) { ssg_set_error("ssg_query_expand: k2=%d max_nnz=%d needs %zu B LDS", k2, capL, lds); return SSG_ERR_INVALID; }
   if (lds > 64 * 1024) SSG_HIP(hipFuncSetAttribute((const void*)query_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(query_expand_kernel, dim3((nrows + 3) / 4), dim3(256), lds, stream, v_idx, v_val, v_nnz, rank, row0, nrows, K, kk, capV,
-                     capQ, q_idx, q_val, q_nnz);
+                     capQ, capL, q_idx, q_val, q_nnz);
   SSG_LAUNCH_CHECK("query_expand_kernel");
   return SSG_OK;
 }

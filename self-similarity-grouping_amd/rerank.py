@@ -144,11 +144,12 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     # ---- local query expansion (rerank.py:94-99)
     if k2 != 1:
         kk = min(k2, N, K)
-        capQ = kk * capV
+        mx = max(int(v_nnz.max().item()), 1)       # longest V row actually present
+        capQ = kk * mx
         q_idx = torch.empty((nrows, capQ), dtype=torch.int32, device=dev)
         q_val = torch.empty((nrows, capQ), dtype=torch.float16, device=dev)
         q_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
-        check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, ptr(q_idx), ptr(q_val),
+        check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, mx, ptr(q_idx), ptr(q_val),
                                  ptr(q_nnz), st), "ssg_query_expand")
         if group is not None:
             # ship only the used part of the fixed-capacity rows over xGMI

@@ -342,3 +342,40 @@ def test_extract_features_dropin(golden, dev):
             assert np.abs(feats[f][s].numpy() - ref[s, i]).max() < 5e-6
     feats_e, _ = ssg_amd.extract_features(m, loader, for_eval=True)
     assert feats_e["a"].shape == (3 * 2048,) and abs(float(feats_e["a"].norm()) - 1.0) < 1e-5
+
+
+# ------------------------------------------------------------------ edge regimes of the sparse kernels
+def test_wide_neighbourhoods_vs_oracle(dev, ora):
+    """k1=60, k2=16 on weakly clustered data: V rows near the 64-lane limit, inverted lists longer
+    than one wave, touched-column list overflow in the Jaccard kernel (dense epilogue path)."""
+    from ssg_amd import rerank, cluster
+    N, d = 4500, 48
+    rng = np.random.default_rng(12)
+    tgt = rng.standard_normal((N, d)).astype(np.float32); tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+    src = rng.standard_normal((700, d)).astype(np.float32); src /= np.linalg.norm(src, axis=1, keepdims=True)
+    st = {}
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k1=60, k2=16, lambda_value=0.2, stages=st)
+    oe, of, ost = ora.re_ranking(src, tgt, k1=60, k2=16, lambda_value=0.2, stages=True)
+    assert np.array_equal(st["rank"].cpu().numpy(), ost["rank"])
+    assert np.array_equal(_sparse_to_dense(st["v_idx"], st["v_val"], st["v_nnz"], N), bits(ost["V"])), "V"
+    assert np.array_equal(_sparse_to_dense(st["q_idx"], st["q_val"], st["q_nnz"], N), bits(ost["V_qe"])), "V_qe"
+    got, ref = bits(st["Jp"].cpu().numpy()), bits(ost["jaccard_scaled"])
+    touched = (ost["jaccard"] != np.float16(1.0)).sum(axis=1)
+    assert touched.max() > 3072, "test should overflow the touched list (the sparse patch path is covered by the k1=20 tests)"
+    bad = np.argwhere(got != ref)
+    assert len(bad) == 0, (len(bad), bad[:5].tolist(), [(hex(got[a, b]), hex(ref[a, b])) for a, b in bad[:5]], st["q_nnz"].cpu().numpy()[bad[:5, 0]].tolist())
+    assert np.array_equal(h.final_dist().cpu().numpy(), of)
+    eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
+    assert (eps, cnt, top) == ora.eps_rule(of, 1.6e-3)
+    assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h), ora.dbscan(of, eps, 4))
+
+
+def test_more_than_one_column_chunk_vs_oracle(dev, ora):
+    """N > 32768: the Jaccard accumulator row is processed in two LDS column chunks."""
+    from ssg_amd import rerank
+    N, d = 33000, 32
+    tgt = clustered(N, d, 5); src = clustered(2000, d, 6, intra=0.7)
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), lambda_value=0.1)
+    oe, of, ost = ora.re_ranking(src, tgt, lambda_value=0.1, stages=True)
+    assert np.array_equal(bits(h.euclid.cpu().numpy()), bits(oe))
+    assert np.array_equal(bits(h.M.cpu().numpy()), bits(ost["jaccard_scaled"]))
