@@ -65,13 +65,21 @@ __device__ __forceinline__ void load_vals(const MatView& mv, const RowStream& rs
     for (int e = 0; e < 8; e++) if (off + e < rs.total) w[e >> 1] |= (unsigned)M[off + e] << ((e & 1) * 16);
   }
   const int j0 = rs.col0(c, lane);
+  unsigned vw[4] = {0, 0, 0, 0};   // v[j0 .. j0+7] (mode 0)
+  if (MODE == 0) {
+    if (j0 >= 0 && j0 + 8 <= mv.N && (j0 & 7) == 0) {   // rows start on 16-byte boundaries when N % 8 == 0: one load
+      const uint4 x = *reinterpret_cast<const uint4*>(mv.v + j0); vw[0] = x.x; vw[1] = x.y; vw[2] = x.z; vw[3] = x.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const int k = j0 + e; if (k >= 0 && k < mv.N) vw[e >> 1] |= (unsigned)mv.v[k] << ((e & 1) * 16); }
+    }
+  }
+  const hbits vi = MODE == 0 ? mv.v[gi] : (hbits)0;
 #pragma unroll
   for (int e = 0; e < 8; e++) {
     const hbits raw = (hbits)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-    if (MODE == 0) {
-      const int k = j0 + e;
-      d[e] = final_dist_value(raw, mv.v[gi], mv.v[(k >= 0 && k < mv.N) ? k : 0], mv.lambda_value);
-    } else d[e] = (double)h2f(raw);
+    if (MODE == 0) d[e] = final_dist_value(raw, vi, (hbits)((vw[e >> 1] >> ((e & 1) * 16)) & 0xffffu), mv.lambda_value);
+    else d[e] = (double)h2f(raw);
   }
 }
 

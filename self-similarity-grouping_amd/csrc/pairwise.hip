@@ -63,13 +63,27 @@ template <int MODE>
 __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                       const double* __restrict__ nA, const double* __restrict__ nB,
                                                       int M, int N, int d, int rowA0, hbits* __restrict__ D,
-                                                      unsigned* __restrict__ rowred) {
+                                                      unsigned* __restrict__ rowred, int symmetric) {
   constexpr bool R16 = (MODE == 0);
   __shared__ double As[BK * LDR];
   __shared__ double Bs[BK * LDR];
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
-  const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
-  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  int tm, tn;
+  if (MODE == 0 && symmetric) {
+    // D is symmetric (same products, same k order): with the whole matrix on one GPU only the
+    // T(T+1)/2 tiles on or above the diagonal are launched (row-major over the triangle, so every
+    // XCD gets an equal share) and the strictly-upper ones are mirrored on store.
+    const int T = tiles_n;
+    const int t = xcd_remap((int)blockIdx.x, T * (T + 1) / 2);
+    int r = (int)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
+    while (r > 0 && r * T - r * (r - 1) / 2 > t) r--;
+    while ((r + 1) * T - (r + 1) * r / 2 <= t) r++;
+    tm = r; tn = r + (t - (r * T - r * (r - 1) / 2));
+  } else {
+    const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+    tm = tile / tiles_n; tn = tile % tiles_n;
+  }
+  const bool mirror = MODE == 0 && symmetric && tn > tm;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // staging map: one row per thread, 16 consecutive k (4 x float4)
@@ -133,6 +147,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
   }
 
   // epilogue.  f64 MFMA C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
+  unsigned cmax[4] = {0u, 0u, 0u, 0u};   // mirror: running max of the column this lane owns in tile j
 #pragma unroll
   for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -153,6 +168,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
             const hbits dd = h_mul(h, h);               // np.power(half, 2)            rerank.py:62
             D[(int64_t)li * N + gj] = dd;
             red = red > dd ? red : (unsigned)dd;
+            if (mirror) { D[(int64_t)gj * N + li] = dd; cmax[j] = cmax[j] > dd ? cmax[j] : (unsigned)dd; }
           } else {
             const double dist = sqrt(s);
             const hbits h = d2h(dist * dist);           // np.power(cdist, 2).astype(float16)  rerank.py:36-37
@@ -168,6 +184,17 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
       if (l16 == 0 && rok) {
         if (MODE == 0) atomicMax(&rowred[li], red); else atomicMin(&rowred[li], red);
       }
+    }
+  }
+  if (mirror) {
+    // mirrored rows are this tile's columns: reduce over the 4 lanes (lk) that share a column
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      unsigned m = cmax[j];
+      m = max(m, (unsigned)__shfl_xor((int)m, 16, 64));
+      m = max(m, (unsigned)__shfl_xor((int)m, 32, 64));
+      const int gj = tn * BN + wn * 64 + j * 16 + l16;
+      if (lk == 0 && gj < N) atomicMax(&rowred[gj], m);
     }
   }
 }
@@ -218,8 +245,10 @@ extern "C" int ssg_sqdist_self_f16(const float* x, const double* norms, int N, i
   }
   hipLaunchKernelGGL(fill_u32_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, rowmax, nrows, 0u);
   const int tiles = ((nrows + BM - 1) / BM) * ((N + BN - 1) / BN);
-  hipLaunchKernelGGL(gram_kernel<0>, dim3(tiles), dim3(256), 0, stream, x + (int64_t)row0 * d, x, norms + row0, norms, nrows, N, d,
-                     row0, D, rowmax);
+  const int symmetric = (row0 == 0 && nrows == N) ? 1 : 0;   // whole matrix on this GPU: compute the upper triangle, mirror on store
+  const int T = (N + BN - 1) / BN;
+  hipLaunchKernelGGL(gram_kernel<0>, dim3(symmetric ? T * (T + 1) / 2 : tiles), dim3(256), 0, stream, x + (int64_t)row0 * d, x, norms + row0, norms, nrows, N, d,
+                     row0, D, rowmax, symmetric);
   SSG_LAUNCH_CHECK("gram_kernel<self>");
   return SSG_OK;
 }
@@ -229,7 +258,7 @@ extern "C" int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const
   if (nrows <= 0 || Ns <= 0 || (d & 3)) { ssg_set_error("ssg_source_rowmin_f16: bad shape"); return SSG_ERR_INVALID; }
   hipLaunchKernelGGL(fill_u32_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, rowmin, nrows, 0xffffffffu);
   const int tiles = ((nrows + BM - 1) / BM) * ((Ns + BN - 1) / BN);
-  hipLaunchKernelGGL(gram_kernel<1>, dim3(tiles), dim3(256), 0, stream, tgt, src, ntgt, nsrc, nrows, Ns, d, 0, (uint16_t*)nullptr, rowmin);
+  hipLaunchKernelGGL(gram_kernel<1>, dim3(tiles), dim3(256), 0, stream, tgt, src, ntgt, nsrc, nrows, Ns, d, 0, (uint16_t*)nullptr, rowmin, 0);
   SSG_LAUNCH_CHECK("gram_kernel<cross>");
   return SSG_OK;
 }
