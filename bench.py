@@ -76,7 +76,7 @@ def cpu_baseline(args):
     on this box's host cores, bounded sample."""
     from oracle import ssg_oracle as ora, embed_oracle
     import ssg_amd
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     sd = ssg_amd.synthetic_state_dict(seed=1)
     imgs = torch.randn(args.cpu_images, 3, 256, 128, generator=torch.Generator().manual_seed(1))
@@ -211,11 +211,14 @@ def main():
             gbs = byt * n / (ms * 1e-3) / 1e9
             hbm.append({"kernel": k, "bound": "hbm", "what": what, "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(gbs, 1),
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
-    for k, flop in (("ssg_sqdist_self_f16", 2.0 * nrows * args.N * 2048), ("ssg_source_rowmin_f16", 2.0 * nrows * args.Ns * 2048)):
+    # the self term computes only the upper-triangle tiles when one GPU holds the whole matrix (mirrored on store)
+    t128 = (args.N + 127) // 128
+    self_flop = (t128 * (t128 + 1) // 2) * 128 * 128 * 2.0 * 2048 if world == 1 else 2.0 * nrows * args.N * 2048
+    for k, flop in (("ssg_sqdist_self_f16", self_flop), ("ssg_source_rowmin_f16", 2.0 * nrows * args.Ns * 2048)):
         if k in tot:
             n, ms = tot[k]
             tf = flop * n / (ms * 1e-3) / 1e12
-            hbm.append({"kernel": k, "bound": "mfma", "what": "fp64 Gram (v_mfma_f64_16x16x4)", "launches": n, "avg_launch_ms": round(ms / n, 4),
+            hbm.append({"kernel": k, "bound": "mfma", "what": "fp64 Gram (v_mfma_f64_16x16x4); executed flops (self term: upper-triangle tiles only on 1 GPU)", "launches": n, "avg_launch_ms": round(ms / n, 4),
                         "achieved": round(tf, 2), "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_MFMA_TF, 4)})
     hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
                                     "ssg_eps_compact", "ssg_sort_u64", "ssg_eps_mean", "ssg_region_query", "ssg_dbscan_cc") if k in tot) / args.steps

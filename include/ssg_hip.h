@@ -125,6 +125,11 @@ int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int
  * RGB0 pixels, Kpad = 32*ceil(KH*KW/8)); Cout % 64 == 0.  (cuDNN conv+BN+ReLU of base.py:57-93) */
 int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W, int Cin,
                         int Cout, int KH, int KW, int stride, int pad, int relu, ssg_stream_t stream);
+/* Bottleneck tail with a downsample branch (base.py:75-90) as one GEMM over the concatenated K:
+ * out = relu(conv3(in) + downsample(in2) + bias); w [Cout][Cin+Cin2], bias = folded b3 + b_ds;
+ * in [B,H,W,Cin] (1x1 stride 1), in2 [B,H2,W2,Cin2] sampled at (oh*stride2, ow*stride2). */
+int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
+                              int H2, int W2, int Cin2, int stride2, int Cout, int relu, ssg_stream_t stream);
 /* [B,3,H,W] NCHW -> [B,H,W,4] NHWC (4th channel 0); flip != 0 mirrors W (evaluators.py:12-16 fliplr) */
 int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, ssg_stream_t stream);
 /* MaxPool2d(3, stride 2, padding 1) on NHWC (base.py:105) */

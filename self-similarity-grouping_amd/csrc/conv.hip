@@ -31,6 +31,8 @@ struct ConvParams {
   int M, Kpad;   // M = B*OH*OW, Kpad = weight row length (multiple of 32)
   int variant;   // tuning knob (SSG_CONV_VARIANT), 0 = default
   unsigned in_bytes;   // size of the input tensor (buffer-resource bound)
+  // optional second 1x1 input concatenated along K (fused downsample branch): k-tiles >= nk1 read in2
+  const float* in2; int H2, W2, Cin2, stride2, nk1; unsigned in2_bytes;
 };
 
 constexpr int CBK = 32, CLD = 36;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   // the hardware bounds check returns zeros -- no branch, no select (a load under a branch makes
   // hipcc wait for it on the spot and serialises the prefetch).
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? p.in2_bytes : 0u, 0x00020000);
 #define SSG_LOAD_A(J)                                                                                   \
   {                                                                                                     \
     const int ih = ah##J + r, iw = aw##J + s_;                                                          \
@@ -98,12 +101,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);                          \
     pa##J = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
   }
+// second input (fused downsample): 1x1, stride2, same output pixel grid
+#define SSG_LOAD_A2(J)                                                                                  \
+  {                                                                                                     \
+    const int oh_ = (ah##J + p.pad) / p.stride, ow_ = (aw##J + p.pad) / p.stride;                       \
+    const int bc = max(ab##J, 0);                                                                       \
+    const unsigned off = (unsigned)((((bc * p.H2 + oh_ * p.stride2) * p.W2 + ow_ * p.stride2) * p.Cin2 + c2_) * 4) + (ab##J >= 0 ? 0u : 0x80000000u); \
+    const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, off, 0, 0);                         \
+    pa##J = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
+  }
 #define SSG_GLOAD(KT)                                                                                   \
   {                                                                                                     \
-    int r, s_, c;                                                                                       \
-    if (CIN4) { const int tap = (KT) * 8 + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; /* -> !ok */ } \
-    else { const int k0 = (KT) * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s_ = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; } \
-    SSG_LOAD_A(0) SSG_LOAD_A(1) SSG_LOAD_A(2) SSG_LOAD_A(3)                                             \
+    if ((KT) < p.nk1) {                                                                                 \
+      int r, s_, c;                                                                                     \
+      if (CIN4) { const int tap = (KT) * 8 + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; /* -> !ok */ } \
+      else { const int k0 = (KT) * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s_ = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; } \
+      SSG_LOAD_A(0) SSG_LOAD_A(1) SSG_LOAD_A(2) SSG_LOAD_A(3)                                           \
+    } else {                                                                                            \
+      const int c2_ = ((KT) - p.nk1) * CBK + kq * 4;                                                    \
+      SSG_LOAD_A2(0) SSG_LOAD_A2(1) SSG_LOAD_A2(2) SSG_LOAD_A2(3)                                       \
+    }                                                                                                   \
     pb0 = *reinterpret_cast<const float4*>(wbase + (KT) * CBK);                                         \
     pb1 = *reinterpret_cast<const float4*>(wbase + wstep + (KT) * CBK);                                 \
     if (BJ == 4) {                                                                                      \
@@ -188,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   }
 
 #undef SSG_LOAD_A
+#undef SSG_LOAD_A2
 #undef SSG_GLOAD
 #undef SSG_LSTORE
   // epilogue.  D = W * A^T: C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -327,12 +345,37 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
   const int64_t in_bytes = (int64_t)B * H * W * Cin * 4;
   if (in_bytes > 0x7fffffffLL) { ssg_set_error("ssg_conv2d_nhwc_f32: input tensor of %lld bytes exceeds the 2 GiB buffer-resource range of this kernel; use a smaller batch", (long long)in_bytes); return SSG_ERR_INVALID; }
   p.in_bytes = (unsigned)in_bytes;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("SSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
   p.variant = variant;
   const bool cin4 = (Cin == 4);
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
+  p.nk1 = p.Kpad / 32;
   if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);
+  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
+}
+
+// Fused bottleneck tail with a downsample branch (reid/models/base.py:75-90 when
+// self.downsample is not None):  out = relu( conv3(in) + bn3 + downsample_conv(in2) + bn_ds )
+// as ONE implicit GEMM over the concatenated K = Cin + Cin2: w [Cout][Cin + Cin2], bias = b3 + b_ds.
+// in [B,H,W,Cin] (1x1, stride 1); in2 [B,H2,W2,Cin2] sampled at (oh*stride2, ow*stride2).
+extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W,
+                                         int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, hipStream_t stream) {
+  ConvParams p;
+  p.in = in; p.w = w; p.bias = bias; p.res = nullptr; p.out = out;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = relu;
+  p.OH = H; p.OW = W;
+  const int64_t M = (int64_t)B * H * W;
+  const int64_t in_bytes = M * Cin * 4, in2_bytes = (int64_t)B * H2 * W2 * Cin2 * 4;
+  if (B <= 0 || M > 0x7fffffff || (Cout % 64) || (Cin % 32) || (Cin2 % 32) || stride2 < 1 || (H - 1) * stride2 >= H2 || (W - 1) * stride2 >= W2 ||
+      in_bytes > 0x7fffffffLL || in2_bytes > 0x7fffffffLL) {
+    ssg_set_error("ssg_conv1x1_dual_nhwc_f32: unsupported shape B=%d H=%d W=%d Cin=%d H2=%d W2=%d Cin2=%d s2=%d Cout=%d", B, H, W, Cin, H2, W2, Cin2, stride2, Cout);
+    return SSG_ERR_INVALID;
+  }
+  p.M = (int)M; p.in_bytes = (unsigned)in_bytes;
+  p.in2 = in2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.in2_bytes = (unsigned)in2_bytes;
+  p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0;
   return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 

@@ -170,11 +170,16 @@ class ResNet:
         net = dict(stem=_fold(sd, "base.conv1", "base.bn1", 2, 3, dev), blocks=[])
         for blk in _arch(self.depth):
             p = blk["prefix"]
+            c3 = _fold(sd, p + ".conv3", p + ".bn3", 1, 0, dev)
+            ds = _fold(sd, p + ".downsample.0", p + ".downsample.1", blk["stride"], 0, dev) if blk["down"] else None
+            if ds is not None:
+                # downsample branch fused into conv3: one GEMM over K = planes + inplanes
+                # (the residual tensor is never written to / re-read from HBM)
+                ds.w = torch.cat([c3.w, ds.w], dim=1).contiguous(); ds.bias = (c3.bias + ds.bias).contiguous()
             net["blocks"].append(dict(
                 c1=_fold(sd, p + ".conv1", p + ".bn1", 1, 0, dev),
                 c2=_fold(sd, p + ".conv2", p + ".bn2", blk["stride"], 1, dev),
-                c3=_fold(sd, p + ".conv3", p + ".bn3", 1, 0, dev),
-                ds=_fold(sd, p + ".downsample.0", p + ".downsample.1", blk["stride"], 0, dev) if blk["down"] else None))
+                c3=c3, ds=ds))
         self._folded = net
         return net
 
@@ -186,6 +191,16 @@ class ResNet:
         out = torch.empty((B, OH, OW, f.cout), dtype=torch.float32, device=x.device)
         check(L.ssg_conv2d_nhwc_f32(ptr(x), ptr(f.w), ptr(f.bias), ptr(res), ptr(out), B, H, W, f.cin, f.cout, f.k, f.k, f.stride, f.pad,
                                     1 if relu else 0, stream()), "ssg_conv2d_nhwc_f32")
+        return out
+
+    @staticmethod
+    def _conv_dual(L, o, x, c3, ds):
+        """relu(conv3(o) + downsample(x)) as one GEMM (ssg_conv1x1_dual_nhwc_f32)."""
+        B, H, W, _ = o.shape
+        _, H2, W2, _ = x.shape
+        out = torch.empty((B, H, W, c3.cout), dtype=torch.float32, device=o.device)
+        check(L.ssg_conv1x1_dual_nhwc_f32(ptr(o), ptr(x), ptr(ds.w), ptr(ds.bias), ptr(out), B, H, W, c3.cin, H2, W2, ds.cin, ds.stride, c3.cout, 1,
+                                          stream()), "ssg_conv1x1_dual_nhwc_f32")
         return out
 
     def feature_map(self, x, flip=False):
@@ -207,8 +222,10 @@ class ResNet:
         for blk in net["blocks"]:
             o = self._conv(L, y, blk["c1"])
             o = self._conv(L, o, blk["c2"])
-            res = self._conv(L, y, blk["ds"], relu=False) if blk["ds"] is not None else y
-            y = self._conv(L, o, blk["c3"], res=res, relu=True)
+            if blk["ds"] is not None:
+                y = self._conv_dual(L, o, y, blk["c3"], blk["ds"])
+            else:
+                y = self._conv(L, o, blk["c3"], res=y, relu=True)
         return y
 
     def pooled(self, fmap):
