@@ -193,7 +193,8 @@ def main():
         return
     n_img = args.N + args.Ns
     # ---- roofline of the dominant kernel: implicit-GEMM convolution on the fp32 matrix cores
-    n_conv, ms_conv = tot.get("ssg_conv2d_nhwc_f32", (1, float("nan")))
+    convs = [tot[k] for k in ("ssg_conv2d_nhwc_f32", "ssg_conv1x1_dual_nhwc_f32") if k in tot]
+    n_conv, ms_conv = (sum(c[0] for c in convs), sum(c[1] for c in convs)) if convs else (1, float("nan"))
     imgs_rank = (t_hi - t_lo) + (s_hi - s_lo)
     conv_tf = imgs_rank * args.steps * FLOP_PER_IMAGE / (ms_conv * 1e-3) / 1e12
     roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2, 53 convs x 2 orientations per image)",
