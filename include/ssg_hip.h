@@ -130,6 +130,10 @@ int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, cons
  * in [B,H,W,Cin] (1x1 stride 1), in2 [B,H2,W2,Cin2] sampled at (oh*stride2, ow*stride2). */
 int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
                               int H2, int W2, int Cin2, int stride2, int Cout, int relu, ssg_stream_t stream);
+/* float32 squared-L2 block (reid/evaluators.py:63-85 pairwise_distance) on the fp32 matrix cores:
+ * out[i,j] = |x_i|^2 + |y_j|^2 - 2<x_i,y_j>; self_form != 0 gives the reference's query=None form
+ * 2|x_i|^2 - 2<x_i,y_j> (:64-72).  x [m,d], y [n,d], out [m,n]; d % 32 == 0, n % 64 == 0; ws = m+n floats. */
+int ssg_pairwise_sqdist_f32(const float* x, const float* y, int m, int n, int d, int self_form, float* ws, float* out, ssg_stream_t stream);
 /* [B,3,H,W] NCHW -> [B,H,W,4] NHWC (4th channel 0); flip != 0 mirrors W (evaluators.py:12-16 fliplr) */
 int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, ssg_stream_t stream);
 /* MaxPool2d(3, stride 2, padding 1) on NHWC (base.py:105) */

@@ -33,6 +33,8 @@ struct ConvParams {
   unsigned in_bytes;   // size of the input tensor (buffer-resource bound)
   // optional second 1x1 input concatenated along K (fused downsample branch): k-tiles >= nk1 read in2
   const float* in2; int H2, W2, Cin2, stride2, nk1; unsigned in2_bytes;
+  // epilogue mode 1 (pairwise distance, reid/evaluators.py:63-85): out = rowterm[m] + bias[col] - 2*acc
+  const float* rowterm; int epi;
 };
 
 constexpr int CBK = 32, CLD = 36;
@@ -237,6 +239,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         const int col = tn * BN + wn * WN + j * 32 + 8 * q + 4 * h;
         const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
         float4 v = make_float4(acc[i][j][4 * q] + bias.x, acc[i][j][4 * q + 1] + bias.y, acc[i][j][4 * q + 2] + bias.z, acc[i][j][4 * q + 3] + bias.w);
+        if (p.epi == 1) {
+          const float rt = p.rowterm[m < p.M ? m : 0];
+          v = make_float4((rt + bias.x) - 2.f * acc[i][j][4 * q], (rt + bias.y) - 2.f * acc[i][j][4 * q + 1], (rt + bias.z) - 2.f * acc[i][j][4 * q + 2],
+                          (rt + bias.w) - 2.f * acc[i][j][4 * q + 3]);
+        }
         if (resp) { v.x += rr[i][j][q].x; v.y += rr[i][j][q].y; v.z += rr[i][j][q].z; v.w += rr[i][j][q].w; }
         if (p.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
         if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
@@ -345,7 +352,7 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
   const int64_t in_bytes = (int64_t)B * H * W * Cin * 4;
   if (in_bytes > 0x7fffffffLL) { ssg_set_error("ssg_conv2d_nhwc_f32: input tensor of %lld bytes exceeds the 2 GiB buffer-resource range of this kernel; use a smaller batch", (long long)in_bytes); return SSG_ERR_INVALID; }
   p.in_bytes = (unsigned)in_bytes;
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 0;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("SSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
   p.variant = variant;
@@ -375,8 +382,41 @@ extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, cons
   }
   p.M = (int)M; p.in_bytes = (unsigned)in_bytes;
   p.in2 = in2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.in2_bytes = (unsigned)in2_bytes;
-  p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0;
+  p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0;
   return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
+}
+
+namespace ssg {
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, int rows, int d, float scale, float* __restrict__ out) {
+  const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (row >= rows) return;
+  const int lane = lane_id();
+  float s = 0.f;
+  for (int c = lane; c < d; c += 64) { const float v = x[(int64_t)row * d + c]; s += v * v; }
+  for (int sh = 1; sh < 64; sh <<= 1) s += __shfl_xor(s, sh, 64);
+  if (lane == 0) out[row] = s * scale;
+}
+}  // namespace ssg
+
+// Squared-L2 distance block in float32 (reid/evaluators.py:63-85 pairwise_distance):
+//   out[i, j] = rowterm[i] + colterm[j] - 2 * <x_i, y_j>      x [m,d], y [n,d], out [m,n]
+// rowterm/colterm are computed here: |x_i|^2 and |y_j|^2, or (self_form != 0, the reference's
+// query=None branch :64-72) rowterm = 2*|x_i|^2, colterm = 0.  d % 32 == 0, n % 64 == 0 (pad).
+// ws: m + n floats.  Same fp32-MFMA GEMM as the convolutions.
+extern "C" int ssg_pairwise_sqdist_f32(const float* x, const float* y, int m, int n, int d, int self_form, float* ws, float* out, hipStream_t stream) {
+  if (m <= 0 || n <= 0 || (d % 32) || (n % 64) || (int64_t)m * d * 4 > 0x7fffffffLL) {
+    ssg_set_error("ssg_pairwise_sqdist_f32: need d %% 32 == 0, n %% 64 == 0 and x < 2 GiB (m=%d n=%d d=%d)", m, n, d);
+    return SSG_ERR_INVALID;
+  }
+  float* rowterm = ws; float* colterm = ws + m;
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((m + 3) / 4), dim3(256), 0, stream, x, m, d, self_form ? 2.f : 1.f, rowterm);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, y, n, d, self_form ? 0.f : 1.f, colterm);
+  ConvParams p;
+  p.in = x; p.w = y; p.bias = colterm; p.res = nullptr; p.out = out;
+  p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
+  p.M = m; p.Kpad = d; p.nk1 = d / 32; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 1;
+  return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
 extern "C" int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, hipStream_t stream) {

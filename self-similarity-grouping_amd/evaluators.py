@@ -77,21 +77,39 @@ def extract_features(model, data_loader, print_freq=20, for_eval=True, metric=No
     return features, labels
 
 
-def pairwise_distance(features, query=None, gallery=None, metric=None):
-    """reid/evaluators.py:63-85 (float32 squared L2 on device; evaluation path)."""
+def _sqdist(x, y, self_form=False):
+    """float32 squared-L2 block on the HIP fp32-MFMA GEMM (ssg_pairwise_sqdist_f32)."""
+    from . import _lib
+    from ._lib import check, ptr, stream
+    L = _lib.lib()
     dev = torch.device("cuda", torch.cuda.current_device())
+    x = x.to(dev, torch.float32).contiguous(); y = y.to(dev, torch.float32).contiguous()
+    m, d = x.shape; n = y.shape[0]
+    dp, npad = (-d) % 32, (-n) % 64
+    if dp:
+        x = torch.nn.functional.pad(x, (0, dp)); y = torch.nn.functional.pad(y, (0, dp))
+    if npad:
+        y = torch.nn.functional.pad(y, (0, 0, 0, npad))
+    out = torch.empty((m, n + npad), dtype=torch.float32, device=dev)
+    ws = torch.empty(m + n + npad, dtype=torch.float32, device=dev)
+    check(L.ssg_pairwise_sqdist_f32(ptr(x), ptr(y), m, n + npad, d + dp, 1 if self_form else 0, ptr(ws), ptr(out), stream()), "ssg_pairwise_sqdist_f32")
+    return out[:, :n]
+
+
+def pairwise_distance(features, query=None, gallery=None, metric=None):
+    """reid/evaluators.py:63-85 on the GPU (float32 squared L2; returns a CPU tensor like the
+    reference).  The query=None branch keeps the reference's 2|x_i|^2 - 2<x_i,x_j> form (:64-72),
+    which equals the squared distance only for unit-norm rows."""
     if query is None and gallery is None:
         n = len(features)
-        x = torch.cat([f.view(1, -1) for f in features.values()]).to(dev).view(n, -1)
+        x = torch.cat([f.view(1, -1) for f in features.values()]).view(n, -1)
         if metric is not None:
             x = metric.transform(x)
-        dist = torch.pow(x, 2).sum(dim=1, keepdim=True) * 2
-        return (dist.expand(n, n) - 2 * torch.mm(x, x.t())).cpu()
-    x = torch.cat([features[f].unsqueeze(0) for f, _, _ in query], 0).to(dev)
-    y = torch.cat([features[f].unsqueeze(0) for f, _, _ in gallery], 0).to(dev)
+        return _sqdist(x, x, self_form=True).cpu()
+    x = torch.cat([features[f].unsqueeze(0) for f, _, _ in query], 0)
+    y = torch.cat([features[f].unsqueeze(0) for f, _, _ in gallery], 0)
     m, n = x.size(0), y.size(0)
     x = x.view(m, -1); y = y.view(n, -1)
     if metric is not None:
         x = metric.transform(x); y = metric.transform(y)
-    dist = torch.pow(x, 2).sum(dim=1, keepdim=True).expand(m, n) + torch.pow(y, 2).sum(dim=1, keepdim=True).expand(n, m).t()
-    return torch.addmm(dist, x, y.t(), beta=1, alpha=-2).cpu()
+    return _sqdist(x, y).cpu()

@@ -379,3 +379,24 @@ def test_more_than_one_column_chunk_vs_oracle(dev, ora):
     oe, of, ost = ora.re_ranking(src, tgt, lambda_value=0.1, stages=True)
     assert np.array_equal(bits(h.euclid.cpu().numpy()), bits(oe))
     assert np.array_equal(bits(h.M.cpu().numpy()), bits(ost["jaccard_scaled"]))
+
+
+def test_pairwise_distance_dropin(dev):
+    """reid/evaluators.py:63-85 (float32): both branches vs the torch CPU formula; 2e-5 absolute
+    on distances of unit-norm features (fp32 GEMM accumulation order)."""
+    from collections import OrderedDict
+    import ssg_amd
+    g = torch.Generator().manual_seed(3)
+    feats = OrderedDict()
+    for i in range(70):
+        f = torch.randn(200, generator=g); feats["f%d" % i] = f / f.norm()
+    query = [("f%d" % i, 0, 0) for i in range(0, 30)]
+    gallery = [("f%d" % i, 0, 0) for i in range(20, 70)]
+    x = torch.stack([feats[f] for f, _, _ in query]); y = torch.stack([feats[f] for f, _, _ in gallery])
+    ref = x.pow(2).sum(1, keepdim=True).expand(30, 50) + y.pow(2).sum(1, keepdim=True).expand(50, 30).t() - 2 * x @ y.t()
+    got = ssg_amd.pairwise_distance(feats, query, gallery)
+    assert got.shape == (30, 50) and got.device.type == "cpu" and (got - ref).abs().max() < 2e-5
+    allx = torch.stack(list(feats.values()))
+    ref_self = allx.pow(2).sum(1, keepdim=True) * 2 - 2 * allx @ allx.t()
+    got_self = ssg_amd.pairwise_distance(feats)
+    assert got_self.shape == (70, 70) and (got_self - ref_self).abs().max() < 2e-5
