@@ -37,7 +37,7 @@ struct ConvParams {
   const float* rowterm; int epi;
 };
 
-constexpr int CBK = 32, CLD = 36;
+constexpr int CLD32 = 36;   // LDS row pitch in floats for BK=32 (BK=16 uses 20): pitch/4 odd -> conflict-free b128
 
 __device__ __forceinline__ int conv_xcd_remap(int b, int nwg) {
   const int nx = 8, q = nwg / nx, r = nwg % nx, x = b % nx, s = b / nx;
@@ -51,12 +51,15 @@ __device__ __forceinline__ int conv_xcd_remap(int b, int nwg) {
 // The MFMA is issued as D = W_tile * A_tile^T (weights are the A operand), so a lane ends up
 // with 4 consecutive output channels of one pixel per accumulator quad: bias/residual/output
 // move as float4.
-template <int BM, int BN, int WM, int WN, bool CIN4>
+template <int BM, int BN, int WM, int WN, bool CIN4, int CBK>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   constexpr int WCOLS = BN / WN;
   static_assert((BM / WM) * WCOLS == 4, "4 waves per workgroup");
   constexpr int MT = WM / 32, NT = WN / 32;
-  constexpr int AJ = BM / 32, BJ = BN / 32; // float4 loads per thread for the A / W tile
+  constexpr int CLD = CBK + 4;              // LDS row pitch (floats)
+  constexpr int KQ = CBK / 4;               // float4 per tile row
+  constexpr int RPP = 256 / KQ;             // tile rows staged per pass
+  constexpr int AJ = BM / RPP, BJ = BN / RPP; // float4 loads per thread for the A / W tile
   constexpr int STAGE = (BM + BN) * CLD;    // floats per LDS stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // one declaration shared by the unity TU
   float* lds = reinterpret_cast<float*>(smem);
@@ -66,27 +69,28 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WCOLS, wn = wave % WCOLS;
-  const int kq = tid & 7, r0 = tid >> 3;
+  const int kq = tid & (KQ - 1), r0 = tid / KQ;
 
   // Staging state is kept in NAMED scalars, not arrays: hipcc left `float4 pb[BJ]` in scratch
   // memory (the prefetch then waited on every load to bounce it through the stack).
-  static_assert(AJ == 4 && (BJ == 4 || BJ == 2), "staging code is written for BM=128, BN in {64,128}");
-  int ab0, ab1, ab2, ab3, ah0, ah1, ah2, ah3, aw0, aw1, aw2, aw3;
+  static_assert((AJ == 4 && (BJ == 4 || BJ == 2)) || (AJ == 2 && (BJ == 2 || BJ == 1)), "staging code is written for BM=128, BN in {64,128}, BK in {16,32}");
+  int ab0, ab1, ab2 = -1, ab3 = -1, ah0, ah1, ah2 = 0, ah3 = 0, aw0, aw1, aw2 = 0, aw3 = 0;
 #define SSG_ROW_INIT(J)                                                            \
   {                                                                                \
-    const int m = tm * BM + r0 + 32 * J;                                           \
+    const int m = tm * BM + r0 + RPP * J;                                          \
     if (m < p.M) {                                                                 \
       const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);                \
       const int oh = rem / p.OW, ow = rem - oh * p.OW;                             \
       ab##J = b; ah##J = oh * p.stride - p.pad; aw##J = ow * p.stride - p.pad;     \
     } else { ab##J = -1; ah##J = 0; aw##J = 0; }                                   \
   }
-  SSG_ROW_INIT(0) SSG_ROW_INIT(1) SSG_ROW_INIT(2) SSG_ROW_INIT(3)
+  SSG_ROW_INIT(0) SSG_ROW_INIT(1)
+  if (AJ == 4) { SSG_ROW_INIT(2) SSG_ROW_INIT(3) }
 #undef SSG_ROW_INIT
   const float* wbase = p.w + (int64_t)(tn * BN + r0) * p.Kpad + kq * 4;
-  const int64_t wstep = (int64_t)32 * p.Kpad;
+  const int64_t wstep = (int64_t)RPP * p.Kpad;
   float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
-  pb2 = pb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  pa2 = pa3 = pb1 = pb2 = pb3 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // A tile through a buffer resource: padding taps / rows beyond M get an out-of-range offset and
   // the hardware bounds check returns zeros -- no branch, no select (a load under a branch makes
@@ -116,15 +120,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   {                                                                                                     \
     if ((KT) < p.nk1) {                                                                                 \
       int r, s_, c;                                                                                     \
-      if (CIN4) { const int tap = (KT) * 8 + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; /* -> !ok */ } \
+      if (CIN4) { const int tap = (KT) * KQ + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; /* -> !ok */ } \
       else { const int k0 = (KT) * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s_ = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; } \
-      SSG_LOAD_A(0) SSG_LOAD_A(1) SSG_LOAD_A(2) SSG_LOAD_A(3)                                           \
+      SSG_LOAD_A(0) SSG_LOAD_A(1) if (AJ == 4) { SSG_LOAD_A(2) SSG_LOAD_A(3) }                          \
     } else {                                                                                            \
       const int c2_ = ((KT) - p.nk1) * CBK + kq * 4;                                                    \
-      SSG_LOAD_A2(0) SSG_LOAD_A2(1) SSG_LOAD_A2(2) SSG_LOAD_A2(3)                                       \
+      SSG_LOAD_A2(0) SSG_LOAD_A2(1) if (AJ == 4) { SSG_LOAD_A2(2) SSG_LOAD_A2(3) }                      \
     }                                                                                                   \
     pb0 = *reinterpret_cast<const float4*>(wbase + (KT) * CBK);                                         \
-    pb1 = *reinterpret_cast<const float4*>(wbase + wstep + (KT) * CBK);                                 \
+    if (BJ >= 2) pb1 = *reinterpret_cast<const float4*>(wbase + wstep + (KT) * CBK);                    \
     if (BJ == 4) {                                                                                      \
       pb2 = *reinterpret_cast<const float4*>(wbase + 2 * wstep + (KT) * CBK);                           \
       pb3 = *reinterpret_cast<const float4*>(wbase + 3 * wstep + (KT) * CBK);                           \
@@ -135,14 +139,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     float* As_ = lds + (BUF) * STAGE;                                                                   \
     float* Bs_ = As_ + BM * CLD;                                                                        \
     *reinterpret_cast<float4*>(As_ + (r0 + 0) * CLD + kq * 4) = pa0;                                    \
-    *reinterpret_cast<float4*>(As_ + (r0 + 32) * CLD + kq * 4) = pa1;                                   \
-    *reinterpret_cast<float4*>(As_ + (r0 + 64) * CLD + kq * 4) = pa2;                                   \
-    *reinterpret_cast<float4*>(As_ + (r0 + 96) * CLD + kq * 4) = pa3;                                   \
+    *reinterpret_cast<float4*>(As_ + (r0 + RPP) * CLD + kq * 4) = pa1;                                  \
+    if (AJ == 4) {                                                                                      \
+      *reinterpret_cast<float4*>(As_ + (r0 + 2 * RPP) * CLD + kq * 4) = pa2;                            \
+      *reinterpret_cast<float4*>(As_ + (r0 + 3 * RPP) * CLD + kq * 4) = pa3;                            \
+    }                                                                                                   \
     *reinterpret_cast<float4*>(Bs_ + (r0 + 0) * CLD + kq * 4) = pb0;                                    \
-    *reinterpret_cast<float4*>(Bs_ + (r0 + 32) * CLD + kq * 4) = pb1;                                   \
+    if (BJ >= 2) *reinterpret_cast<float4*>(Bs_ + (r0 + RPP) * CLD + kq * 4) = pb1;                     \
     if (BJ == 4) {                                                                                      \
-      *reinterpret_cast<float4*>(Bs_ + (r0 + 64) * CLD + kq * 4) = pb2;                                 \
-      *reinterpret_cast<float4*>(Bs_ + (r0 + 96) * CLD + kq * 4) = pb3;                                 \
+      *reinterpret_cast<float4*>(Bs_ + (r0 + 2 * RPP) * CLD + kq * 4) = pb2;                            \
+      *reinterpret_cast<float4*>(Bs_ + (r0 + 3 * RPP) * CLD + kq * 4) = pb3;                            \
     }                                                                                                   \
   }
 
@@ -318,19 +324,29 @@ __global__ __launch_bounds__(256) void flip_sum_l2norm_kernel(const float* __res
 
 using namespace ssg;
 
-template <int BM, int BN, int WM, int WN, bool CIN4>
-static int launch_conv(const ConvParams& p, hipStream_t stream) {
-  const size_t lds = 2 * (size_t)(BM + BN) * CLD * sizeof(float);
+template <int BM, int BN, int WM, int WN, bool CIN4, int CBK>
+static int launch_conv_bk(const ConvParams& p, hipStream_t stream) {
+  const size_t lds = 2 * (size_t)(BM + BN) * (CBK + 4) * sizeof(float);
   const int tiles = ((p.M + BM - 1) / BM) * (p.Cout / BN);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    int rc = ssg_check_hip(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, CIN4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+    int rc = ssg_check_hip(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "hipFuncSetAttribute(conv)");
     if (rc) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, CIN4>), dim3(tiles), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK>), dim3(tiles), dim3(256), lds, stream, p);
   return ssg_check_hip(hipGetLastError(), "conv_igemm_kernel");
+}
+// BK=16 stages (default): half the LDS of BK=32 -> 3 instead of 2 co-resident workgroups per CU, so one
+// workgroup's prologue / epilogue overlaps the others' MFMA phases.  The fused dual-input GEMM stays
+// on BK=32.  SSG_CONV_BK16_MAXK=<K> restricts BK=16 to reductions of at most K (tuning knob).
+template <int BM, int BN, int WM, int WN, bool CIN4>
+static int launch_conv(const ConvParams& p, hipStream_t stream) {
+  static int bk16_max = -1;   // measured on MI355X: BK=16 wins for every ResNet-50 layer (9.1k -> 9.8k img/s)
+  if (bk16_max < 0) { const char* e = getenv("SSG_CONV_BK16_MAXK"); bk16_max = e ? atoi(e) : 0x7fffffff; }
+  if (!p.in2 && p.Kpad <= bk16_max) return launch_conv_bk<BM, BN, WM, WN, CIN4, 16>(p, stream);
+  return launch_conv_bk<BM, BN, WM, WN, CIN4, 32>(p, stream);
 }
 
 // Conv2d(bias folded from eval BatchNorm) + optional residual add + optional ReLU, NHWC fp32.
@@ -358,7 +374,7 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
   p.variant = variant;
   const bool cin4 = (Cin == 4);
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
-  p.nk1 = p.Kpad / 32;
+  p.nk1 = p.Kpad / 16;   // no second input: every k-tile (of either BK) reads `in`
   if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);
   return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
@@ -382,7 +398,7 @@ extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, cons
   }
   p.M = (int)M; p.in_bytes = (unsigned)in_bytes;
   p.in2 = in2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.in2_bytes = (unsigned)in2_bytes;
-  p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0;
+  p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0;   // dual input stays on BK=32 (nk1 counts 32-wide tiles)
   return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
@@ -414,7 +430,7 @@ extern "C" int ssg_pairwise_sqdist_f32(const float* x, const float* y, int m, in
   ConvParams p;
   p.in = x; p.w = y; p.bias = colterm; p.res = nullptr; p.out = out;
   p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
-  p.M = m; p.Kpad = d; p.nk1 = d / 32; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
+  p.M = m; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
   p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 1;
   return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }

@@ -7,7 +7,7 @@
 // v_mfma_f64_16x16x4_f64 (MFMA-bound, 2*M*N*d flop).  Row norms are taken from the SAME
 // instruction sequence (norm_kernel) so duplicate rows give d2 == 0 exactly, like cdist.
 //
-// Block tile 128x128, BK=32, 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles (16 f64
+// Block tile 128x128, BK=16 (double-buffered LDS stages), 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles (16 f64
 // accumulators x4 = 128 VGPRs).  Operands are converted f32 -> (half ->) f64 while being
 // staged into LDS in [k][row] order with a 16-double pad per k-row: fragment reads
 // (ds_read_b64, lane = row + 16*k) are bank-conflict free.
@@ -17,7 +17,7 @@ namespace ssg {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDR = 144;  // LDR: padded rows per k slice
+constexpr int BM = 128, BN = 128, BK = 16, LDR = 144;  // LDR: padded rows per k slice
 
 template <bool ROUND16>
 __device__ __forceinline__ double cvt_in(float x) {
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
                                                       int M, int N, int d, int rowA0, hbits* __restrict__ D,
                                                       unsigned* __restrict__ rowred, int symmetric) {
   constexpr bool R16 = (MODE == 0);
-  __shared__ double As[BK * LDR];
-  __shared__ double Bs[BK * LDR];
+  // double-buffered LDS stages of BK=16 k-slices: [stage][A|B][k][row(+pad)] doubles
+  __shared__ double lds[2 * 2 * BK * LDR];
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   int tm, tn;
   if (MODE == 0 && symmetric) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
   const bool mirror = MODE == 0 && symmetric && tn > tm;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // staging map: one row per thread, 16 consecutive k (4 x float4)
+  // staging map: one row per thread, 8 consecutive k (2 x float4) of the 16-wide k slice
   const int srow = tid & 127, shalf = tid >> 7;
   const int arow = tm * BM + srow, brow = tn * BN + srow;
   const float* ap = A + (int64_t)(arow < M ? arow : 0) * d;
@@ -99,52 +99,69 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = (v4d){0., 0., 0., 0.};
 
-  float4 pa[4], pb[4];
-  auto gload = [&](int kt) {
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      // unconditional loads (clamped address) + select: loads under a branch are waited for on the spot
-      const int k = kt * BK + shalf * 16 + q * 4;
-      const bool kin = k < d;
-      const float4 va = *reinterpret_cast<const float4*>(ap + (kin ? k : 0));
-      const float4 vb = *reinterpret_cast<const float4*>(bp + (kin ? k : 0));
-      pa[q] = (aok && kin) ? va : make_float4(0.f, 0.f, 0.f, 0.f);
-      pb[q] = (bok && kin) ? vb : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
+  // named prefetch registers (arrays of float4 tend to end up in scratch)
+  float4 pa0, pa1, pb0, pb1;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define SSG_GL(KT)                                                                         \
+  {                                                                                        \
+    const int k_ = (KT) * BK + shalf * 8;                                                  \
+    const bool in0 = k_ < d, in1 = k_ + 4 < d;                                             \
+    const float4 va0 = *reinterpret_cast<const float4*>(ap + (in0 ? k_ : 0));              \
+    const float4 va1 = *reinterpret_cast<const float4*>(ap + (in1 ? k_ + 4 : 0));          \
+    const float4 vb0 = *reinterpret_cast<const float4*>(bp + (in0 ? k_ : 0));              \
+    const float4 vb1 = *reinterpret_cast<const float4*>(bp + (in1 ? k_ + 4 : 0));          \
+    pa0 = (aok && in0) ? va0 : z4; pa1 = (aok && in1) ? va1 : z4;                          \
+    pb0 = (bok && in0) ? vb0 : z4; pb1 = (bok && in1) ? vb1 : z4;                          \
+  }
+#define SSG_LS(BUF)                                                                        \
+  {                                                                                        \
+    double* As_ = lds + (BUF) * (2 * BK * LDR);                                            \
+    double* Bs_ = As_ + BK * LDR;                                                          \
+    const int k_ = shalf * 8;                                                              \
+    As_[(k_ + 0) * LDR + srow] = cvt_in<R16>(pa0.x); As_[(k_ + 1) * LDR + srow] = cvt_in<R16>(pa0.y); \
+    As_[(k_ + 2) * LDR + srow] = cvt_in<R16>(pa0.z); As_[(k_ + 3) * LDR + srow] = cvt_in<R16>(pa0.w); \
+    As_[(k_ + 4) * LDR + srow] = cvt_in<R16>(pa1.x); As_[(k_ + 5) * LDR + srow] = cvt_in<R16>(pa1.y); \
+    As_[(k_ + 6) * LDR + srow] = cvt_in<R16>(pa1.z); As_[(k_ + 7) * LDR + srow] = cvt_in<R16>(pa1.w); \
+    Bs_[(k_ + 0) * LDR + srow] = cvt_in<R16>(pb0.x); Bs_[(k_ + 1) * LDR + srow] = cvt_in<R16>(pb0.y); \
+    Bs_[(k_ + 2) * LDR + srow] = cvt_in<R16>(pb0.z); Bs_[(k_ + 3) * LDR + srow] = cvt_in<R16>(pb0.w); \
+    Bs_[(k_ + 4) * LDR + srow] = cvt_in<R16>(pb1.x); Bs_[(k_ + 5) * LDR + srow] = cvt_in<R16>(pb1.y); \
+    Bs_[(k_ + 6) * LDR + srow] = cvt_in<R16>(pb1.z); Bs_[(k_ + 7) * LDR + srow] = cvt_in<R16>(pb1.w); \
+  }
   const int nk = (d + BK - 1) / BK;
-  gload(0);
   const int l16 = lane & 15, lk = lane >> 4;
+  SSG_GL(0)
+  SSG_LS(0)
+  __syncthreads();
   for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk) SSG_GL(kt + 1)   // next slice's HBM/L2 latency hides under this slice's MFMAs
+    const double* As = lds + (kt & 1) * (2 * BK * LDR);
+    const double* Bs = As + BK * LDR;
+    // fragments of k-step kk+1 are read from LDS while the 16 MFMAs of step kk run
+    double a[2][4], b[2][4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int k = shalf * 16 + q * 4;
-      As[(k + 0) * LDR + srow] = cvt_in<R16>(pa[q].x);
-      As[(k + 1) * LDR + srow] = cvt_in<R16>(pa[q].y);
-      As[(k + 2) * LDR + srow] = cvt_in<R16>(pa[q].z);
-      As[(k + 3) * LDR + srow] = cvt_in<R16>(pa[q].w);
-      Bs[(k + 0) * LDR + srow] = cvt_in<R16>(pb[q].x);
-      Bs[(k + 1) * LDR + srow] = cvt_in<R16>(pb[q].y);
-      Bs[(k + 2) * LDR + srow] = cvt_in<R16>(pb[q].z);
-      Bs[(k + 3) * LDR + srow] = cvt_in<R16>(pb[q].w);
-    }
-    __syncthreads();
-    if (kt + 1 < nk) gload(kt + 1);  // next tile's HBM/L2 latency hides under the MFMAs
+    for (int i = 0; i < 4; i++) a[0][i] = As[lk * LDR + wm * 64 + i * 16 + l16];
+#pragma unroll
+    for (int j = 0; j < 4; j++) b[0][j] = Bs[lk * LDR + wn * 64 + j * 16 + l16];
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
-      const int k = kk * 4 + lk;
-      double a[4], b[4];
+      const int cur = kk & 1, nxt = cur ^ 1;
+      if (kk + 1 < BK / 4) {
+        const int k = (kk + 1) * 4 + lk;
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[k * LDR + wm * 64 + i * 16 + l16];
+        for (int i = 0; i < 4; i++) a[nxt][i] = As[k * LDR + wm * 64 + i * 16 + l16];
 #pragma unroll
-      for (int j = 0; j < 4; j++) b[j] = Bs[k * LDR + wn * 64 + j * 16 + l16];
+        for (int j = 0; j < 4; j++) b[nxt][j] = Bs[k * LDR + wn * 64 + j * 16 + l16];
+      }
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
+    if (kt + 1 < nk) SSG_LS((kt + 1) & 1)   // other stage: its readers finished before the previous barrier
     __syncthreads();
   }
+#undef SSG_GL
+#undef SSG_LS
 
   // epilogue.  f64 MFMA C/D layout: col = lane&15, row = (lane>>4) + 4*reg.
   unsigned cmax[4] = {0u, 0u, 0u, 0u};   // mirror: running max of the column this lane owns in tile j
