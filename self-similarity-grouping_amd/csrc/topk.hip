@@ -71,22 +71,24 @@ __global__ __launch_bounds__(256) void topk_rank_kernel(const hbits* __restrict_
     const unsigned w[4] = {cur.x, cur.y, cur.z, cur.w};
     const int j0 = c * 512 + lane * 8 - first;   // row-relative column of element 0
     const bool interior = (c > 0) && (c + 1 < nchunks);   // every lane's 8 columns are inside the row
-    if (interior) {
-      // fast reject: packed 16-bit min of the lane's 8 raw values against the prefilter bound
-      unsigned lo = 0xffffu, hi = 0xffffu;
-#pragma unroll
-      for (int q = 0; q < 4; q++) { const unsigned a0 = w[q] & 0xffffu, a1 = w[q] >> 16; lo = a0 < lo ? a0 : lo; hi = a1 < hi ? a1 : hi; }
-      const unsigned mn = lo < hi ? lo : hi;
-      if (!__any(mn <= raw_hi)) continue;
-    }
+    // per-lane bitmask of elements that pass the raw prefilter
+    unsigned pm = 0;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-      const hbits r = (hbits)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      const unsigned r = (w[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
       const int j = j0 + e;
-      const bool pre = (interior || (j >= 0 && j < N)) && r <= raw_hi;
-      if (!__any(pre)) continue;
+      if ((interior || (j >= 0 && j < N)) && r <= raw_hi) pm |= 1u << e;
+    }
+    // drain the masks: one element per lane per round (typically a single round with 1-2 lanes)
+    while (__any(pm != 0)) {
       uint64_t comp = ~0ULL;
-      if (pre) comp = make_comp(f2h(h2f(r) / fmx), j, r);
+      if (pm) {
+        const int e = __ffs((int)pm) - 1;
+        pm &= pm - 1;
+        const unsigned wsel = e < 2 ? w[0] : e < 4 ? w[1] : e < 6 ? w[2] : w[3];
+        const hbits r = (hbits)((wsel >> ((e & 1) * 16)) & 0xffffu);
+        if (r <= raw_hi) comp = make_comp(f2h(h2f(r) / fmx), j0 + e, r);   // raw_hi may have tightened since pm was built
+      }
       bool cand = comp < tau;
       uint64_t mask = __ballot(cand);
       while (mask) {
