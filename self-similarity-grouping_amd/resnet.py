@@ -113,6 +113,11 @@ class ResNet:
             raise KeyError("Unsupported depth:", depth)
         if cluster:
             raise NotImplementedError("cluster=True (DEC head, reid/models/dce.py) is outside the grouping hot path")
+        if num_classes > 0:
+            raise NotImplementedError("num_classes > 0 (dropout + classifier head, resnet.py:118-120) is a training-only path; "
+                                      "the grouping path uses num_classes=0 (selftraining.py:121-123)")
+        if num_features > 0 and num_features % 64:
+            raise ValueError("num_features must be a multiple of 64")
         self.depth, self.num_features, self.dropout, self.num_classes = depth, num_features, dropout, num_classes
         self.num_split, self.cluster, self.pretrained, self.training = num_split, cluster, pretrained, False
         self.device = torch.device("cpu")
@@ -239,13 +244,20 @@ class ResNet:
         return out
 
     def _x2(self, gap):
+        """x2 = relu(feat_bn(feat(gap))) (resnet.py:112-117; unused by the extraction path, which takes
+        model(...)[0]) -- Linear + eval BatchNorm1d folded into one 1x1 GEMM on the same HIP kernel."""
         if self.num_features <= 0:
             return None
-        sd, dev = self._sd, self.device
-        x2 = gap @ sd["feat.weight"].to(dev).t()
-        x2 = (x2 - sd["feat_bn.running_mean"].to(dev)) / torch.sqrt(sd["feat_bn.running_var"].to(dev) + _BN_EPS) * sd["feat_bn.weight"].to(dev) \
-            + sd["feat_bn.bias"].to(dev)
-        return torch.relu(x2)
+        net = self._prepare()
+        if "feat" not in net:
+            sd = dict(self._sd)
+            sd["feat.weight4"] = sd["feat.weight"].view(self.num_features, 2048, 1, 1)
+            f = _fold({"c.weight": sd["feat.weight4"], "b.weight": sd["feat_bn.weight"], "b.bias": sd["feat_bn.bias"],
+                       "b.running_mean": sd["feat_bn.running_mean"], "b.running_var": sd["feat_bn.running_var"]}, "c", "b", 1, 0, self.device)
+            net["feat"] = f
+        B = gap.shape[0]
+        out = self._conv(_lib.lib(), gap.reshape(B, 1, 1, 2048).contiguous(), net["feat"], relu=True)
+        return out.reshape(B, self.num_features)
 
     def __call__(self, x, for_eval=False):
         sets = self.pooled(self.feature_map(x))

@@ -400,3 +400,22 @@ def test_pairwise_distance_dropin(dev):
     ref_self = allx.pow(2).sum(1, keepdim=True) * 2 - 2 * allx @ allx.t()
     got_self = ssg_amd.pairwise_distance(feats)
     assert got_self.shape == (70, 70) and (got_self - ref_self).abs().max() < 2e-5
+
+
+def test_x2_branch_matches_torch(dev):
+    """resnet.py:112-117 feat -> feat_bn -> relu on the pooled feature (HIP GEMM with folded BN)."""
+    import ssg_amd
+    m = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=3).cuda().eval()
+    sd = m.state_dict()
+    g = torch.Generator().manual_seed(0)
+    sd["feat_bn.running_mean"] = torch.randn(2048, generator=g) * 0.01; sd["feat_bn.running_var"] = torch.rand(2048, generator=g) + 0.5
+    sd["feat_bn.weight"] = torch.rand(2048, generator=g) + 0.5; sd["feat_bn.bias"] = torch.randn(2048, generator=g) * 0.01
+    m.load_state_dict(sd)
+    x = torch.randn(3, 3, 256, 128, generator=g)
+    x1, x2 = m(x, False)
+    gap = x1.cpu().double()
+    ref = gap @ sd["feat.weight"].double().t()
+    ref = (ref - sd["feat_bn.running_mean"].double()) / torch.sqrt(sd["feat_bn.running_var"].double() + 1e-5) * sd["feat_bn.weight"].double() + sd["feat_bn.bias"].double()
+    ref = torch.relu(ref)
+    assert x2.shape == (3, 2048)
+    assert (x2.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())     # fp32 GEMM over K=2048
