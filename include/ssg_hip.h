@@ -143,6 +143,21 @@ int ssg_gap_stripes(const float* in, float* out, int B, int H, int W, int C, int
 /* out = (a+b)/||a+b||_2 per row (evaluators.py:31-35: original + flipped features, L2 norm) */
 int ssg_flip_sum_l2norm(const float* a, const float* b, float* out, int rows, int C, ssg_stream_t stream);
 
+/* ---- float32 re-ranking variant "re_ranking_init" (reid/rerank.py:171-234 == reid/rerank_initial.py:40-99) */
+/* out[i,j] = 2 - 2<x_i,y_j> (rerank.py:174-182); d % 32 == 0, n % 64 == 0; zeros = n floats of 0 */
+int ssg_cosine_dist_f32(const float* x, const float* y, int m, int n, int d, const float* zeros, float* out, ssg_stream_t stream);
+int ssg_affine_2m2x_f32(const float* in, float* out, int64_t n, ssg_stream_t stream); /* out = 2 - 2*in (rerank_initial.py:50) */
+/* D [N,N] symmetric float32: row max, top-(k1+1) ranking, k-reciprocal encoding -> sparse V (rerank.py:183-204) */
+int ssg_rerank_init_stage1(const float* D, int N, int k1, int k2, int capV, float* rowmax, int32_t* rank, int32_t* v_idx, float* v_val,
+                           int32_t* v_nnz, ssg_stream_t stream);
+/* query expansion V_qe (rerank.py:207-212); max_nnz = max(v_nnz), capQ >= k2*max_nnz */
+int ssg_rerank_init_expand(const int32_t* v_idx, const float* v_val, const int32_t* v_nnz, const int32_t* rank, int N, int k1, int k2, int capV,
+                           int capQ, int max_nnz, int32_t* q_idx, float* q_val, int32_t* q_nnz, ssg_stream_t stream);
+/* inverted index + Jaccard + blend for the nq query rows -> out [nq, N-nq] (rerank.py:214-233) */
+int ssg_rerank_init_jaccard(const float* D, const float* rowmax, const int32_t* q_idx, const float* q_val, const int32_t* q_nnz, int capQ, int N,
+                            int nq, float lambda_value, int32_t* colcnt, int64_t* colptr, int32_t* inv_row, float* inv_val, float* out,
+                            ssg_stream_t stream);
+
 /* ---- device self-tests used by the parity suite ----------------------------------------- */
 int ssg_selftest_half_table(int which, uint16_t* out65536, ssg_stream_t stream);
 int ssg_selftest_half_binop(int which, const uint16_t* a, const uint16_t* b, int n, uint16_t* out, ssg_stream_t stream);

@@ -497,6 +497,103 @@ int ora_re_ranking(const float* src, const float* tgt, int Ns, int N, int d, int
   return (mx & 0x7fff) == 0;
 }
 
+/* ------------------------------------------------------------------ reid/rerank.py:171-234 ==
+ * reid/rerank_initial.py:40-99  re_ranking_init (float32 cosine variant, caller reid/eug.py:223-226).
+ * dots [N,N] float32 = the stacked [[q_q, q_g],[q_g^T, g_g]] dot products (np.dot in the reference; the
+ * caller of this oracle provides them so that BLAS summation order is not part of the restatement).
+ * out [nq, N-nq] float32.  np.exp(float32) is libm-class accurate here (numpy's SIMD exp differs in the
+ * last ulp): parity for this variant is tolerance based. */
+static int cmp_pair_f(const void* a, const void* b) {
+  const float x = ((const float*)a)[0], y = ((const float*)b)[0];
+  if (x < y) return -1; if (x > y) return 1;
+  const float i = ((const float*)a)[1], j = ((const float*)b)[1];
+  return (i > j) - (i < j);
+}
+void ora_re_ranking_init(const float* dots, int N, int nq, int k1, int k2, float lambda_value, float* out) {
+  const size_t nn = (size_t)N * N;
+  float* od = (float*)malloc(nn * 4);            /* original_dist = 2 - 2*dots, then transpose(od / max(od, axis=0)) */
+  float* Dn = (float*)malloc(nn * 4);
+  for (size_t x = 0; x < nn; x++) od[x] = 2.f - 2.f * dots[x];
+  float* colmax = (float*)malloc((size_t)N * 4);
+  for (int j = 0; j < N; j++) { float m = od[j]; for (int i = 1; i < N; i++) if (od[(size_t)i * N + j] > m) m = od[(size_t)i * N + j]; colmax[j] = m; }
+  for (int a = 0; a < N; a++) for (int b = 0; b < N; b++) Dn[(size_t)a * N + b] = 1.f * od[(size_t)b * N + a] / colmax[a];
+  int K = k1 + 1; if (K > N) K = N;
+  int kh = (int)rint((double)k1 / 2.0) + 1; if (kh > K) kh = K;
+  int32_t* rank = (int32_t*)malloc((size_t)N * K * 4);
+#pragma omp parallel
+  {
+    float* pr = (float*)malloc((size_t)N * 8);
+#pragma omp for schedule(dynamic, 16)
+    for (int a = 0; a < N; a++) {              /* argpartition(range(1,k1+1)): k1+1 smallest ascending */
+      for (int b = 0; b < N; b++) { pr[2 * b] = Dn[(size_t)a * N + b]; pr[2 * b + 1] = (float)b; }
+      qsort(pr, N, 8, cmp_pair_f);
+      for (int r = 0; r < K; r++) rank[(size_t)a * K + r] = (int32_t)pr[2 * r + 1];
+    }
+    free(pr);
+  }
+  float* V = (float*)calloc(nn, 4);
+#pragma omp parallel
+  {
+    int cap = K + K * kh + 8;
+    int32_t* rec = (int32_t*)malloc(4 * (K + 1)); int32_t* crec = (int32_t*)malloc(4 * (kh + 1)); int32_t* expn = (int32_t*)malloc(4 * cap);
+    float* w = (float*)malloc(4 * cap);
+#pragma omp for schedule(dynamic, 32)
+    for (int i = 0; i < N; i++) {
+      const int32_t* fwd = rank + (size_t)i * K; int nrec = 0;
+      for (int a = 0; a < K; a++) { const int32_t* bw = rank + (size_t)fwd[a] * K; int hit = 0; for (int b = 0; b < K; b++) if (bw[b] == i) { hit = 1; break; } if (hit) rec[nrec++] = fwd[a]; }
+      int ne = 0; for (int a = 0; a < nrec; a++) expn[ne++] = rec[a];
+      for (int a = 0; a < nrec; a++) {
+        int32_t cand = rec[a]; const int32_t* cf = rank + (size_t)cand * K; int nc = 0;
+        for (int b = 0; b < kh; b++) { const int32_t* cb = rank + (size_t)cf[b] * K; int hit = 0; for (int c = 0; c < kh; c++) if (cb[c] == cand) { hit = 1; break; } if (hit) crec[nc++] = cf[b]; }
+        int inter = 0; for (int b = 0; b < nc; b++) for (int c = 0; c < nrec; c++) if (crec[b] == rec[c]) { inter++; break; }
+        if ((double)inter > (2.0 / 3.0) * (double)nc) for (int b = 0; b < nc; b++) expn[ne++] = crec[b];
+      }
+      qsort(expn, ne, 4, cmp_i32);
+      int nu = 0; for (int a = 0; a < ne; a++) if (nu == 0 || expn[a] != expn[nu - 1]) expn[nu++] = expn[a];
+      for (int a = 0; a < nu; a++) w[a] = expf(-Dn[(size_t)i * N + expn[a]]);
+      const float sum = pairwise_sum_f32(w, nu);
+      for (int a = 0; a < nu; a++) V[(size_t)i * N + expn[a]] = 1.f * w[a] / sum;
+    }
+    free(rec); free(crec); free(expn); free(w);
+  }
+  float* Vq = V;
+  if (k2 != 1) {
+    int kk = k2; if (kk > K) kk = K;
+    Vq = (float*)malloc(nn * 4);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < N; i++) {
+      const int32_t* r = rank + (size_t)i * K;
+      for (int j = 0; j < N; j++) { float s = V[(size_t)r[0] * N + j]; for (int q = 1; q < kk; q++) s += V[(size_t)r[q] * N + j]; Vq[(size_t)i * N + j] = s / (float)kk; }
+    }
+  }
+  int64_t* colptr = (int64_t*)calloc((size_t)N + 1, 8);
+  for (int r = 0; r < N; r++) for (int c = 0; c < N; c++) if (Vq[(size_t)r * N + c] != 0.f) colptr[c + 1]++;
+  for (int c = 0; c < N; c++) colptr[c + 1] += colptr[c];
+  int32_t* rows = (int32_t*)malloc((size_t)(colptr[N] ? colptr[N] : 1) * 4);
+  int64_t* fill = (int64_t*)malloc((size_t)N * 8); memcpy(fill, colptr, (size_t)N * 8);
+  for (int r = 0; r < N; r++) for (int c = 0; c < N; c++) if (Vq[(size_t)r * N + c] != 0.f) rows[fill[c]++] = r;
+  const int ng = N - nq;
+#pragma omp parallel
+  {
+    float* t = (float*)malloc((size_t)N * 4);
+#pragma omp for schedule(dynamic, 8)
+    for (int i = 0; i < nq; i++) {
+      memset(t, 0, (size_t)N * 4);
+      for (int c = 0; c < N; c++) {
+        const float vic = Vq[(size_t)i * N + c]; if (vic == 0.f) continue;
+        for (int64_t p = colptr[c]; p < colptr[c + 1]; p++) { const int r = rows[p]; const float vr = Vq[(size_t)r * N + c]; t[r] = t[r] + (vr < vic ? vr : vic); }
+      }
+      for (int g = 0; g < ng; g++) {
+        const float j = 1.f - t[nq + g] / (2.f - t[nq + g]);
+        out[(size_t)i * ng + g] = j * (1.f - lambda_value) + Dn[(size_t)i * N + nq + g] * lambda_value;
+      }
+    }
+    free(t);
+  }
+  if (Vq != V) free(Vq);
+  free(V); free(rank); free(colmax); free(Dn); free(od); free(colptr); free(rows); free(fill);
+}
+
 int ora_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -188,3 +188,20 @@ def generate_selflabel(e_dist, r_dist, n_iter, rho, no_rerank, eps_list=None):
             eps_list.append(eps)
         labels_list.append(dbscan(tmp, eps_list[s], 4))
     return labels_list, eps_list
+
+
+def re_ranking_init(query_feature, gallery_feature, k1=20, k2=6, lambda_value=0.3):
+    """reid/rerank.py:171-234 (float32 cosine variant).  The dot products are taken with numpy
+    (float32 BLAS, like the reference); everything after that is the C restatement."""
+    q = _c(query_feature, np.float32); g = _c(gallery_feature, np.float32)
+    qg = np.dot(q, g.T); qq = np.dot(q, q.T); gg = np.dot(g, g.T)
+    return re_ranking_init_dist(qg, qq, gg, k1, k2, lambda_value)
+
+
+def re_ranking_init_dist(q_g_dist, q_q_dist, g_g_dist, k1=20, k2=6, lambda_value=0.3):
+    """reid/rerank_initial.py:40-99 (takes the three dot-product matrices)."""
+    dots = _c(np.concatenate([np.concatenate([q_q_dist, q_g_dist], axis=1), np.concatenate([q_g_dist.T, g_g_dist], axis=1)], axis=0), np.float32)
+    N, nq = dots.shape[0], q_g_dist.shape[0]
+    out = np.empty((nq, N - nq), np.float32)
+    lib().ora_re_ranking_init(_p(dots, _f32p), N, nq, int(k1), int(k2), ctypes.c_float(lambda_value), _p(out, _f32p))
+    return out

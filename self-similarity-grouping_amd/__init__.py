@@ -12,7 +12,7 @@ __all__ = ["re_ranking", "re_ranking_device", "DBSCAN", "eps_rule", "compute_dis
 
 
 def __getattr__(name):   # lazy: torch import only when the compute surface is touched
-    if name in ("re_ranking", "re_ranking_device", "DistHandle", "ReRankNaNError"):
+    if name in ("re_ranking", "re_ranking_device", "re_ranking_init", "re_ranking_init_dist", "DistHandle", "ReRankNaNError"):
         from . import rerank
         return getattr(rerank, name)
     if name in ("DBSCAN", "eps_rule", "as_handle"):

@@ -245,7 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
         const int col = tn * BN + wn * WN + j * 32 + 8 * q + 4 * h;
         const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
         float4 v = make_float4(acc[i][j][4 * q] + bias.x, acc[i][j][4 * q + 1] + bias.y, acc[i][j][4 * q + 2] + bias.z, acc[i][j][4 * q + 3] + bias.w);
-        if (p.epi == 1) {
+        if (p.epi == 2) {       // cosine form 2 - 2<x,y> (reid/rerank.py:182)
+          v = make_float4(2.f - 2.f * acc[i][j][4 * q], 2.f - 2.f * acc[i][j][4 * q + 1], 2.f - 2.f * acc[i][j][4 * q + 2], 2.f - 2.f * acc[i][j][4 * q + 3]);
+        } else if (p.epi == 1) {
           const float rt = p.rowterm[m < p.M ? m : 0];
           v = make_float4((rt + bias.x) - 2.f * acc[i][j][4 * q], (rt + bias.y) - 2.f * acc[i][j][4 * q + 1], (rt + bias.z) - 2.f * acc[i][j][4 * q + 2],
                           (rt + bias.w) - 2.f * acc[i][j][4 * q + 3]);
@@ -432,6 +434,21 @@ extern "C" int ssg_pairwise_sqdist_f32(const float* x, const float* y, int m, in
   p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
   p.M = m; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
   p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 1;
+  return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
+}
+
+// out[i,j] = 2 - 2 <x_i, y_j> in float32 (reid/rerank.py:174-182 original_dist of re_ranking_init).
+// x [m,d], y [n,d], out [m,n]; d % 32 == 0, n % 64 == 0 (pad).  zeros [n] floats (bias slot).
+extern "C" int ssg_cosine_dist_f32(const float* x, const float* y, int m, int n, int d, const float* zeros, float* out, hipStream_t stream) {
+  if (m <= 0 || n <= 0 || (d % 32) || (n % 64) || (int64_t)m * d * 4 > 0x7fffffffLL) {
+    ssg_set_error("ssg_cosine_dist_f32: need d %% 32 == 0, n %% 64 == 0 and x < 2 GiB (m=%d n=%d d=%d)", m, n, d);
+    return SSG_ERR_INVALID;
+  }
+  ConvParams p;
+  p.in = x; p.w = y; p.bias = zeros; p.res = nullptr; p.out = out;
+  p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
+  p.M = m; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 2;
   return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 

@@ -7,3 +7,4 @@
 #include "jaccard.hip"
 #include "cluster.hip"
 #include "conv.hip"
+#include "rerank_init.hip"

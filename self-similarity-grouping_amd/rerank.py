@@ -206,3 +206,63 @@ def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.
     final = h.final_dist().cpu().numpy().view(DeviceBackedArray)
     final.ssg_handle = h
     return euclid, final
+
+
+def _init_pipeline(D, nq, k1, k2, lambda_value):
+    """sparse stages of re_ranking_init on a float32 distance matrix D [N,N] (device)."""
+    L = _lib.lib()
+    dev, st = D.device, stream()
+    N = D.shape[0]
+    K = min(k1 + 1, N)
+    capV = int(L.ssg_krecip_row_capacity(k1))
+    rowmax = torch.empty(N, dtype=torch.float32, device=dev)
+    rank = torch.empty((N, K), dtype=torch.int32, device=dev)
+    v_idx = torch.empty((N, capV), dtype=torch.int32, device=dev); v_val = torch.empty((N, capV), dtype=torch.float32, device=dev)
+    v_nnz = torch.empty(N, dtype=torch.int32, device=dev)
+    check(L.ssg_rerank_init_stage1(ptr(D), N, k1, k2, capV, ptr(rowmax), ptr(rank), ptr(v_idx), ptr(v_val), ptr(v_nnz), st), "ssg_rerank_init_stage1")
+    if k2 != 1:
+        kk = min(k2, N, K)
+        mx = max(int(v_nnz.max().item()), 1)
+        capQ = kk * mx
+        q_idx = torch.empty((N, capQ), dtype=torch.int32, device=dev); q_val = torch.empty((N, capQ), dtype=torch.float32, device=dev)
+        q_nnz = torch.empty(N, dtype=torch.int32, device=dev)
+        check(L.ssg_rerank_init_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, k1, k2, capV, capQ, mx, ptr(q_idx), ptr(q_val), ptr(q_nnz), st),
+              "ssg_rerank_init_expand")
+    else:
+        capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
+    total = max(int(q_nnz.sum().item()), 1)
+    colcnt = torch.empty(N, dtype=torch.int32, device=dev); colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    inv_row = torch.empty(total, dtype=torch.int32, device=dev); inv_val = torch.empty(total, dtype=torch.float32, device=dev)
+    out = torch.empty((nq, N - nq), dtype=torch.float32, device=dev)
+    check(L.ssg_rerank_init_jaccard(ptr(D), ptr(rowmax), ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, N, nq, float(lambda_value), ptr(colcnt), ptr(colptr),
+                                    ptr(inv_row), ptr(inv_val), ptr(out), st), "ssg_rerank_init_jaccard")
+    return out
+
+
+def re_ranking_init(query_feature, gallery_feature, k1=20, k2=6, lambda_value=0.3, device=None):
+    """Drop-in for reid/rerank.py:171 re_ranking_init (float32 cosine variant; numpy in, numpy
+    [num_query, num_gallery] float32 out).  The stacked Gram matrix 2 - 2 x.y runs on the fp32-MFMA GEMM."""
+    L = _lib.lib()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    q = torch.as_tensor(np.asarray(query_feature, dtype=np.float32)); g = torch.as_tensor(np.asarray(gallery_feature, dtype=np.float32))
+    nq, N = q.shape[0], q.shape[0] + g.shape[0]
+    x = _as_dev_f32(torch.cat([q, g], 0), device)
+    npad = (-N) % 64
+    y = torch.nn.functional.pad(x, (0, 0, 0, npad)) if npad else x
+    zeros = torch.zeros(N + npad, dtype=torch.float32, device=device)
+    Dp = torch.empty((N, N + npad), dtype=torch.float32, device=device)
+    check(L.ssg_cosine_dist_f32(ptr(x), ptr(y), N, N + npad, x.shape[1], ptr(zeros), ptr(Dp), stream()), "ssg_cosine_dist_f32")
+    D = Dp[:, :N].contiguous() if npad else Dp
+    return _init_pipeline(D, nq, k1, k2, lambda_value).cpu().numpy()
+
+
+def re_ranking_init_dist(q_g_dist, q_q_dist, g_g_dist, k1=20, k2=6, lambda_value=0.3, device=None):
+    """Drop-in for reid/rerank_initial.py:40 re_ranking_init (takes the dot-product matrices)."""
+    L = _lib.lib()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    qg = torch.as_tensor(np.asarray(q_g_dist, dtype=np.float32)); qq = torch.as_tensor(np.asarray(q_q_dist, dtype=np.float32))
+    gg = torch.as_tensor(np.asarray(g_g_dist, dtype=np.float32))
+    dots = torch.cat([torch.cat([qq, qg], 1), torch.cat([qg.t(), gg], 1)], 0).to(device).contiguous()
+    D = torch.empty_like(dots)
+    check(L.ssg_affine_2m2x_f32(ptr(dots), ptr(D), dots.numel(), stream()), "ssg_affine_2m2x_f32")
+    return _init_pipeline(D, qg.shape[0], k1, k2, lambda_value).cpu().numpy()

@@ -419,3 +419,24 @@ def test_x2_branch_matches_torch(dev):
     ref = torch.relu(ref)
     assert x2.shape == (3, 2048)
     assert (x2.cpu().double() - ref).abs().max() < 2e-5 * max(1.0, ref.abs().max().item())     # fp32 GEMM over K=2048
+
+
+def test_re_ranking_init_vs_reference_golden(golden, dev, ora):
+    """float32 cosine variant (reid/rerank.py:171-234, rerank_initial.py:40-99) vs the reference's own
+    output; tolerance 2e-5 (fp32 GEMM / exp are not bit reproducible across BLAS and libm)."""
+    import ssg_amd
+    g = golden("rerank_init.npz")
+    for tag in ("a", "b"):
+        q, gal = g["q_" + tag], g["g_" + tag]
+        k1, k2, lam = int(g["k1_" + tag]), int(g["k2_" + tag]), float(g["lam_" + tag])
+        out = ssg_amd.re_ranking_init(q, gal, k1=k1, k2=k2, lambda_value=lam)
+        ref = g["final_" + tag]
+        assert out.shape == ref.shape and out.dtype == np.float32
+        assert np.abs(out - ref).max() < 2e-5, np.abs(out - ref).max()
+        out2 = ssg_amd.re_ranking_init_dist(np.dot(q, gal.T), np.dot(q, q.T), np.dot(gal, gal.T), k1=k1, k2=k2, lambda_value=lam)
+        assert np.abs(out2 - ref).max() < 2e-5
+    # a larger ragged case against the oracle
+    x = clustered(1000 + 333, 72, 9)
+    out = ssg_amd.re_ranking_init(x[:333], x[333:], k1=20, k2=6, lambda_value=0.3)
+    ref = ora.re_ranking_init(x[:333], x[333:], k1=20, k2=6, lambda_value=0.3)
+    assert out.shape == (333, 1000) and np.abs(out - ref).max() < 2e-5

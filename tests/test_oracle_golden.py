@@ -14,7 +14,7 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_*.npz")))
+RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_n*.npz")))
 
 
 @pytest.mark.parametrize("name", RERANK)
@@ -106,3 +106,14 @@ def test_edge_cases(ora):
     assert (lab == 0).all()
     lab = ora.dbscan(f, 1e-9, 4)
     assert (lab == -1).all()
+
+
+def test_re_ranking_init_oracle_vs_reference_golden(golden, ora):
+    """float32 cosine variant (rerank.py:171-234): tolerance based (np.dot / np.exp are not
+    reproducible bit for bit across BLAS builds)."""
+    g = golden("rerank_init.npz")
+    for tag in ("a", "b"):
+        out = ora.re_ranking_init(g["q_" + tag], g["g_" + tag], k1=int(g["k1_" + tag]), k2=int(g["k2_" + tag]), lambda_value=float(g["lam_" + tag]))
+        ref = g["final_" + tag]
+        assert out.shape == ref.shape and out.dtype == np.float32
+        assert np.abs(out - ref).max() < 5e-6

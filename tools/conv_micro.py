@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single conv configurations (development aid)."""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ssg_amd
+from ssg_amd import _lib
+from ssg_amd._lib import check, ptr, stream
+
+def run(B, H, W, Cin, Cout, k, stride, pad, res, reps=20):
+    L = _lib.lib(); dev = torch.device("cuda", 0)
+    x = torch.randn(B, H, W, Cin, device=dev); w = torch.randn(Cout, k * k * Cin, device=dev) * 0.02; b = torch.randn(Cout, device=dev)
+    OH = (H + 2 * pad - k) // stride + 1; OW = (W + 2 * pad - k) // stride + 1
+    out = torch.empty(B, OH, OW, Cout, device=dev); r = torch.randn_like(out) if res else None
+    f = lambda: check(L.ssg_conv2d_nhwc_f32(ptr(x), ptr(w), ptr(b), ptr(r), ptr(out), B, H, W, Cin, Cout, k, k, stride, pad, 1, stream()), "conv")
+    f(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * B * OH * OW * Cout * k * k * Cin
+    print("B=%d %dx%d cin=%d cout=%d k=%d s=%d res=%d: %.3f ms %.1f TF/s" % (B, H, W, Cin, Cout, k, stride, int(res), ms, fl / ms / 1e9))
+
+if __name__ == "__main__":
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+    if cfg == "c3": run(512, 16, 8, 256, 256, 3, 1, 1, False, 40)
+    elif cfg == "c1": run(512, 16, 8, 1024, 256, 1, 1, 0, False, 40)
+    elif cfg == "e1": run(512, 64, 32, 64, 256, 1, 1, 0, True, 40)

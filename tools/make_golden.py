@@ -178,6 +178,26 @@ def embed_fixture():
     return ok
 
 
+def init_fixture(mod):
+    """re_ranking_init (float32 cosine variant, rerank.py:171-234 / rerank_initial.py:40-99)."""
+    spec = importlib.util.spec_from_file_location("ref_init", os.path.join(REF, "reid", "rerank_initial.py"))
+    m2 = importlib.util.module_from_spec(spec); spec.loader.exec_module(m2)
+    ok = True
+    rec = {}
+    for tag, nq, ng, d, seed, lam, k1, k2 in (("a", 64, 192, 64, 31, 0.3, 20, 6), ("b", 48, 300, 96, 32, 0.1, 10, 4)):
+        x = clustered(nq + ng, d, seed)
+        q, g = x[:nq], x[nq:]
+        ref = mod.re_ranking_init(q, g, k1=k1, k2=k2, lambda_value=lam)
+        ref2 = m2.re_ranking_init(np.dot(q, g.T), np.dot(q, q.T), np.dot(g, g.T), k1=k1, k2=k2, lambda_value=lam)
+        mine = ora.re_ranking_init(q, g, k1=k1, k2=k2, lambda_value=lam)
+        err = float(np.abs(mine - ref).max())
+        print("re_ranking_init %s: both reference copies identical: %s; oracle max|diff| = %.2e" % (tag, np.array_equal(ref, ref2), err))
+        ok = ok and np.array_equal(ref, ref2) and err < 2e-6
+        rec.update({"q_" + tag: q, "g_" + tag: g, "final_" + tag: ref, "k1_" + tag: k1, "k2_" + tag: k2, "lam_" + tag: lam})
+    np.savez_compressed(os.path.join(OUT, "rerank_init.npz"), **rec)
+    return ok
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ora.build(force=True)
@@ -286,6 +306,7 @@ def main():
         mats.append(D); epss.append(eps); labs.append(lab.astype(np.int64))
     np.savez_compressed(os.path.join(OUT, "dbscan_cases.npz"), D=np.stack(mats), eps=np.array(epss), labels=np.stack(labs))
 
+    ok = init_fixture(mod) and ok
     ok = embed_fixture() and ok
     print("ALL OK" if ok else "ORACLE MISMATCH")
     sys.exit(0 if ok else 1)
