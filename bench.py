@@ -221,6 +221,12 @@ def main():
             tf = flop * n / (ms * 1e-3) / 1e12
             hbm.append({"kernel": k, "bound": "mfma", "what": "fp64 Gram (v_mfma_f64_16x16x4); executed flops (self term: upper-triangle tiles only on 1 GPU)", "launches": n, "avg_launch_ms": round(ms / n, 4),
                         "achieved": round(tf, 2), "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_MFMA_TF, 4)})
+    if "ssg_source_rowmin_filtered" in tot:
+        n, ms = tot["ssg_source_rowmin_filtered"]
+        tf = 2.0 * nrows * args.Ns * 2048 * n / (ms * 1e-3) / 1e12
+        hbm.append({"kernel": "ssg_source_rowmin_filtered", "bound": "mfma", "what": "source term by filter-and-refine: fp32-MFMA bound pass (2*N*Ns*d flop) + fp64 "
+                    "re-evaluation of candidate tiles; time covers both", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
+                    "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TF, 4)})
     hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
                                     "ssg_eps_compact", "ssg_sort_u64", "ssg_eps_mean", "ssg_region_query", "ssg_dbscan_cc") if k in tot) / args.steps
     k5_12 = 8.0 * nrows * args.N / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else float("nan")

@@ -35,6 +35,9 @@ struct ConvParams {
   const float* in2; int H2, W2, Cin2, stride2, nk1; unsigned in2_bytes;
   // epilogue mode 1 (pairwise distance, reid/evaluators.py:63-85): out = rowterm[m] + bias[col] - 2*acc
   const float* rowterm; int epi;
+  // epilogue mode 3 (distance filter): no matrix store; per output row the minimum of rowterm+bias-2*acc over each
+  // 64-column wave tile goes to tilemin[m * tmin_ld + tile]
+  float* tilemin; int tmin_ld;
 };
 
 constexpr int CLD32 = 36;   // LDS row pitch in floats for BK=32 (BK=16 uses 20): pitch/4 odd -> conflict-free b128
@@ -218,6 +221,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #undef SSG_LSTORE
   // epilogue.  D = W * A^T: C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   // -> channel; accumulator quad q holds channels 8q + 4h + {0,1,2,3} of one pixel.
+  if (p.epi == 3) {
+    // distance filter epilogue: min over this wave's WN columns of every row (lane = row, registers = columns)
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int m = tm * BM + wm * WM + i * 32 + l32;
+      const float rt = p.rowterm[m < p.M ? m : 0];
+      float mn = INFINITY;
+#pragma unroll
+      for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 bias = *reinterpret_cast<const float4*>(p.bias + tn * BN + wn * WN + j * 32 + 8 * q + 4 * h);
+          mn = fminf(mn, fminf(fminf((rt + bias.x) - 2.f * acc[i][j][4 * q], (rt + bias.y) - 2.f * acc[i][j][4 * q + 1]),
+                               fminf((rt + bias.z) - 2.f * acc[i][j][4 * q + 2], (rt + bias.w) - 2.f * acc[i][j][4 * q + 3])));
+        }
+      mn = fminf(mn, __shfl_xor(mn, 32, 64));
+      if (h == 0 && m < p.M) p.tilemin[(int64_t)m * p.tmin_ld + tn * WCOLS + wn] = mn;
+    }
+    return;
+  }
   // All residual loads are issued first (one round trip), then bias/add/ReLU/stores: the stores
   // may alias the residual as far as the compiler knows, so an interleaved loop would serialise
   // 16 load->use->store round trips per wave.
@@ -370,7 +393,7 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
   const int64_t in_bytes = (int64_t)B * H * W * Cin * 4;
   if (in_bytes > 0x7fffffffLL) { ssg_set_error("ssg_conv2d_nhwc_f32: input tensor of %lld bytes exceeds the 2 GiB buffer-resource range of this kernel; use a smaller batch", (long long)in_bytes); return SSG_ERR_INVALID; }
   p.in_bytes = (unsigned)in_bytes;
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 0;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 0; p.tilemin = nullptr; p.tmin_ld = 0;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("SSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
   p.variant = variant;
@@ -400,7 +423,7 @@ extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, cons
   }
   p.M = (int)M; p.in_bytes = (unsigned)in_bytes;
   p.in2 = in2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.in2_bytes = (unsigned)in2_bytes;
-  p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0;   // dual input stays on BK=32 (nk1 counts 32-wide tiles)
+  p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0; p.tilemin = nullptr; p.tmin_ld = 0;   // dual input stays on BK=32 (nk1 counts 32-wide tiles)
   return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
@@ -433,7 +456,7 @@ extern "C" int ssg_pairwise_sqdist_f32(const float* x, const float* y, int m, in
   p.in = x; p.w = y; p.bias = colterm; p.res = nullptr; p.out = out;
   p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
   p.M = m; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 1;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 1; p.tilemin = nullptr; p.tmin_ld = 0;
   return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
@@ -448,8 +471,74 @@ extern "C" int ssg_cosine_dist_f32(const float* x, const float* y, int m, int n,
   p.in = x; p.w = y; p.bias = zeros; p.res = nullptr; p.out = out;
   p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
   p.M = m; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 2;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 2; p.tilemin = nullptr; p.tmin_ld = 0;
   return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
+}
+
+namespace ssg {
+// Exact refinement of the source-term minimum: one wave per target row.  Tiles (64 sources) whose float32
+// lower-bounded minimum can still beat the row's best are re-evaluated in float64 with the difference form
+// sum_k (x_k - y_k)^2 (like cdist), then half(sqrt(s)^2) as in reid/rerank.py:36-37.
+__global__ __launch_bounds__(256) void source_refine_kernel(const float* __restrict__ tgt, const float* __restrict__ src, const float* __restrict__ tilemin,
+                                                            int ld, int ntiles, float tol, int nrows, int Ns, int d, unsigned* __restrict__ rowmin) {
+  const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (row >= nrows) return;
+  const int lane = lane_id();
+  float gmin = INFINITY;
+  for (int t = lane; t < ntiles; t += 64) gmin = fminf(gmin, tilemin[(int64_t)row * ld + t]);
+  for (int sh = 1; sh < 64; sh <<= 1) gmin = fminf(gmin, __shfl_xor(gmin, sh, 64));
+  const float bound = gmin + tol;
+  const float* x = tgt + (int64_t)row * d;
+  unsigned best = 0xffffffffu;
+  for (int t0 = 0; t0 < ntiles; t0 += 64) {
+    const int t = t0 + lane;
+    uint64_t cand = __ballot(t < ntiles && tilemin[(int64_t)row * ld + t] <= bound);
+    while (cand) {
+      const int tt = t0 + __ffsll((long long)cand) - 1;
+      cand &= cand - 1;
+      const int s1 = (tt + 1) * 64 < Ns ? (tt + 1) * 64 : Ns;
+      for (int s = tt * 64; s < s1; s++) {
+        const float* y = src + (int64_t)s * d;
+        double acc = 0.0;
+        for (int k = lane; k < d; k += 64) { const double df = (double)x[k] - (double)y[k]; acc += df * df; }
+        for (int sh = 1; sh < 64; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
+        const double dist = sqrt(acc);
+        const unsigned hb = d2h(dist * dist);     // np.power(cdist, 2).astype(float16)
+        best = best < hb ? best : hb;
+      }
+    }
+  }
+  if (lane == 0) rowmin[row] = best;
+}
+}  // namespace ssg
+
+// Source-term row minimum (reid/rerank.py:36-37,39) by filter-and-refine: a float32 MFMA pass bounds every
+// target-source distance (per row and 64-source tile), a float64 pass re-evaluates only the tiles within `tol`
+// of the row's bound.  Same result as ssg_source_rowmin_f16 (exact min of the half-rounded float64 distances)
+// whenever tol >= the float32 error of the bound (callers pass 8*d*2^-24*max|x|*max|y| + margin).
+// tgt [nrows,d], src [Ns_pad,d] (rows >= Ns are padding), d % 32 == 0, Ns_pad % 128 == 0.
+// ws: nrows + Ns_pad + nrows*(Ns_pad/64) floats.
+extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float* ws,
+                                          uint32_t* rowmin, hipStream_t stream) {
+  if (nrows <= 0 || Ns <= 0 || Ns_pad < Ns || (Ns_pad % 128) || (d % 32) || (int64_t)nrows * d * 4 > 0x7fffffffLL) {
+    ssg_set_error("ssg_source_rowmin_filtered: bad shape nrows=%d Ns=%d Ns_pad=%d d=%d", nrows, Ns, Ns_pad, d);
+    return SSG_ERR_INVALID;
+  }
+  float* rowterm = ws; float* colterm = ws + nrows; float* tilemin = colterm + Ns_pad;
+  const int ntiles = Ns_pad / 64;
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
+  if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
+  ConvParams p;
+  p.in = tgt; p.w = src; p.bias = colterm; p.res = nullptr; p.out = nullptr;
+  p.B = nrows; p.H = 1; p.W = 1; p.Cin = d; p.Cout = Ns_pad; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
+  p.M = nrows; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)nrows * d * 4);
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles;
+  int rc = launch_conv<128, 128, 64, 64, false>(p, stream);   // wave tile = 64 columns = one tilemin entry
+  if (rc) return rc;
+  hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
+  SSG_LAUNCH_CHECK("source_refine_kernel");
+  return SSG_OK;
 }
 
 extern "C" int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, hipStream_t stream) {

@@ -74,18 +74,41 @@ def _as_dev_f32(x, device):
     return x
 
 
-def source_vector(src, tgt, row0=0, nrows=None):
-    """reid/rerank.py:35-40 on device -> (rowmin uint32-as-int32 [nrows]) for a row block."""
+def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
+    """reid/rerank.py:35-40 on device -> (rowmin uint32-as-int32 [nrows]) for a row block.
+
+    Default: filter-and-refine (float32 MFMA bound per 64-source tile, float64 re-evaluation of the
+    tiles that can still hold the minimum) -- the exact minimum of the half-rounded float64 distances
+    at about half the cost of the full float64 Gram.  exact_gemm=True (or SSG_SOURCE_EXACT_GEMM=1)
+    forces the full fp64-MFMA pass."""
+    import os
     L = _lib.lib()
     N, d = tgt.shape
     nrows = N if nrows is None else nrows
-    ntgt = torch.empty(N, dtype=torch.float64, device=tgt.device)
-    nsrc = torch.empty(src.shape[0], dtype=torch.float64, device=tgt.device)
-    check(L.ssg_row_norms_f64(ptr(tgt), N, d, 0, ptr(ntgt), stream()), "ssg_row_norms_f64")
-    check(L.ssg_row_norms_f64(ptr(src), src.shape[0], d, 0, ptr(nsrc), stream()), "ssg_row_norms_f64")
+    if exact_gemm is None:
+        exact_gemm = os.environ.get("SSG_SOURCE_EXACT_GEMM", "0") == "1"
     rowmin = torch.empty(nrows, dtype=torch.int32, device=tgt.device)
     tblk = tgt[row0:row0 + nrows]
-    check(L.ssg_source_rowmin_f16(ptr(tblk), ptr(ntgt[row0:]), ptr(src), ptr(nsrc), nrows, src.shape[0], d, ptr(rowmin), stream()),
+    Ns = src.shape[0]
+    if not exact_gemm and (nrows * d * 4) < 2 ** 31:
+        npad = (-Ns) % 128
+        srcp = torch.nn.functional.pad(src, (0, 0, 0, npad)) if npad else src
+        # rigorous float32 error bound of |x|^2 + |y|^2 - 2<x,y>: the MFMA dot is a d-term fmaf chain
+        # (|err| <= gamma_d * sum|x_k y_k| <= gamma_d |x||y|, gamma_d = d*u/(1-d*u), u = 2^-24); the squared
+        # norms come from a 32-term chain + 6-level tree (38 u relative); a few ulps for the final adds.
+        nx = float(tblk.norm(dim=1).max().item()); ny = float(src.norm(dim=1).max().item())
+        u = 2.0 ** -24
+        gam = d * u / (1.0 - d * u)
+        tol = 2.0 * (2.0 * gam * nx * ny + 40.0 * u * (nx * nx + ny * ny)) + 8.0 * u * (nx + ny) ** 2
+        ws = torch.empty(nrows + Ns + npad + nrows * ((Ns + npad) // 64), dtype=torch.float32, device=tgt.device)
+        check(L.ssg_source_rowmin_filtered(ptr(tblk), ptr(srcp), nrows, Ns, Ns + npad, d, tol, ptr(ws), ptr(rowmin), stream()),
+              "ssg_source_rowmin_filtered")
+        return rowmin
+    ntgt = torch.empty(N, dtype=torch.float64, device=tgt.device)
+    nsrc = torch.empty(Ns, dtype=torch.float64, device=tgt.device)
+    check(L.ssg_row_norms_f64(ptr(tgt), N, d, 0, ptr(ntgt), stream()), "ssg_row_norms_f64")
+    check(L.ssg_row_norms_f64(ptr(src), Ns, d, 0, ptr(nsrc), stream()), "ssg_row_norms_f64")
+    check(L.ssg_source_rowmin_f16(ptr(tblk), ptr(ntgt[row0:]), ptr(src), ptr(nsrc), nrows, Ns, d, ptr(rowmin), stream()),
           "ssg_source_rowmin_f16")
     return rowmin
 

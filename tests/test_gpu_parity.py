@@ -104,7 +104,9 @@ def test_pairwise_vs_oracle(N, Ns, d, dev, ora):
     ref = ora.euclid(tgt)
     assert np.array_equal(bits(D), bits(ref))
     assert np.array_equal(D, D.T) and np.all(np.diag(D) == 0) and D[7, 2] == 0
-    rowmin = rerank.source_vector(rerank._as_dev_f32(src, dev), rerank._as_dev_f32(tgt, dev))
+    rowmin = rerank.source_vector(rerank._as_dev_f32(src, dev), rerank._as_dev_f32(tgt, dev))                    # filter-and-refine
+    rowmin_full = rerank.source_vector(rerank._as_dev_f32(src, dev), rerank._as_dev_f32(tgt, dev), exact_gemm=True)   # full fp64 Gram
+    assert torch.equal(rowmin, rowmin_full)
     v_raw, v, mx = ora.source_vec(tgt, src)
     # rowmin holds half(d^2) bits; v_raw = 1-exp(-min) (monotone) -> compare through the finish kernel
     from ssg_amd._lib import check, ptr, stream, lib
