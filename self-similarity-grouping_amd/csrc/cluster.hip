@@ -281,6 +281,55 @@ __global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long
 // ------------------------------------------------------------------ K11 region query
 // cnt[il] = #{k : d(i,k) <= eps} (self included when d(i,i) <= eps);  edges (i,k) incl. self hits.
 struct Edge { int i, k; };
+
+// append the hit columns (bit e of hitmask -> column j0+e) of this wave to its LDS stage (out of line: rare)
+__device__ __forceinline__ int rq_append(WaveStage<Edge>& st, unsigned hitmask, int j0, int gi, Edge* eout, unsigned long long cap,
+                                                   unsigned long long* cursor) {
+  const int lane = lane_id();
+  const uint64_t lt = lanemask_lt();
+  int added = 0;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const bool h = (hitmask >> e) & 1u;
+    const uint64_t m = __ballot(h);
+    if (h) { Edge& x = st.buf[st.n + added + __popcll(m & lt)]; x.i = gi; x.k = j0 + e; }
+    added += __popcll(m);
+  }
+  st.n += added;
+  if (st.n > STAGE_CAP - 512) st.flush(eout, cap, cursor, lane);
+  return added;
+}
+
+// generic chunk (row edges, unaligned rows, plain matrices): exact value of every element
+template <int MODE>
+__device__ __forceinline__ unsigned rq_generic_chunk(const MatView& mv, const RowStream& rs, int c, int lane, int gi, double eps) {
+  double dv[8];
+  load_vals<MODE>(mv, rs, c, lane, gi, dv);
+  const int j0 = rs.col0(c, lane);
+  unsigned hitmask = 0;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const int k = j0 + e;
+    if (k >= 0 && k < mv.N && dv[e] <= eps) hitmask |= 1u << e;
+  }
+  return hitmask;
+}
+
+// exact decision for the elements flagged by the packed-half prefilter (mode 0)
+__device__ __forceinline__ unsigned rq_decide(const MatView& mv, unsigned flags, const uint4& xj, const uint4& xv, int gi, double eps) {
+  const unsigned wj[4] = {xj.x, xj.y, xj.z, xj.w}, wv[4] = {xv.x, xv.y, xv.z, xv.w};
+  const hbits vi = mv.v[gi];
+  unsigned hitmask = 0;
+  while (flags) {
+    const int e = __ffs((int)flags) - 1;
+    flags &= flags - 1;
+    const unsigned a = e < 2 ? wj[0] : e < 4 ? wj[1] : e < 6 ? wj[2] : wj[3], b = e < 2 ? wv[0] : e < 4 ? wv[1] : e < 6 ? wv[2] : wv[3];
+    const hbits jp = (hbits)((a >> ((e & 1) * 16)) & 0xffffu), vk = (hbits)((b >> ((e & 1) * 16)) & 0xffffu);
+    if (final_dist_value(jp, vi, vk, mv.lambda_value) <= eps) hitmask |= 1u << e;    // exact, rerank.py:122
+  }
+  return hitmask;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
                                                            unsigned long long cap, unsigned long long* __restrict__ cursor) {
@@ -288,31 +337,52 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
   const int lane = lane_id();
   WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
   Edge* eout = reinterpret_cast<Edge*>(edges);
+  // mode-0 prefilter in packed half math (2 elements per instruction): d16 = half(v_i+v_k)*half(lambda) + J' is
+  // within `band` of the exact float64 value, so only elements with d16 < eps + band can be hits; those (a
+  // handful per row) are decided exactly.  half(v_i + v_k) with the native half add equals numpy's
+  // float32-add-then-round for every pair of halves.
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const float bandf = 0.0078125f * (1.f + fabsf((float)eps) + fabsf((float)mv.lambda_value));   // >= 2^-9*lambda*|s| + 3*2^-11*|d| with margin
+  const _Float16 thr16 = (_Float16)((float)eps + bandf + 0.002f * (1.f + fabsf((float)eps)));   // margin also covers the rounding of the threshold itself
+  const h2 thr2 = {thr16, thr16};
+  const h2 lam2 = {(_Float16)(float)mv.lambda_value, (_Float16)(float)mv.lambda_value};
+  const bool fast_ok = MODE == 0 && (mv.N & 7) == 0 && (float)eps < 30000.f && fabsf((float)mv.lambda_value) < 16.f;
   for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
     const int gi = mv.row0 + il;
     RowStream rs(il, mv.N, mv.nrows);
     int rowcnt = 0;
-    for (int c = 0; c < rs.nchunks; c++) {
-      double dv[8];
-      load_vals<MODE>(mv, rs, c, lane, gi, dv);
-      const int j0 = rs.col0(c, lane);
-      unsigned hitmask = 0;
+    if (fast_ok) {
+      // N % 8 == 0: every row starts on a 16-byte boundary, all chunks are aligned; the last one may be partial
+      const hbits* M = reinterpret_cast<const hbits*>(mv.M) + (int64_t)il * mv.N;
+      const _Float16 vi16 = __builtin_bit_cast(_Float16, mv.v[gi]);
+      const h2 vi2 = {vi16, vi16};
+      const int nfull = mv.N / 512;
+      for (int c = 0; c < nfull; c++) {
+        const int j0 = c * 512 + lane * 8;
+        const uint4 xj = *reinterpret_cast<const uint4*>(M + j0);
+        const uint4 xv = *reinterpret_cast<const uint4*>(mv.v + j0);
+        const unsigned wj[4] = {xj.x, xj.y, xj.z, xj.w}, wv[4] = {xv.x, xv.y, xv.z, xv.w};
+        unsigned flags = 0;   // bit e set: element e may be <= eps
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int k = j0 + e;
-        if (k >= 0 && k < mv.N && dv[e] <= eps) hitmask |= 1u << e;
+        for (int q = 0; q < 4; q++) {
+          const h2 s2 = __builtin_bit_cast(h2, wv[q]) + vi2;
+          const h2 d2 = s2 * lam2 + __builtin_bit_cast(h2, wj[q]);
+          const unsigned sg = __builtin_bit_cast(unsigned, (h2)(d2 - thr2));     // sign bit set <=> d16 < thr (NaNs never hit)
+          flags |= ((sg >> 15) & 1u) << (2 * q) | ((sg >> 31) & 1u) << (2 * q + 1);
+        }
+        if (!__any(flags != 0)) continue;                         // the common case: one branch per KiB
+        const unsigned hitmask = rq_decide(mv, flags, xj, xv, gi, eps);
+        if (__any(hitmask != 0)) rowcnt += rq_append(st, hitmask, j0, gi, eout, cap, cursor);
       }
-      if (!__any(hitmask != 0)) continue;
-      const int n = __popc(hitmask);
-      int incl = n;
-      for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
-      const int tot = __shfl(incl, 63, 64);
-      rowcnt += tot;
-      int w = st.n + incl - n;
-#pragma unroll
-      for (int e = 0; e < 8; e++) if (hitmask & (1u << e)) { st.buf[w].i = gi; st.buf[w].k = j0 + e; w++; }
-      st.n += tot;
-      if (st.n > STAGE_CAP - 512) st.flush(eout, cap, cursor, lane);
+      if (nfull * 512 < mv.N) {
+        const unsigned hitmask = rq_generic_chunk<MODE>(mv, rs, nfull, lane, gi, eps);
+        if (__any(hitmask != 0)) rowcnt += rq_append(st, hitmask, rs.col0(nfull, lane), gi, eout, cap, cursor);
+      }
+    } else {
+      for (int c = 0; c < rs.nchunks; c++) {
+        const unsigned hitmask = rq_generic_chunk<MODE>(mv, rs, c, lane, gi, eps);
+        if (__any(hitmask != 0)) rowcnt += rq_append(st, hitmask, rs.col0(c, lane), gi, eout, cap, cursor);
+      }
     }
     if (lane == 0) cnt[il] = rowcnt;
   }
@@ -391,7 +461,10 @@ static int check_view(const char* fn, const void* M, const uint16_t* v, int N, i
   }
   return SSG_OK;
 }
-static int stream_grid(int nrows) { int b = (nrows + 3) / 4; return b < 4096 ? b : 4096; }
+// Persistent grid: ~5 workgroups per CU.  Every wave walks many rows and publishes its staged results with one
+// cursor atomic per ~500 entries; one wave per row meant N cursor / histogram atomics on a single word
+// (one word saturates at ~90 atomics/us: 16 000 rows = 0.18 ms of pure serialisation).
+static int stream_grid(int nrows) { int b = (nrows + 3) / 4; return b < 1280 ? b : 1280; }
 
 extern "C" int ssg_eps_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
                             uint64_t prefix, int shift, int width, int count_nonzero, uint64_t* hist, hipStream_t stream) {
