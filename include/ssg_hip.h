@@ -56,9 +56,9 @@ int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int r
 int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const float* src, const double* nsrc, int nrows, int Ns, int d,
                           uint32_t* rowmin, ssg_stream_t stream);
 /* Same result by filter-and-refine: a float32 MFMA pass bounds every target-source distance per row and
- * 64-source tile, float64 re-evaluates only the tiles within `tol` of the row's bound (tol >= float32
+ * 8-source granule, float64 re-evaluates only the granules within `tol` of the row's bound (tol >= float32
  * error of the bound).  src has Ns_pad rows (rows >= Ns padding), d % 32 == 0, Ns_pad % 128 == 0;
- * ws = nrows + Ns_pad + nrows*Ns_pad/64 floats. */
+ * ws = nrows + Ns_pad + nrows*Ns_pad/8 floats (row norms + the per-row bounds of every 8-source granule). */
 int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float* ws,
                                uint32_t* rowmin, ssg_stream_t stream);
 /* v = half(1-exp(-rowmin)); *max_bits = max(v); v /= max(v)   (rerank.py:38-40).  A zero

@@ -222,22 +222,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   // epilogue.  D = W * A^T: C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   // -> channel; accumulator quad q holds channels 8q + 4h + {0,1,2,3} of one pixel.
   if (p.epi == 3) {
-    // distance filter epilogue: min over this wave's WN columns of every row (lane = row, registers = columns)
+    // distance filter epilogue: per output row, the minimum over every 8-column granule of this wave's tile
+    // (lane = row; accumulator quad q of tile j holds columns j*32 + 8q + 4h + {0..3}; the two half-waves
+    // h = 0/1 together cover the 8 columns of granule (j, q)).  tilemin[m][col/8], 8 floats per lane-row.
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const int m = tm * BM + wm * WM + i * 32 + l32;
       const float rt = p.rowterm[m < p.M ? m : 0];
-      float mn = INFINITY;
 #pragma unroll
-      for (int j = 0; j < NT; j++)
+      for (int j = 0; j < NT; j++) {
+        float g[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const float4 bias = *reinterpret_cast<const float4*>(p.bias + tn * BN + wn * WN + j * 32 + 8 * q + 4 * h);
-          mn = fminf(mn, fminf(fminf((rt + bias.x) - 2.f * acc[i][j][4 * q], (rt + bias.y) - 2.f * acc[i][j][4 * q + 1]),
-                               fminf((rt + bias.z) - 2.f * acc[i][j][4 * q + 2], (rt + bias.w) - 2.f * acc[i][j][4 * q + 3])));
+          float mn = fminf(fminf((rt + bias.x) - 2.f * acc[i][j][4 * q], (rt + bias.y) - 2.f * acc[i][j][4 * q + 1]),
+                           fminf((rt + bias.z) - 2.f * acc[i][j][4 * q + 2], (rt + bias.w) - 2.f * acc[i][j][4 * q + 3]));
+          g[q] = fminf(mn, __shfl_xor(mn, 32, 64));
         }
-      mn = fminf(mn, __shfl_xor(mn, 32, 64));
-      if (h == 0 && m < p.M) p.tilemin[(int64_t)m * p.tmin_ld + tn * WCOLS + wn] = mn;
+        if (h == 0 && m < p.M)
+          *reinterpret_cast<float4*>(p.tilemin + (int64_t)m * p.tmin_ld + (tn * BN + wn * WN + j * 32) / 8) = make_float4(g[0], g[1], g[2], g[3]);
+      }
     }
     return;
   }
@@ -476,38 +480,46 @@ extern "C" int ssg_cosine_dist_f32(const float* x, const float* y, int m, int n,
 }
 
 namespace ssg {
-// Exact refinement of the source-term minimum: one wave per target row.  Tiles (64 sources) whose float32
+// Exact refinement of the source-term minimum: one wave per target row.  Granules (8 sources) whose float32
 // lower-bounded minimum can still beat the row's best are re-evaluated in float64 with the difference form
 // sum_k (x_k - y_k)^2 (like cdist), then half(sqrt(s)^2) as in reid/rerank.py:36-37.
 __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restrict__ tgt, const float* __restrict__ src, const float* __restrict__ tilemin,
-                                                            int ld, int ntiles, float tol, int nrows, int Ns, int d, unsigned* __restrict__ rowmin) {
+                                                            int ld, int ngran, float tol, int nrows, int Ns, int d, unsigned* __restrict__ rowmin) {
   const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (row >= nrows) return;
   const int lane = lane_id();
   float gmin = INFINITY;
-  for (int t = lane; t < ntiles; t += 64) gmin = fminf(gmin, tilemin[(int64_t)row * ld + t]);
+  for (int t = lane; t < ngran; t += 64) gmin = fminf(gmin, tilemin[(int64_t)row * ld + t]);
   for (int sh = 1; sh < 64; sh <<= 1) gmin = fminf(gmin, __shfl_xor(gmin, sh, 64));
   const float bound = gmin + tol;
   const float* x = tgt + (int64_t)row * d;
   unsigned best = 0xffffffffu;
-  for (int t0 = 0; t0 < ntiles; t0 += 64) {
+  for (int t0 = 0; t0 < ngran; t0 += 64) {
     const int t = t0 + lane;
-    uint64_t cand = __ballot(t < ntiles && tilemin[(int64_t)row * ld + t] <= bound);
+    uint64_t cand = __ballot(t < ngran && tilemin[(int64_t)row * ld + t] <= bound);
     while (cand) {
       const int tt = t0 + __ffsll((long long)cand) - 1;
       cand &= cand - 1;
-      const int s1 = (tt + 1) * 64 < Ns ? (tt + 1) * 64 : Ns;
-      for (int s = tt * 64; s < s1; s++) {
-        const float* y = src + (int64_t)s * d;
-        double acc = 0.0;
-        for (int k = lane; k < d; k += 64) { const double df = (double)x[k] - (double)y[k]; acc += df * df; }
-        for (int sh = 1; sh < 64; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
+      // 8 sources of the granule: lane group g = lane>>3 takes source tt*8+g, its 8 lanes split k
+      const int sidx = tt * 8 + (lane >> 3);
+      double acc = 0.0;
+      if (sidx < Ns) {
+        const float* y = src + (int64_t)sidx * d;
+        for (int k = (lane & 7) * 4; k < d; k += 32) {
+          const float4 xv = *reinterpret_cast<const float4*>(x + k), yv = *reinterpret_cast<const float4*>(y + k);
+          const double d0 = (double)xv.x - (double)yv.x, d1 = (double)xv.y - (double)yv.y, d2 = (double)xv.z - (double)yv.z, d3 = (double)xv.w - (double)yv.w;
+          acc += d0 * d0; acc += d1 * d1; acc += d2 * d2; acc += d3 * d3;
+        }
+      }
+      for (int sh = 1; sh < 8; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
+      if (sidx < Ns) {
         const double dist = sqrt(acc);
         const unsigned hb = d2h(dist * dist);     // np.power(cdist, 2).astype(float16)
         best = best < hb ? best : hb;
       }
     }
   }
+  for (int sh = 1; sh < 64; sh <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)best, sh, 64); best = best < o ? best : o; }
   if (lane == 0) rowmin[row] = best;
 }
 }  // namespace ssg
@@ -517,7 +529,7 @@ __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restr
 // of the row's bound.  Same result as ssg_source_rowmin_f16 (exact min of the half-rounded float64 distances)
 // whenever tol >= the float32 error of the bound (callers pass 8*d*2^-24*max|x|*max|y| + margin).
 // tgt [nrows,d], src [Ns_pad,d] (rows >= Ns are padding), d % 32 == 0, Ns_pad % 128 == 0.
-// ws: nrows + Ns_pad + nrows*(Ns_pad/64) floats.
+// ws: nrows + Ns_pad + nrows*(Ns_pad/8) floats.
 extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float* ws,
                                           uint32_t* rowmin, hipStream_t stream) {
   if (nrows <= 0 || Ns <= 0 || Ns_pad < Ns || (Ns_pad % 128) || (d % 32) || (int64_t)nrows * d * 4 > 0x7fffffffLL) {
@@ -525,7 +537,7 @@ extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, in
     return SSG_ERR_INVALID;
   }
   float* rowterm = ws; float* colterm = ws + nrows; float* tilemin = colterm + Ns_pad;
-  const int ntiles = Ns_pad / 64;
+  const int ntiles = Ns_pad / 8;   // 8-source granules
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
   if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins

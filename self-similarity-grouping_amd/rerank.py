@@ -100,7 +100,7 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
         u = 2.0 ** -24
         gam = d * u / (1.0 - d * u)
         tol = 2.0 * (2.0 * gam * nx * ny + 40.0 * u * (nx * nx + ny * ny)) + 8.0 * u * (nx + ny) ** 2
-        ws = torch.empty(nrows + Ns + npad + nrows * ((Ns + npad) // 64), dtype=torch.float32, device=tgt.device)
+        ws = torch.empty(nrows + Ns + npad + nrows * ((Ns + npad) // 8), dtype=torch.float32, device=tgt.device)
         check(L.ssg_source_rowmin_filtered(ptr(tblk), ptr(srcp), nrows, Ns, Ns + npad, d, tol, ptr(ws), ptr(rowmin), stream()),
               "ssg_source_rowmin_filtered")
         return rowmin
