@@ -136,6 +136,25 @@ int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, cons
  * in [B,H,W,Cin] (1x1 stride 1), in2 [B,H2,W2,Cin2] sampled at (oh*stride2, ow*stride2). */
 int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W, int Cin,
                               int H2, int W2, int Cin2, int stride2, int Cout, int relu, ssg_stream_t stream);
+/* Same two layers with the fp32 values carried as SPLIT HALVES ("h8l8": per 8 consecutive channels 32 bytes =
+ * [8 x half hi][8 x half lo], hi = half(v), lo = half(v - hi); same 4 bytes per value and same addressing as
+ * fp32).  flags & SSG_CONV_IN_SPLIT: in (in2) and w are h8l8, w pre-multiplied by 1/acc_scale (a power of two
+ * that lifts small weights out of the half subnormals); the GEMM then runs on v_mfma_f32_32x32x16_f16 as
+ * xh*wh + xh*wl + xl*wh with fp32 accumulation (half x half products are exact in fp32, the dropped xl*wl is
+ * < 2^-22 |x*w|): fp32-class results at 3/16 of the fp32-MFMA cost.  flags & SSG_CONV_OUT_SPLIT: out and res
+ * are h8l8 (values must stay below 65504).  flags = 0 is exactly ssg_conv2d_nhwc_f32. */
+#define SSG_CONV_IN_SPLIT 1
+#define SSG_CONV_OUT_SPLIT 2
+int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bias, const void* res, void* out, int B, int H, int W, int Cin,
+                      int Cout, int KH, int KW, int stride, int pad, int relu, int flags, float acc_scale, ssg_stream_t stream);
+int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const void* w, const float* bias, void* out, int B, int H, int W, int Cin,
+                            int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, ssg_stream_t stream);
+/* MaxPool2d(3,2,1) and the global/stripe average pool on h8l8 maps (the averages come out as fp32) */
+int ssg_maxpool3x3s2_h8l8(const void* in, void* out, int B, int H, int W, int C, ssg_stream_t stream);
+int ssg_gap_stripes_h8l8(const void* in, float* out, int B, int H, int W, int C, int num_split, ssg_stream_t stream);
+/* fp32 [n] -> h8l8 of (in * scale), and h8l8 -> fp32 (times scale); n % 8 == 0 */
+int ssg_h8l8_encode(const float* in, void* out, int64_t n, float scale, ssg_stream_t stream);
+int ssg_h8l8_decode(const void* in, float* out, int64_t n, float scale, ssg_stream_t stream);
 /* float32 squared-L2 block (reid/evaluators.py:63-85 pairwise_distance) on the fp32 matrix cores:
  * out[i,j] = |x_i|^2 + |y_j|^2 - 2<x_i,y_j>; self_form != 0 gives the reference's query=None form
  * 2|x_i|^2 - 2<x_i,y_j> (:64-72).  x [m,d], y [n,d], out [m,n]; d % 32 == 0, n % 64 == 0; ws = m+n floats. */

@@ -24,6 +24,31 @@ namespace ssg {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+// ---- split-half activations ---------------------------------------------------------------------------
+// The fp32 matrix cores run at 1/16 of the fp16 rate on gfx950, so the SPLIT kernels carry every fp32 value v
+// as two halves  hi = half(v), lo = half(v - hi)  (hi + lo reproduces 22 significand bits of v; |v| < 65504,
+// absolute floor 2^-25) and evaluate  x*w = xh*wh + xh*wl + xl*wh  on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation: half x half products are exact in fp32, the dropped xl*wl term is below 2^-22 |x*w|, so the
+// result is fp32-class (measured against fp64 next to the pure fp32 MFMA kernel in tests/test_gpu_parity.py)
+// at 3/16 of the fp32 MFMA cost.  Memory format ("h8l8"): per 8 consecutive channels 32 bytes =
+// [8 x half hi][8 x half lo] -- the same 4 bytes per value and the same addresses as the fp32 layout, so the
+// staging code below is shared by both element types.
+__device__ __forceinline__ unsigned pack_h2(_Float16 a, _Float16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ float unpack_lo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float unpack_hi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+// 4 values -> (hi pair of dwords, lo pair of dwords)
+__device__ __forceinline__ void split_encode4(const float4 v, uint2& hi, uint2& lo) {
+  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+  hi = make_uint2(pack_h2(h0, h1), pack_h2(h2, h3));
+  lo = make_uint2(pack_h2((_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1)), pack_h2((_Float16)(v.z - (float)h2), (_Float16)(v.w - (float)h3)));
+}
+__device__ __forceinline__ float4 split_decode4(const uint2 hi, const uint2 lo) {
+  return make_float4(unpack_lo(hi.x) + unpack_lo(lo.x), unpack_hi(hi.x) + unpack_hi(lo.x), unpack_lo(hi.y) + unpack_lo(lo.y), unpack_hi(hi.y) + unpack_hi(lo.y));
+}
 
 struct ConvParams {
   const float* in; const float* w; const float* bias; const float* res; float* out;
@@ -38,6 +63,9 @@ struct ConvParams {
   // epilogue mode 3 (distance filter): no matrix store; per output row the minimum of rowterm+bias-2*acc over each
   // 64-column wave tile goes to tilemin[m * tmin_ld + tile]
   float* tilemin; int tmin_ld;
+  // split-half format (see "split-half activations" below): which tensors are encoded, and the factor
+  // that undoes the operand scaling (weights / features are pre-scaled by a power of two)
+  int out_split, res_split; float acc_scale;
 };
 
 constexpr int CLD32 = 36;   // LDS row pitch in floats for BK=32 (BK=16 uses 20): pitch/4 odd -> conflict-free b128
@@ -54,7 +82,7 @@ __device__ __forceinline__ int conv_xcd_remap(int b, int nwg) {
 // The MFMA is issued as D = W_tile * A_tile^T (weights are the A operand), so a lane ends up
 // with 4 consecutive output channels of one pixel per accumulator quad: bias/residual/output
 // move as float4.
-template <int BM, int BN, int WM, int WN, bool CIN4, int CBK>
+template <int BM, int BN, int WM, int WN, bool CIN4, int CBK, bool SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
   constexpr int WCOLS = BN / WN;
   static_assert((BM / WM) * WCOLS == 4, "4 waves per workgroup");
@@ -178,6 +206,49 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     if (kt + 1 < nk) SSG_GLOAD(kt + 1)        // HBM/L2 latency hides under this tile's MFMAs
     const float* As = lds + (kt & 1) * STAGE;
     const float* Bs = As + BM * CLD;
+    if constexpr (SPLIT) {
+      // one k-step = 16 channels = two 32-byte [hi8|lo8] groups; half-wave h takes group 2s+h (A and W alike)
+      constexpr int KS = CBK / 16;
+      v8h ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+#pragma unroll
+      for (int i = 0; i < MT; i++) {
+        const float* q = As + (wm * WM + i * 32 + l32) * CLD + h * 8;
+        ah[0][i] = *reinterpret_cast<const v8h*>(q); al[0][i] = *reinterpret_cast<const v8h*>(q + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        const float* q = Bs + (wn * WN + j * 32 + l32) * CLD + h * 8;
+        bh[0][j] = *reinterpret_cast<const v8h*>(q); bl[0][j] = *reinterpret_cast<const v8h*>(q + 4);
+      }
+#pragma unroll
+      for (int g = 0; g < KS; g++) {
+        const int cur = g & 1, nxt = cur ^ 1;
+        if (g + 1 < KS) {
+#pragma unroll
+          for (int i = 0; i < MT; i++) {
+            const float* q = As + (wm * WM + i * 32 + l32) * CLD + (g + 1) * 16 + h * 8;
+            ah[nxt][i] = *reinterpret_cast<const v8h*>(q); al[nxt][i] = *reinterpret_cast<const v8h*>(q + 4);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; j++) {
+            const float* q = Bs + (wn * WN + j * 32 + l32) * CLD + (g + 1) * 16 + h * 8;
+            bh[nxt][j] = *reinterpret_cast<const v8h*>(q); bl[nxt][j] = *reinterpret_cast<const v8h*>(q + 4);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[cur][j], al[cur][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
+      }
+    } else {
     // fragments for k-group g+1 are fetched from LDS while the MFMAs of group g run
     float4 a[2][MT], b[2][NT];
 #pragma unroll
@@ -211,6 +282,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].w, a[cur][i].w, acc[i][j], 0, 0, 0);
     }
+    }
     if (kt + 1 < nk) SSG_LSTORE((kt + 1) & 1) // other buffer: its readers finished before the last barrier
     __syncthreads();
   }
@@ -219,6 +291,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #undef SSG_LOAD_A2
 #undef SSG_GLOAD
 #undef SSG_LSTORE
+  if constexpr (SPLIT) {   // undo the power-of-two operand scaling (exact)
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+      for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] *= p.acc_scale;
+  }
   // epilogue.  D = W * A^T: C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   // -> channel; accumulator quad q holds channels 8q + 4h + {0,1,2,3} of one pixel.
   if (p.epi == 3) {
@@ -245,11 +325,69 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     }
     return;
   }
+  const float* __restrict__ resp = p.res;
+  float* __restrict__ outp = p.out;
+  if (p.epi == 0 && !(p.variant & 2)) {
+    // Convolution epilogue, coalesced: the accumulators have one PIXEL per lane (row stride Cout*4 bytes), so direct
+    // stores touch 64 cache lines per instruction.  Each wave instead turns its tile through a private LDS patch, 32
+    // pixels x WN channels at a time, and leaves with lanes running along the channels: every residual load / output
+    // store instruction covers whole WN*4-byte row segments (the stage buffers are free after the last barrier).
+    constexpr int EP = WN + 4;                 // patch pitch (floats): EP/4 odd -> conflict-free b128 both ways
+    constexpr int CPR = WN / 4, RPI = 64 / CPR, ITS = 32 / RPI;
+    static_assert(4 * 32 * EP <= 2 * (BM + BN) * CLD, "epilogue patch fits in the stage buffers");
+    float* patch = lds + wave * (32 * EP);
+    const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
+    const int col = tn * BN + wn * WN + chunk * 4;
+    const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int mbase = tm * BM + wm * WM + i * 32;
+      float4 rr[ITS];
+      if (resp) {
+#pragma unroll
+        for (int it = 0; it < ITS; it++) {
+          const int m = mbase + it * RPI + prow;
+          rr[it] = *reinterpret_cast<const float4*>(resp + (int64_t)(m < p.M ? m : 0) * p.Cout + col);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          *reinterpret_cast<float4*>(patch + l32 * EP + j * 32 + 8 * q + 4 * h) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      // same wave wrote it: LDS operations of one wave complete in order
+#pragma unroll
+      for (int it = 0; it < ITS; it++) {
+        const int m = mbase + it * RPI + prow;
+        float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + chunk * 4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (resp) {
+          float4 r4 = rr[it];
+          if (p.res_split) {
+            // even lane holds hi0..7 of the 8-channel group, odd lane lo0..7; each needs hi and lo of ITS four channels
+            const unsigned s0 = odd ? __float_as_uint(r4.x) : __float_as_uint(r4.z), s1 = odd ? __float_as_uint(r4.y) : __float_as_uint(r4.w);
+            const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+            r4 = odd ? split_decode4(make_uint2(g0, g1), make_uint2(__float_as_uint(r4.z), __float_as_uint(r4.w)))
+                     : split_decode4(make_uint2(__float_as_uint(r4.x), __float_as_uint(r4.y)), make_uint2(g0, g1));
+          }
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        if (p.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+        if (p.out_split) {
+          uint2 hp, lp;
+          split_encode4(v, hp, lp);
+          const uint2 send = odd ? hp : lp;
+          const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 1, 64), (unsigned)__shfl_xor((int)send.y, 1, 64));
+          const uint4 st = odd ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
+          if (m < p.M) *reinterpret_cast<uint4*>(outp + (int64_t)m * p.Cout + col) = st;
+        } else if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
+      }
+    }
+    return;
+  }
   // All residual loads are issued first (one round trip), then bias/add/ReLU/stores: the stores
   // may alias the residual as far as the compiler knows, so an interleaved loop would serialise
   // 16 load->use->store round trips per wave.
-  const float* __restrict__ resp = p.res;
-  float* __restrict__ outp = p.out;
   float4 rr[MT][NT][4];
   if (resp) {
 #pragma unroll
@@ -259,7 +397,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
       for (int j = 0; j < NT; j++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) rr[i][j][q] = *reinterpret_cast<const float4*>(resp + mrow + tn * BN + wn * WN + j * 32 + 8 * q + 4 * h);
+        for (int q = 0; q < 4; q++) {
+          const float* g = resp + mrow + tn * BN + wn * WN + j * 32 + 8 * q;
+          if (p.res_split) {   // this lane's channels 4h..4h+3 of the group: hi at +8h bytes, lo at +16+8h bytes
+            const uint2 hi = *reinterpret_cast<const uint2*>(g + 2 * h), lo = *reinterpret_cast<const uint2*>(g + 4 + 2 * h);
+            rr[i][j][q] = make_float4(__uint_as_float(hi.x), __uint_as_float(hi.y), __uint_as_float(lo.x), __uint_as_float(lo.y));
+          } else rr[i][j][q] = *reinterpret_cast<const float4*>(g + 4 * h);
+        }
     }
   }
 #pragma unroll
@@ -279,9 +423,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
           v = make_float4((rt + bias.x) - 2.f * acc[i][j][4 * q], (rt + bias.y) - 2.f * acc[i][j][4 * q + 1], (rt + bias.z) - 2.f * acc[i][j][4 * q + 2],
                           (rt + bias.w) - 2.f * acc[i][j][4 * q + 3]);
         }
-        if (resp) { v.x += rr[i][j][q].x; v.y += rr[i][j][q].y; v.z += rr[i][j][q].z; v.w += rr[i][j][q].w; }
+        if (resp) {
+          float4 r4 = rr[i][j][q];
+          if (p.res_split) r4 = split_decode4(make_uint2(__float_as_uint(r4.x), __float_as_uint(r4.y)), make_uint2(__float_as_uint(r4.z), __float_as_uint(r4.w)));
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
         if (p.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-        if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
+        if (p.out_split) {
+          // group of 8 channels = [hi0..7][lo0..7]; this lane has channels 4h..4h+3, its partner (lane^32) the other
+          // four: half-wave 0 ends up storing the 16 hi bytes, half-wave 1 the 16 lo bytes.
+          uint2 hp, lp;
+          split_encode4(v, hp, lp);
+          const uint2 send = h ? hp : lp;
+          const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 32, 64), (unsigned)__shfl_xor((int)send.y, 32, 64));
+          const uint4 st = h ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
+          if (m < p.M) *reinterpret_cast<uint4*>(outp + (int64_t)m * p.Cout + col) = st;
+        } else if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
       }
     }
   }
@@ -335,6 +492,75 @@ __global__ void gap_stripes_kernel(const float* __restrict__ in, float* __restri
   }
 }
 
+// ---- split-half (h8l8) versions of the non-GEMM layers
+__device__ __forceinline__ void h8l8_load8(const float* g, float4& a, float4& b) {
+  const uint4 hi = *reinterpret_cast<const uint4*>(g), lo = *reinterpret_cast<const uint4*>(g + 4);
+  a = split_decode4(make_uint2(hi.x, hi.y), make_uint2(lo.x, lo.y));
+  b = split_decode4(make_uint2(hi.z, hi.w), make_uint2(lo.z, lo.w));
+}
+__device__ __forceinline__ void h8l8_store8(float* g, const float4 a, const float4 b) {
+  uint2 ha, la, hb, lb;
+  split_encode4(a, ha, la); split_encode4(b, hb, lb);
+  *reinterpret_cast<uint4*>(g) = make_uint4(ha.x, ha.y, hb.x, hb.y);
+  *reinterpret_cast<uint4*>(g + 4) = make_uint4(la.x, la.y, lb.x, lb.y);
+}
+
+__global__ void maxpool3x3s2_h8l8_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int OH, int OW) {
+  const int C8 = C / 8;
+  const int64_t total = (int64_t)B * OH * OW * C8;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+    const int c8 = (int)(x % C8); int64_t t = x / C8;
+    const int ow = (int)(t % OW); t /= OW; const int oh = (int)(t % OH); const int b = (int)(t / OH);
+    float4 m0 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), m1 = m0;
+    for (int r = 0; r < 3; r++) {
+      const int ih = oh * 2 - 1 + r; if (ih < 0 || ih >= H) continue;
+      for (int s = 0; s < 3; s++) {
+        const int iw = ow * 2 - 1 + s; if (iw < 0 || iw >= W) continue;
+        float4 a, c;
+        h8l8_load8(in + ((int64_t)(b * H + ih) * W + iw) * C + c8 * 8, a, c);
+        m0.x = fmaxf(m0.x, a.x); m0.y = fmaxf(m0.y, a.y); m0.z = fmaxf(m0.z, a.z); m0.w = fmaxf(m0.w, a.w);
+        m1.x = fmaxf(m1.x, c.x); m1.y = fmaxf(m1.y, c.y); m1.z = fmaxf(m1.z, c.z); m1.w = fmaxf(m1.w, c.w);
+      }
+    }
+    h8l8_store8(out + x * 8, m0, m1);
+  }
+}
+
+__global__ void gap_stripes_h8l8_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int S) {
+  const int nsets = S > 1 ? S + 1 : 1;
+  const int64_t total = (int64_t)nsets * B * C;
+  const unsigned short* hp = reinterpret_cast<const unsigned short*>(in);
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(x % C); int64_t t = x / C; const int b = (int)(t % B); const int s = (int)(t / B);
+    int h0 = 0, h1 = H;
+    if (s > 0) { const int hs = H / S; h0 = hs * (s - 1); h1 = hs * s; }
+    float acc = 0.f;
+    for (int hh = h0; hh < h1; hh++)
+      for (int w = 0; w < W; w++) {
+        const int64_t e = (((int64_t)(b * H + hh) * W + w) * C + (c & ~7)) * 2 + (c & 7);   // half index of the hi part
+        acc += (float)__builtin_bit_cast(_Float16, hp[e]) + (float)__builtin_bit_cast(_Float16, hp[e + 8]);
+      }
+    out[x] = acc / (float)((h1 - h0) * W);
+  }
+}
+
+// fp32 [n] (n % 8 == 0) <-> h8l8, with a power-of-two scale applied on the way in (out = split(in * scale))
+__global__ void h8l8_encode_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t ngroups, float scale) {
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ngroups; x += (int64_t)gridDim.x * blockDim.x) {
+    float4 a = reinterpret_cast<const float4*>(in)[2 * x], b = reinterpret_cast<const float4*>(in)[2 * x + 1];
+    a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale; b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
+    h8l8_store8(out + x * 8, a, b);
+  }
+}
+__global__ void h8l8_decode_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t ngroups, float scale) {
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < ngroups; x += (int64_t)gridDim.x * blockDim.x) {
+    float4 a, b;
+    h8l8_load8(in + x * 8, a, b);
+    a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale; b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
+    reinterpret_cast<float4*>(out)[2 * x] = a; reinterpret_cast<float4*>(out)[2 * x + 1] = b;
+  }
+}
+
 // out = (a + b) / ||a + b||_2 per row (reid/evaluators.py:31-35); one wave per row
 __global__ __launch_bounds__(256) void flip_sum_l2norm_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                                               int rows, int C) {
@@ -353,51 +579,66 @@ __global__ __launch_bounds__(256) void flip_sum_l2norm_kernel(const float* __res
 
 using namespace ssg;
 
-template <int BM, int BN, int WM, int WN, bool CIN4, int CBK>
+template <int BM, int BN, int WM, int WN, bool CIN4, int CBK, bool SPLIT>
 static int launch_conv_bk(const ConvParams& p, hipStream_t stream) {
   const size_t lds = 2 * (size_t)(BM + BN) * (CBK + 4) * sizeof(float);
   const int tiles = ((p.M + BM - 1) / BM) * (p.Cout / BN);
   static bool attr_set = false;
   if (lds > 64 * 1024 && !attr_set) {
-    int rc = ssg_check_hip(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+    int rc = ssg_check_hip(hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
                            "hipFuncSetAttribute(conv)");
     if (rc) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK>), dim3(tiles), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK, SPLIT>), dim3(tiles), dim3(256), lds, stream, p);
   return ssg_check_hip(hipGetLastError(), "conv_igemm_kernel");
 }
 // BK=16 stages (default): half the LDS of BK=32 -> 3 instead of 2 co-resident workgroups per CU, so one
 // workgroup's prologue / epilogue overlaps the others' MFMA phases.  The fused dual-input GEMM stays
 // on BK=32.  SSG_CONV_BK16_MAXK=<K> restricts BK=16 to reductions of at most K (tuning knob).
 template <int BM, int BN, int WM, int WN, bool CIN4>
-static int launch_conv(const ConvParams& p, hipStream_t stream) {
+static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = false) {
   static int bk16_max = -1;   // measured on MI355X: BK=16 wins for every ResNet-50 layer (9.1k -> 9.8k img/s)
   if (bk16_max < 0) { const char* e = getenv("SSG_CONV_BK16_MAXK"); bk16_max = e ? atoi(e) : 0x7fffffff; }
-  if (!p.in2 && p.Kpad <= bk16_max) return launch_conv_bk<BM, BN, WM, WN, CIN4, 16>(p, stream);
-  return launch_conv_bk<BM, BN, WM, WN, CIN4, 32>(p, stream);
+  if (split) {
+    if constexpr (CIN4) { ssg_set_error("conv: the 4-channel stem takes fp32 pixels"); return SSG_ERR_INVALID; }
+    else {
+      static int sbk16 = -1;
+      if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 0; }
+      if (!p.in2 && sbk16) return launch_conv_bk<BM, BN, WM, WN, false, 16, true>(p, stream);
+      return launch_conv_bk<BM, BN, WM, WN, false, 32, true>(p, stream);
+    }
+  }
+  if (!p.in2 && p.Kpad <= bk16_max) return launch_conv_bk<BM, BN, WM, WN, CIN4, 16, false>(p, stream);
+  return launch_conv_bk<BM, BN, WM, WN, CIN4, 32, false>(p, stream);
 }
 
 // Conv2d(bias folded from eval BatchNorm) + optional residual add + optional ReLU, NHWC fp32.
 //   in  [B,H,W,Cin]; w [Cout][Kpad] with k = (r*KW + s)*Cin + c, rows zero-padded to Kpad
 //   (multiple of 32); bias [Cout]; res/out [B,OH,OW,Cout].  Cin % 32 == 0, or Cin == 4 (stem:
 //   RGB0 pixels, Kpad = 32*ceil(KH*KW/8)).  Cout % 64 == 0.
-extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W,
-                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, hipStream_t stream) {
+//
+// flags: SSG_CONV_IN_SPLIT (1) = in and w are in the split-half h8l8 format (w additionally pre-multiplied by
+// 1/acc_scale, a power of two), the GEMM runs on the fp16 matrix cores (3 products per term, fp32 accumulate);
+// SSG_CONV_OUT_SPLIT (2) = out (and res) are written / read in h8l8.  flags = 0 is the plain fp32 path.
+extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bias, const void* res, void* out, int B, int H, int W,
+                                 int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int flags, float acc_scale, hipStream_t stream) {
   ConvParams p;
-  p.in = in; p.w = w; p.bias = bias; p.res = res; p.out = out;
+  p.in = (const float*)in; p.w = (const float*)w; p.bias = bias; p.res = (const float*)res; p.out = (float*)out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
   p.OH = (H + 2 * pad - KH) / stride + 1; p.OW = (W + 2 * pad - KW) / stride + 1;
   const int64_t M = (int64_t)B * p.OH * p.OW;
-  if (B <= 0 || M <= 0 || M > 0x7fffffff || (Cout % 64) || !((Cin % 32) == 0 || Cin == 4) || stride < 1) {
-    ssg_set_error("ssg_conv2d_nhwc_f32: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d", B, H, W, Cin, Cout, KH, KW, stride, pad);
+  const bool split = (flags & 1) != 0;
+  if (B <= 0 || M <= 0 || M > 0x7fffffff || (Cout % 64) || !((Cin % 32) == 0 || (Cin == 4 && !split)) || stride < 1) {
+    ssg_set_error("ssg_conv2d_nhwc: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d flags=%d", B, H, W, Cin, Cout, KH, KW, stride, pad, flags);
     return SSG_ERR_INVALID;
   }
   p.M = (int)M;
   const int64_t in_bytes = (int64_t)B * H * W * Cin * 4;
-  if (in_bytes > 0x7fffffffLL) { ssg_set_error("ssg_conv2d_nhwc_f32: input tensor of %lld bytes exceeds the 2 GiB buffer-resource range of this kernel; use a smaller batch", (long long)in_bytes); return SSG_ERR_INVALID; }
+  if (in_bytes > 0x7fffffffLL) { ssg_set_error("ssg_conv2d_nhwc: input tensor of %lld bytes exceeds the 2 GiB buffer-resource range of this kernel; use a smaller batch", (long long)in_bytes); return SSG_ERR_INVALID; }
   p.in_bytes = (unsigned)in_bytes;
   p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 0; p.tilemin = nullptr; p.tmin_ld = 0;
+  p.out_split = (flags & 2) ? 1 : 0; p.res_split = p.out_split; p.acc_scale = acc_scale;
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("SSG_CONV_VARIANT"); variant = e ? atoi(e) : 0; }
   p.variant = variant;
@@ -405,30 +646,42 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
   p.nk1 = p.Kpad / 16;   // no second input: every k-tile (of either BK) reads `in`
   if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);
-  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
+  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
+}
+
+extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W,
+                                   int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, hipStream_t stream) {
+  return ssg_conv2d_nhwc_x(in, w, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, 0, 1.f, stream);
 }
 
 // Fused bottleneck tail with a downsample branch (reid/models/base.py:75-90 when
 // self.downsample is not None):  out = relu( conv3(in) + bn3 + downsample_conv(in2) + bn_ds )
 // as ONE implicit GEMM over the concatenated K = Cin + Cin2: w [Cout][Cin + Cin2], bias = b3 + b_ds.
 // in [B,H,W,Cin] (1x1, stride 1); in2 [B,H2,W2,Cin2] sampled at (oh*stride2, ow*stride2).
-extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W,
-                                         int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, hipStream_t stream) {
+extern "C" int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const void* w, const float* bias, void* out, int B, int H, int W,
+                                       int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, hipStream_t stream) {
   ConvParams p;
-  p.in = in; p.w = w; p.bias = bias; p.res = nullptr; p.out = out;
+  p.in = (const float*)in; p.w = (const float*)w; p.bias = bias; p.res = nullptr; p.out = (float*)out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = relu;
   p.OH = H; p.OW = W;
   const int64_t M = (int64_t)B * H * W;
   const int64_t in_bytes = M * Cin * 4, in2_bytes = (int64_t)B * H2 * W2 * Cin2 * 4;
   if (B <= 0 || M > 0x7fffffff || (Cout % 64) || (Cin % 32) || (Cin2 % 32) || stride2 < 1 || (H - 1) * stride2 >= H2 || (W - 1) * stride2 >= W2 ||
       in_bytes > 0x7fffffffLL || in2_bytes > 0x7fffffffLL) {
-    ssg_set_error("ssg_conv1x1_dual_nhwc_f32: unsupported shape B=%d H=%d W=%d Cin=%d H2=%d W2=%d Cin2=%d s2=%d Cout=%d", B, H, W, Cin, H2, W2, Cin2, stride2, Cout);
+    ssg_set_error("ssg_conv1x1_dual_nhwc: unsupported shape B=%d H=%d W=%d Cin=%d H2=%d W2=%d Cin2=%d s2=%d Cout=%d", B, H, W, Cin, H2, W2, Cin2, stride2, Cout);
     return SSG_ERR_INVALID;
   }
   p.M = (int)M; p.in_bytes = (unsigned)in_bytes;
-  p.in2 = in2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.in2_bytes = (unsigned)in2_bytes;
+  p.in2 = (const float*)in2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2; p.in2_bytes = (unsigned)in2_bytes;
   p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0; p.tilemin = nullptr; p.tmin_ld = 0;   // dual input stays on BK=32 (nk1 counts 32-wide tiles)
-  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
+  p.out_split = (flags & 2) ? 1 : 0; p.res_split = p.out_split; p.acc_scale = acc_scale;
+  const bool split = (flags & 1) != 0;
+  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
+}
+
+extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W,
+                                         int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, hipStream_t stream) {
+  return ssg_conv1x1_dual_nhwc_x(in, in2, w, bias, out, B, H, W, Cin, H2, W2, Cin2, stride2, Cout, relu, 0, 1.f, stream);
 }
 
 namespace ssg {
@@ -460,7 +713,7 @@ extern "C" int ssg_pairwise_sqdist_f32(const float* x, const float* y, int m, in
   p.in = x; p.w = y; p.bias = colterm; p.res = nullptr; p.out = out;
   p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
   p.M = m; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 1; p.tilemin = nullptr; p.tmin_ld = 0;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 1; p.tilemin = nullptr; p.tmin_ld = 0; p.out_split = p.res_split = 0; p.acc_scale = 1.f;
   return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
@@ -475,7 +728,7 @@ extern "C" int ssg_cosine_dist_f32(const float* x, const float* y, int m, int n,
   p.in = x; p.w = y; p.bias = zeros; p.res = nullptr; p.out = out;
   p.B = m; p.H = 1; p.W = 1; p.Cin = d; p.Cout = n; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
   p.M = m; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)m * d * 4);
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 2; p.tilemin = nullptr; p.tmin_ld = 0;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = nullptr; p.epi = 2; p.tilemin = nullptr; p.tmin_ld = 0; p.out_split = p.res_split = 0; p.acc_scale = 1.f;
   return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
@@ -545,7 +798,7 @@ extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, in
   p.in = tgt; p.w = src; p.bias = colterm; p.res = nullptr; p.out = nullptr;
   p.B = nrows; p.H = 1; p.W = 1; p.Cin = d; p.Cout = Ns_pad; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
   p.M = nrows; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)nrows * d * 4);
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles;
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles; p.out_split = p.res_split = 0; p.acc_scale = 1.f;
   int rc = launch_conv<128, 128, 64, 64, false>(p, stream);   // wave tile = 64 columns = one tilemin entry
   if (rc) return rc;
   hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
@@ -565,6 +818,35 @@ extern "C" int ssg_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, 
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(8192), dim3(256), 0, stream, in, out, B, H, W, C, OH, OW);
   SSG_LAUNCH_CHECK("maxpool3x3s2_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_maxpool3x3s2_h8l8(const void* in, void* out, int B, int H, int W, int C, hipStream_t stream) {
+  if (B <= 0 || (C & 7)) { ssg_set_error("ssg_maxpool3x3s2_h8l8: C %% 8 != 0"); return SSG_ERR_INVALID; }
+  const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_h8l8_kernel, dim3(8192), dim3(256), 0, stream, (const float*)in, (float*)out, B, H, W, C, OH, OW);
+  SSG_LAUNCH_CHECK("maxpool3x3s2_h8l8_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_gap_stripes_h8l8(const void* in, float* out, int B, int H, int W, int C, int num_split, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || num_split > H) { ssg_set_error("ssg_gap_stripes_h8l8: bad shape"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(gap_stripes_h8l8_kernel, dim3(2048), dim3(256), 0, stream, (const float*)in, out, B, H, W, C, num_split);
+  SSG_LAUNCH_CHECK("gap_stripes_h8l8_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_h8l8_encode(const float* in, void* out, int64_t n, float scale, hipStream_t stream) {
+  if (n <= 0 || (n & 7)) { ssg_set_error("ssg_h8l8_encode: n must be a positive multiple of 8"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(h8l8_encode_kernel, dim3(4096), dim3(256), 0, stream, in, (float*)out, n / 8, scale);
+  SSG_LAUNCH_CHECK("h8l8_encode_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_h8l8_decode(const void* in, float* out, int64_t n, float scale, hipStream_t stream) {
+  if (n <= 0 || (n & 7)) { ssg_set_error("ssg_h8l8_decode: n must be a positive multiple of 8"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(h8l8_decode_kernel, dim3(4096), dim3(256), 0, stream, (const float*)in, out, n / 8, scale);
+  SSG_LAUNCH_CHECK("h8l8_decode_kernel");
   return SSG_OK;
 }
 

@@ -9,10 +9,16 @@ pooled feature sets (or their concatenation when for_eval=True), resnet.py:86-13
 
 The forward runs on hand-written HIP kernels (csrc/conv.hip) through the C ABI: NHWC fp32,
 eval-mode BatchNorm folded into the convolution weights at load time, bias/residual/ReLU
-fused into the GEMM epilogue.  There is no training path here (fine-tuning is out of scope,
+fused into the GEMM epilogue.  precision='split' (default) carries every fp32 activation /
+weight as two halves (hi + lo, 22 significand bits) and evaluates the products on the fp16
+matrix cores with fp32 accumulation (include/ssg_hip.h, ssg_conv2d_nhwc_x); precision='f32'
+keeps everything on the fp32 matrix cores.  There is no training path here (fine-tuning is out of scope,
 SURVEY.md section 2 rows 10-11).
 """
 from collections import OrderedDict
+
+import math
+import os
 
 import torch
 
@@ -78,11 +84,31 @@ def synthetic_state_dict(seed=1, depth=50, num_features=2048, randomize_bn=True)
 
 
 class _FoldedConv:
-    __slots__ = ("w", "bias", "cin", "cout", "k", "stride", "pad")
+    __slots__ = ("w", "bias", "cin", "cout", "k", "stride", "pad", "split", "acc_scale")
 
 
-def _fold(sd, conv_name, bn_name, stride, pad, device):
-    """conv + eval BatchNorm -> (w [Cout][Kpad] with k=(r,s,c), bias [Cout]); float64 fold."""
+_IN_SPLIT, _OUT_SPLIT = 1, 2      # include/ssg_hip.h SSG_CONV_IN_SPLIT / SSG_CONV_OUT_SPLIT
+
+
+def _h8l8(v):
+    """float32 [rows, K] (K % 8 == 0) -> the same shape of float32 CONTAINERS in the split-half layout:
+    per 8 values 32 bytes = [8 x half hi][8 x half lo], hi = half(v), lo = half(v - hi)."""
+    rows, K = v.shape
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    g = torch.stack([hi.view(rows, K // 8, 8), lo.view(rows, K // 8, 8)], dim=2)      # [rows, K/8, 2, 8]
+    return g.reshape(rows, 2 * K).contiguous().view(torch.float32)
+
+
+def _weight_scale(w):
+    """power of two that lifts the weights towards 1 (out of the half subnormals) without overflow"""
+    mx = float(w.abs().max())
+    return 256.0 if mx == 0 else float(min(256.0, 2.0 ** math.floor(math.log2(16384.0 / mx))))
+
+
+def _fold(sd, conv_name, bn_name, stride, pad, device, split=False):
+    """conv + eval BatchNorm -> (w [Cout][Kpad] with k=(r,s,c), bias [Cout]); float64 fold.
+    split=True: w in the h8l8 split-half layout, pre-multiplied by 1/acc_scale."""
     w = sd[conv_name + ".weight"].double()
     gamma, beta = sd[bn_name + ".weight"].double(), sd[bn_name + ".bias"].double()
     mean, var = sd[bn_name + ".running_mean"].double(), sd[bn_name + ".running_var"].double()
@@ -99,7 +125,15 @@ def _fold(sd, conv_name, bn_name, stride, pad, device):
     else:
         w = w.reshape(cout, k * k * cin)
     f = _FoldedConv()
-    f.w = w.float().contiguous().to(device); f.bias = bias.float().contiguous().to(device)
+    w = w.float().contiguous()
+    f.split, f.acc_scale = bool(split), 1.0
+    if split:
+        if cin == 4:
+            raise ValueError("the stem convolution takes fp32 pixels")
+        sc = _weight_scale(w)
+        w = _h8l8(w * sc)
+        f.acc_scale = 1.0 / sc
+    f.w = w.to(device); f.bias = bias.float().contiguous().to(device)
     f.cin, f.cout, f.k, f.stride, f.pad = cin, cout, k, stride, pad
     return f
 
@@ -108,7 +142,7 @@ class ResNet:
     """Mirror of reid.models.resnet.ResNet (resnet.py:17-148), forward only."""
 
     def __init__(self, depth=50, checkpoint=None, pretrained=True, num_features=2048, dropout=0.1, num_classes=0, num_split=1,
-                 mode='Dissimilarity', cluster=False, seed=1):
+                 mode='Dissimilarity', cluster=False, seed=1, precision=None):
         if depth not in _LAYERS:
             raise KeyError("Unsupported depth:", depth)
         if cluster:
@@ -120,6 +154,9 @@ class ResNet:
             raise ValueError("num_features must be a multiple of 64")
         self.depth, self.num_features, self.dropout, self.num_classes = depth, num_features, dropout, num_classes
         self.num_split, self.cluster, self.pretrained, self.training = num_split, cluster, pretrained, False
+        self.precision = precision or os.environ.get("SSG_EMBED_PRECISION", "split")
+        if self.precision not in ("split", "f32"):
+            raise ValueError("precision must be 'split' or 'f32'")
         self.device = torch.device("cpu")
         self._sd = synthetic_state_dict(seed, depth, num_features)
         self._folded = None
@@ -172,75 +209,104 @@ class ResNet:
         if self.device.type != "cuda":
             raise _lib.SSGError("the embedder runs on the GPU only: call model.cuda() first (no CPU fallback)")
         sd, dev = self._sd, self.device
-        net = dict(stem=_fold(sd, "base.conv1", "base.bn1", 2, 3, dev), blocks=[])
+        sp = self.precision == "split"
+        net = dict(stem=_fold(sd, "base.conv1", "base.bn1", 2, 3, dev), blocks=[], split=sp)
         for blk in _arch(self.depth):
             p = blk["prefix"]
-            c3 = _fold(sd, p + ".conv3", p + ".bn3", 1, 0, dev)
-            ds = _fold(sd, p + ".downsample.0", p + ".downsample.1", blk["stride"], 0, dev) if blk["down"] else None
-            if ds is not None:
-                # downsample branch fused into conv3: one GEMM over K = planes + inplanes
-                # (the residual tensor is never written to / re-read from HBM)
-                ds.w = torch.cat([c3.w, ds.w], dim=1).contiguous(); ds.bias = (c3.bias + ds.bias).contiguous()
+            if blk["down"]:
+                # downsample branch fused into conv3: one GEMM over K = planes + inplanes (the residual tensor
+                # is never written to / re-read from HBM); both halves share one weight scale
+                c3 = _fold(sd, p + ".conv3", p + ".bn3", 1, 0, dev)
+                ds = _fold(sd, p + ".downsample.0", p + ".downsample.1", blk["stride"], 0, dev)
+                wcat = torch.cat([c3.w, ds.w], dim=1)
+                if sp:
+                    sc = _weight_scale(wcat)
+                    ds.w = _h8l8((wcat * sc).cpu()).to(dev); ds.acc_scale = 1.0 / sc; ds.split = True
+                else:
+                    ds.w = wcat.contiguous()
+                ds.bias = (c3.bias + ds.bias).contiguous()
+            else:
+                c3 = _fold(sd, p + ".conv3", p + ".bn3", 1, 0, dev, split=sp)
+                ds = None
             net["blocks"].append(dict(
-                c1=_fold(sd, p + ".conv1", p + ".bn1", 1, 0, dev),
-                c2=_fold(sd, p + ".conv2", p + ".bn2", blk["stride"], 1, dev),
+                c1=_fold(sd, p + ".conv1", p + ".bn1", 1, 0, dev, split=sp),
+                c2=_fold(sd, p + ".conv2", p + ".bn2", blk["stride"], 1, dev, split=sp),
                 c3=c3, ds=ds))
         self._folded = net
         return net
 
     # ---- forward
     @staticmethod
-    def _conv(L, x, f, res=None, relu=True):
+    def _conv(L, x, f, res=None, relu=True, out_split=False):
         B, H, W, _ = x.shape
         OH = (H + 2 * f.pad - f.k) // f.stride + 1; OW = (W + 2 * f.pad - f.k) // f.stride + 1
         out = torch.empty((B, OH, OW, f.cout), dtype=torch.float32, device=x.device)
-        check(L.ssg_conv2d_nhwc_f32(ptr(x), ptr(f.w), ptr(f.bias), ptr(res), ptr(out), B, H, W, f.cin, f.cout, f.k, f.k, f.stride, f.pad,
-                                    1 if relu else 0, stream()), "ssg_conv2d_nhwc_f32")
+        flags = (_IN_SPLIT if f.split else 0) | (_OUT_SPLIT if out_split else 0)
+        check(L.ssg_conv2d_nhwc_x(ptr(x), ptr(f.w), ptr(f.bias), ptr(res), ptr(out), B, H, W, f.cin, f.cout, f.k, f.k, f.stride, f.pad,
+                                  1 if relu else 0, flags, f.acc_scale, stream()), "ssg_conv2d_nhwc_x")
         return out
 
     @staticmethod
-    def _conv_dual(L, o, x, c3, ds):
-        """relu(conv3(o) + downsample(x)) as one GEMM (ssg_conv1x1_dual_nhwc_f32)."""
+    def _conv_dual(L, o, x, c3, ds, out_split=False):
+        """relu(conv3(o) + downsample(x)) as one GEMM (ssg_conv1x1_dual_nhwc_x)."""
         B, H, W, _ = o.shape
         _, H2, W2, _ = x.shape
         out = torch.empty((B, H, W, c3.cout), dtype=torch.float32, device=o.device)
-        check(L.ssg_conv1x1_dual_nhwc_f32(ptr(o), ptr(x), ptr(ds.w), ptr(ds.bias), ptr(out), B, H, W, c3.cin, H2, W2, ds.cin, ds.stride, c3.cout, 1,
-                                          stream()), "ssg_conv1x1_dual_nhwc_f32")
+        flags = (_IN_SPLIT if ds.split else 0) | (_OUT_SPLIT if out_split else 0)
+        check(L.ssg_conv1x1_dual_nhwc_x(ptr(o), ptr(x), ptr(ds.w), ptr(ds.bias), ptr(out), B, H, W, c3.cin, H2, W2, ds.cin, ds.stride, c3.cout, 1,
+                                        flags, ds.acc_scale, stream()), "ssg_conv1x1_dual_nhwc_x")
         return out
 
-    def feature_map(self, x, flip=False):
-        """images [B,3,H,W] float32 (NCHW, any device) -> layer4 map [B,H/32,W/32,2048] NHWC
-        (resnet.py:87-92: every base module up to, not including, avgpool)."""
+    def _fmap(self, x, flip=False):
+        """-> (layer4 map [B,h,w,2048], is_split): with precision='split' the float32 tensor is a container of
+        h8l8 split halves (decode with ssg_h8l8_decode)."""
         L = _lib.lib()
         net = self._prepare()
+        sp = net["split"]
         x = x.to(self.device, torch.float32).contiguous()
         B, C, H, W = x.shape
         if C != 3:
             raise ValueError("expected RGB images [B,3,H,W]")
         x4 = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
         check(L.ssg_nchw_to_nhwc4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4")
-        y = self._conv(L, x4, net["stem"])
+        y = self._conv(L, x4, net["stem"], out_split=sp)
         _, H2, W2, _ = y.shape
         p = torch.empty((B, (H2 + 1) // 2, (W2 + 1) // 2, 64), dtype=torch.float32, device=self.device)
-        check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
+        if sp:
+            check(L.ssg_maxpool3x3s2_h8l8(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_h8l8")
+        else:
+            check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
         y = p
         for blk in net["blocks"]:
-            o = self._conv(L, y, blk["c1"])
-            o = self._conv(L, o, blk["c2"])
+            o = self._conv(L, y, blk["c1"], out_split=sp)
+            o = self._conv(L, o, blk["c2"], out_split=sp)
             if blk["ds"] is not None:
-                y = self._conv_dual(L, o, y, blk["c3"], blk["ds"])
+                y = self._conv_dual(L, o, y, blk["c3"], blk["ds"], out_split=sp)
             else:
-                y = self._conv(L, o, blk["c3"], res=y, relu=True)
+                y = self._conv(L, o, blk["c3"], res=y, relu=True, out_split=sp)
+        return y, sp
+
+    def feature_map(self, x, flip=False):
+        """images [B,3,H,W] float32 (NCHW, any device) -> layer4 map [B,H/32,W/32,2048] NHWC fp32
+        (resnet.py:87-92: every base module up to, not including, avgpool)."""
+        y, sp = self._fmap(x, flip)
+        if sp:
+            out = torch.empty_like(y)
+            check(_lib.lib().ssg_h8l8_decode(ptr(y), ptr(out), y.numel(), 1.0, stream()), "ssg_h8l8_decode")
+            return out
         return y
 
-    def pooled(self, fmap):
+    def pooled(self, fmap, split=False):
         """[B,h,w,2048] -> [(S+1), B, 2048] (whole + S stripes) or [1,B,2048] (resnet.py:93-111)."""
         L = _lib.lib()
         B, h, w, C = fmap.shape
         S = self.num_split if self.num_split > 1 else 1
         nsets = S + 1 if S > 1 else 1
         out = torch.empty((nsets, B, C), dtype=torch.float32, device=fmap.device)
-        check(L.ssg_gap_stripes(ptr(fmap), ptr(out), B, h, w, C, S, stream()), "ssg_gap_stripes")
+        if split:
+            check(L.ssg_gap_stripes_h8l8(ptr(fmap), ptr(out), B, h, w, C, S, stream()), "ssg_gap_stripes_h8l8")
+        else:
+            check(L.ssg_gap_stripes(ptr(fmap), ptr(out), B, h, w, C, S, stream()), "ssg_gap_stripes")
         return out
 
     def _x2(self, gap):
@@ -260,7 +326,7 @@ class ResNet:
         return out.reshape(B, self.num_features)
 
     def __call__(self, x, for_eval=False):
-        sets = self.pooled(self.feature_map(x))
+        sets = self.pooled(*self._fmap(x))
         x2 = self._x2(sets[0])
         if self.num_split > 1:
             x1 = [sets[s] for s in range(sets.shape[0])]
@@ -276,8 +342,8 @@ class ResNet:
         Returns [(S+1), B, 2048] (per-set norm) or, for_eval / single set, [B, (S+1)*2048]."""
         L = _lib.lib()
         x = x.to(self.device, torch.float32)          # one H2D copy for both orientations
-        a = self.pooled(self.feature_map(x, flip=False))
-        b = self.pooled(self.feature_map(x, flip=True))
+        a = self.pooled(*self._fmap(x, flip=False))
+        b = self.pooled(*self._fmap(x, flip=True))
         nsets, B, C = a.shape
         if for_eval or nsets == 1:
             a = a.permute(1, 0, 2).reshape(B, nsets * C).contiguous(); b = b.permute(1, 0, 2).reshape(B, nsets * C).contiguous()

@@ -307,16 +307,80 @@ def test_conv_vs_torch(cfg, L, dev):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err     # fp32 accumulation over K <= 1152 terms
 
 
-def test_embedding_vs_reference_golden(golden, dev):
+@pytest.mark.parametrize("cfg", [
+    (3, 16, 8, 64, 64, 1, 1, 0, False, True),
+    (2, 16, 8, 64, 256, 1, 1, 0, True, True),
+    (2, 16, 8, 128, 128, 3, 1, 1, False, True),
+    (2, 16, 8, 128, 128, 3, 2, 1, False, True),
+    (2, 16, 8, 256, 512, 1, 2, 0, False, False),
+    (5, 9, 7, 64, 64, 3, 1, 1, False, True),
+    (2, 8, 4, 512, 512, 3, 1, 1, True, True),       # K = 4608
+])
+def test_conv_split_half_vs_fp64(cfg, L, dev):
+    """Split-half convolution (fp16 matrix cores, hi/lo operands, fp32 accumulate) against an fp64 convolution,
+    side by side with the pure fp32-MFMA kernel on the same data: the split path must be fp32-class --
+    within 2x of the fp32 kernel's own error (+ the 2^-22 operand representation) and inside the same
+    absolute bound the fp32 test uses."""
+    from ssg_amd._lib import check, ptr, stream
+    from ssg_amd.resnet import _h8l8, _weight_scale
+    B, H, W, Cin, Cout, k, stride, pad, use_res, relu = cfg
+    g = torch.Generator().manual_seed(hash(cfg) % 1000 + 1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[0, :, 0, 0] *= 1e-4                      # a pixel of tiny activations (half-subnormal lo parts)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride, pad)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = torch.relu(ref)
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev); wk = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    OH, OW = ref.shape[2], ref.shape[3]
+    bias_d = bias.to(dev)
+    res_d = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    # fp32 MFMA kernel
+    out32 = torch.empty(B, OH, OW, Cout, device=dev)
+    check(L.ssg_conv2d_nhwc_f32(ptr(xin), ptr(wk.to(dev)), ptr(bias_d), ptr(res_d), ptr(out32), B, H, W, Cin, Cout, k, k, stride, pad, int(relu), stream()), "conv")
+    # split-half kernel: encode activations / residual on the device, weights on the host
+    sc = _weight_scale(wk)
+    ws = _h8l8(wk * sc).to(dev)
+    xs = torch.empty_like(xin); check(L.ssg_h8l8_encode(ptr(xin), ptr(xs), xin.numel(), 1.0, stream()), "enc")
+    rs = None
+    if use_res:
+        rs = torch.empty_like(res_d); check(L.ssg_h8l8_encode(ptr(res_d), ptr(rs), res_d.numel(), 1.0, stream()), "enc")
+    outs = torch.empty(B, OH, OW, Cout, device=dev)
+    check(L.ssg_conv2d_nhwc_x(ptr(xs), ptr(ws), ptr(bias_d), ptr(rs), ptr(outs), B, H, W, Cin, Cout, k, k, stride, pad, int(relu), 3, 1.0 / sc, stream()), "convx")
+    dec = torch.empty_like(outs); check(L.ssg_h8l8_decode(ptr(outs), ptr(dec), outs.numel(), 1.0, stream()), "dec")
+    # fp32 output of the same split GEMM (flags = IN only)
+    outp = torch.empty(B, OH, OW, Cout, device=dev)
+    check(L.ssg_conv2d_nhwc_x(ptr(xs), ptr(ws), ptr(bias_d), ptr(res_d), ptr(outp), B, H, W, Cin, Cout, k, k, stride, pad, int(relu), 1, 1.0 / sc, stream()), "convx")
+    scale = max(1.0, ref.abs().max().item())
+    e32 = (out32.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    esp = (dec.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    print("conv %r: fp32-mfma err %.3g  split err %.3g" % (cfg, e32, esp))
+    assert esp < 2e-5 * scale, (esp, e32)
+    assert esp < 2.0 * e32 + 2.0 ** -21 * scale, (esp, e32)
+    # the stored format is a fixed point: decode -> encode -> decode gives the same values back
+    re = torch.empty_like(dec); check(L.ssg_h8l8_encode(ptr(dec), ptr(re), dec.numel(), 1.0, stream()), "enc")
+    dec2 = torch.empty_like(dec); check(L.ssg_h8l8_decode(ptr(re), ptr(dec2), dec.numel(), 1.0, stream()), "dec")
+    assert torch.equal(dec2, dec)
+    # fp32 output of the same GEMM (flags = IN only) agrees with the decoded split output to the format's 2^-22
+    assert (outp - dec).abs().max().item() <= 2.0 ** -21 * scale
+
+
+@pytest.mark.parametrize("precision", ["split", "f32"])
+def test_embedding_vs_reference_golden(golden, dev, precision):
     """HIP ResNet-50 embed (orig + flip, L2 norm) vs the real reference model's features.
     Tolerance 5e-6 absolute on unit-norm 2048-d features (fp32 conv accumulation order)."""
     import ssg_amd
     g = golden("embed_ref.npz")
     imgs = torch.randn(4, 3, 256, 128, generator=torch.Generator().manual_seed(int(g["image_seed"])))
     for S in (2, 1):
-        m = ssg_amd.create("resnet50", num_classes=0, num_split=S, cluster=False, seed=int(g["weight_seed"])).cuda().eval()
+        m = ssg_amd.create("resnet50", num_classes=0, num_split=S, cluster=False, seed=int(g["weight_seed"]), precision=precision).cuda().eval()
         ref = g["feats_S%d" % S]
         got = m.embed_with_flip(imgs)
+        print("embedding S=%d precision=%s: max |err| vs reference %.3g" % (S, precision, np.abs((got.cpu().numpy() if got.dim() == 3 else got.cpu().numpy()[None]) - ref).max()))
         got = got.cpu().numpy() if got.dim() == 3 else got.cpu().numpy()[None]
         assert got.shape == ref.shape
         assert np.abs(got - ref).max() < 5e-6, np.abs(got - ref).max()

@@ -33,16 +33,29 @@ def main():
         rows = []
         orig = resnet.ResNet._conv
 
-        def timed(L_, x_, f, res=None, relu=True):
+        def timed(L_, x_, f, res=None, relu=True, out_split=False):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); out = orig(L_, x_, f, res, relu); e1.record(); e1.synchronize()
+            e0.record(); out = orig(L_, x_, f, res, relu, out_split); e1.record(); e1.synchronize()
             B, H, W, _ = x_.shape
             flop = 2.0 * out.numel() * f.k * f.k * (3 if f.cin == 4 else f.cin)
             byt = 4.0 * (x_.numel() + out.numel() * (2 if res is not None else 1) + f.w.numel())
             rows.append((H, W, f.cin, f.cout, f.k, f.stride, e0.elapsed_time(e1), flop, byt))
             return out
+        orig_d = resnet.ResNet._conv_dual
+
+        def timed_d(L_, o, x_, c3, ds, out_split=False):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); out = orig_d(L_, o, x_, c3, ds, out_split); e1.record(); e1.synchronize()
+            B, H, W, _ = o.shape
+            flop = 2.0 * out.numel() * (c3.cin + ds.cin)
+            byt = 4.0 * (o.numel() + x_.numel() / (ds.stride ** 2) + out.numel() + ds.w.numel())
+            rows.append((H, W, c3.cin + ds.cin, c3.cout, 1, -ds.stride, e0.elapsed_time(e1), flop, byt))
+            return out
         resnet.ResNet._conv = staticmethod(timed)
-        m.feature_map(x)
+        resnet.ResNet._conv_dual = staticmethod(timed_d)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record(); m._fmap(x); e1.record(); e1.synchronize()
+        print("  one forward (with per-layer syncs): %.2f ms" % e0.elapsed_time(e1))
         tot = sum(r[6] for r in rows)
         for r in rows:
             print("  %3dx%-3d cin=%4d cout=%4d k=%d s=%d  %7.3f ms  %6.1f TF/s  %6.2f TB/s" % (r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7] / r[6] / 1e9, r[8] / r[6] / 1e9))
