@@ -75,6 +75,99 @@ __device__ __forceinline__ int conv_xcd_remap(int b, int nwg) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
 }
 
+// ---- split-half multiply: one k-step = 16 channels = two 32-byte [hi8|lo8] groups; half-wave h takes group 2*step+h
+// (A and W alike).  Fragments of a step live in a SplitFrags; the pipeline in the kernel loads step s+1 while the
+// MFMAs of step s run, and the first step of a tile right after the barrier that published it.
+template <int MT, int NT> struct SplitFrags { v8h ah[MT], al[MT], bh[NT], bl[NT]; };
+
+template <int MT, int NT, int CLD>
+__device__ __forceinline__ void split_load_frags(const float* Arow, const float* Brow, const int kofs, SplitFrags<MT, NT>& f) {
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    const float* q = Arow + i * 32 * CLD + kofs;
+    f.ah[i] = *reinterpret_cast<const v8h*>(q); f.al[i] = *reinterpret_cast<const v8h*>(q + 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const float* q = Brow + j * 32 * CLD + kofs;
+    f.bh[j] = *reinterpret_cast<const v8h*>(q); f.bl[j] = *reinterpret_cast<const v8h*>(q + 4);
+  }
+}
+
+// x*w = xh*wl + xl*wh + xh*wh; consecutive MFMAs hit different accumulators (each is revisited every MT*NT issues)
+template <int MT, int NT>
+__device__ __forceinline__ void split_mma_step(const SplitFrags<MT, NT>& f, v16f (&acc)[MT][NT]) {
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+}
+
+// One K tile on the split path.  f0 already holds step 0.  `mid` (the next tile's LDS stores) is issued after the
+// first step's MFMAs, when the matrix pipe has 12 x 32 cycles of work queued.
+template <int MT, int NT, int CLD, int CBK, typename F>
+__device__ __forceinline__ void split_tile_mma(const float* Arow, const float* Brow, const int h, SplitFrags<MT, NT>& f0, SplitFrags<MT, NT>& f1,
+                                               v16f (&acc)[MT][NT], F mid) {
+  constexpr int KS = CBK / 16;
+  if (KS == 2) split_load_frags<MT, NT, CLD>(Arow, Brow, 16 + h * 8, f1);
+  __builtin_amdgcn_sched_barrier(0);
+  split_mma_step<MT, NT>(f0, acc);
+  __builtin_amdgcn_sched_barrier(0);
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
+  if (KS == 2) split_mma_step<MT, NT>(f1, acc);
+}
+
+// One K tile of the fp32 multiply: Arow / Brow point at this lane's first row of the A (pixels) and W (channels) stage
+// tiles; further MFMA tiles are 32 rows apart.  `mid` runs after the tile's MFMAs have been issued.
+template <int MT, int NT, int CLD, int CBK, typename F>
+__device__ __forceinline__ void conv_tile_mma(const float* Arow, const float* Brow, const int h, v16f (&acc)[MT][NT], F mid) {
+    {
+    // fragments for k-group g+1 are fetched from LDS while the MFMAs of group g run
+    float4 a[2][MT], b[2][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) a[0][i] = *reinterpret_cast<const float4*>(Arow + i * 32 * CLD + h * 4);
+#pragma unroll
+    for (int j = 0; j < NT; j++) b[0][j] = *reinterpret_cast<const float4*>(Brow + j * 32 * CLD + h * 4);
+#pragma unroll
+    for (int g = 0; g < CBK / 8; g++) {
+      const int cur = g & 1, nxt = cur ^ 1;
+      if (g + 1 < CBK / 8) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) a[nxt][i] = *reinterpret_cast<const float4*>(Arow + i * 32 * CLD + (g + 1) * 8 + h * 4);
+#pragma unroll
+        for (int j = 0; j < NT; j++) b[nxt][j] = *reinterpret_cast<const float4*>(Brow + j * 32 * CLD + (g + 1) * 8 + h * 4);
+      }
+      // consecutive MFMAs hit different accumulators (each one is revisited every MT*NT issues)
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].x, a[cur][i].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].y, a[cur][i].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].z, a[cur][i].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].w, a[cur][i].w, acc[i][j], 0, 0, 0);
+      if (g == CBK / 8 - 1) mid();
+    }
+    }
+}
+
 // CIN4: stem mode, input has 4 channels (RGB + zero), one float4 = one filter tap.
 // Workgroup tile BM x BN, 4 waves in a (BM/WM) x (BN/WN) grid, each wave WM x WN = MT x NT MFMA
 // tiles of 32x32.  LDS is double buffered: the next K tile is fetched into registers while the
@@ -120,15 +213,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 #undef SSG_ROW_INIT
   const float* wbase = p.w + (int64_t)(tn * BN + r0) * p.Kpad + kq * 4;
   const int64_t wstep = (int64_t)RPP * p.Kpad;
-  float4 pa0, pa1, pa2, pa3, pb0, pb1, pb2, pb3;
-  pa2 = pa3 = pb1 = pb2 = pb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // two register sets: the SPLIT kernels finish a K tile five times faster than the fp32 ones, so the global
+  // loads run TWO tiles ahead of the multiply (set kt&1 holds tile kt until it is written to LDS)
+  constexpr bool PF2 = SPLIT;
+  float4 pa0_0, pa1_0, pa2_0, pa3_0, pb0_0, pb1_0, pb2_0, pb3_0, pa0_1, pa1_1, pa2_1, pa3_1, pb0_1, pb1_1, pb2_1, pb3_1;
+  pa2_0 = pa3_0 = pb1_0 = pb2_0 = pb3_0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  pa0_1 = pa1_1 = pa2_1 = pa3_1 = pb0_1 = pb1_1 = pb2_1 = pb3_1 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // A tile through a buffer resource: padding taps / rows beyond M get an out-of-range offset and
   // the hardware bounds check returns zeros -- no branch, no select (a load under a branch makes
   // hipcc wait for it on the spot and serialises the prefetch).
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? p.in2_bytes : 0u, 0x00020000);
-#define SSG_LOAD_A(J)                                                                                   \
+#define SSG_LOAD_A(J, S)                                                                                 \
   {                                                                                                     \
     const int ih = ah##J + r, iw = aw##J + s_;                                                          \
     const bool ok = ab##J >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                           \
@@ -136,50 +233,50 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     /* always-valid offset from clamped coordinates, then poisoned past the 2 GiB bound when !ok */     \
     const unsigned off = (unsigned)((((bc * p.H + ihc) * p.W + iwc) * p.Cin + c) * 4) + (ok ? 0u : 0x80000000u); \
     const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, off, 0, 0);                          \
-    pa##J = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
+    pa##J##_##S = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
   }
 // second input (fused downsample): 1x1, stride2, same output pixel grid
-#define SSG_LOAD_A2(J)                                                                                  \
+#define SSG_LOAD_A2(J, S)                                                                                 \
   {                                                                                                     \
     const int oh_ = (ah##J + p.pad) / p.stride, ow_ = (aw##J + p.pad) / p.stride;                       \
     const int bc = max(ab##J, 0);                                                                       \
     const unsigned off = (unsigned)((((bc * p.H2 + oh_ * p.stride2) * p.W2 + ow_ * p.stride2) * p.Cin2 + c2_) * 4) + (ab##J >= 0 ? 0u : 0x80000000u); \
     const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(in2_rsrc, off, 0, 0);                         \
-    pa##J = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
+    pa##J##_##S = make_float4(__uint_as_float(raw.x), __uint_as_float(raw.y), __uint_as_float(raw.z), __uint_as_float(raw.w)); \
   }
-#define SSG_GLOAD(KT)                                                                                   \
+#define SSG_GLOAD(KT, S)                                                                                 \
   {                                                                                                     \
     if ((KT) < p.nk1) {                                                                                 \
       int r, s_, c;                                                                                     \
       if (CIN4) { const int tap = (KT) * KQ + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; /* -> !ok */ } \
       else { const int k0 = (KT) * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s_ = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; } \
-      SSG_LOAD_A(0) SSG_LOAD_A(1) if (AJ == 4) { SSG_LOAD_A(2) SSG_LOAD_A(3) }                          \
+      SSG_LOAD_A(0, S) SSG_LOAD_A(1, S) if (AJ == 4) { SSG_LOAD_A(2, S) SSG_LOAD_A(3, S) }              \
     } else {                                                                                            \
       const int c2_ = ((KT) - p.nk1) * CBK + kq * 4;                                                    \
-      SSG_LOAD_A2(0) SSG_LOAD_A2(1) if (AJ == 4) { SSG_LOAD_A2(2) SSG_LOAD_A2(3) }                      \
+      SSG_LOAD_A2(0, S) SSG_LOAD_A2(1, S) if (AJ == 4) { SSG_LOAD_A2(2, S) SSG_LOAD_A2(3, S) }          \
     }                                                                                                   \
-    pb0 = *reinterpret_cast<const float4*>(wbase + (KT) * CBK);                                         \
-    if (BJ >= 2) pb1 = *reinterpret_cast<const float4*>(wbase + wstep + (KT) * CBK);                    \
+    pb0_##S = *reinterpret_cast<const float4*>(wbase + (KT) * CBK);                                         \
+    if (BJ >= 2) pb1_##S = *reinterpret_cast<const float4*>(wbase + wstep + (KT) * CBK);                    \
     if (BJ == 4) {                                                                                      \
-      pb2 = *reinterpret_cast<const float4*>(wbase + 2 * wstep + (KT) * CBK);                           \
-      pb3 = *reinterpret_cast<const float4*>(wbase + 3 * wstep + (KT) * CBK);                           \
+      pb2_##S = *reinterpret_cast<const float4*>(wbase + 2 * wstep + (KT) * CBK);                           \
+      pb3_##S = *reinterpret_cast<const float4*>(wbase + 3 * wstep + (KT) * CBK);                           \
     }                                                                                                   \
   }
-#define SSG_LSTORE(BUF)                                                                                 \
+#define SSG_LSTORE(BUF, S)                                                                                \
   {                                                                                                     \
     float* As_ = lds + (BUF) * STAGE;                                                                   \
     float* Bs_ = As_ + BM * CLD;                                                                        \
-    *reinterpret_cast<float4*>(As_ + (r0 + 0) * CLD + kq * 4) = pa0;                                    \
-    *reinterpret_cast<float4*>(As_ + (r0 + RPP) * CLD + kq * 4) = pa1;                                  \
+    *reinterpret_cast<float4*>(As_ + (r0 + 0) * CLD + kq * 4) = pa0_##S;                                    \
+    *reinterpret_cast<float4*>(As_ + (r0 + RPP) * CLD + kq * 4) = pa1_##S;                                  \
     if (AJ == 4) {                                                                                      \
-      *reinterpret_cast<float4*>(As_ + (r0 + 2 * RPP) * CLD + kq * 4) = pa2;                            \
-      *reinterpret_cast<float4*>(As_ + (r0 + 3 * RPP) * CLD + kq * 4) = pa3;                            \
+      *reinterpret_cast<float4*>(As_ + (r0 + 2 * RPP) * CLD + kq * 4) = pa2_##S;                            \
+      *reinterpret_cast<float4*>(As_ + (r0 + 3 * RPP) * CLD + kq * 4) = pa3_##S;                            \
     }                                                                                                   \
-    *reinterpret_cast<float4*>(Bs_ + (r0 + 0) * CLD + kq * 4) = pb0;                                    \
-    if (BJ >= 2) *reinterpret_cast<float4*>(Bs_ + (r0 + RPP) * CLD + kq * 4) = pb1;                     \
+    *reinterpret_cast<float4*>(Bs_ + (r0 + 0) * CLD + kq * 4) = pb0_##S;                                    \
+    if (BJ >= 2) *reinterpret_cast<float4*>(Bs_ + (r0 + RPP) * CLD + kq * 4) = pb1_##S;                     \
     if (BJ == 4) {                                                                                      \
-      *reinterpret_cast<float4*>(Bs_ + (r0 + 2 * RPP) * CLD + kq * 4) = pb2;                            \
-      *reinterpret_cast<float4*>(Bs_ + (r0 + 3 * RPP) * CLD + kq * 4) = pb3;                            \
+      *reinterpret_cast<float4*>(Bs_ + (r0 + 2 * RPP) * CLD + kq * 4) = pb2_##S;                            \
+      *reinterpret_cast<float4*>(Bs_ + (r0 + 3 * RPP) * CLD + kq * 4) = pb3_##S;                            \
     }                                                                                                   \
   }
 
@@ -199,92 +296,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     const int pr = ((int)blockIdx.x >> 8) & 3;
     if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 3) __builtin_amdgcn_s_setprio(3);
   }
-  SSG_GLOAD(0)
-  SSG_LSTORE(0)
+  // Branch-free pipeline: the tile index of a prefetch is clamped to the last tile (a harmless reload) and the
+  // stage write after the last tile is redundant, so no load or register definition sits under a condition
+  // (hipcc otherwise waits for the loads at the join).
+  const float* Arow0 = lds + (wm * WM + l32) * CLD;
+  const float* Brow0 = lds + BM * CLD + (wn * WN + l32) * CLD;
+  SSG_GLOAD(0, 0)
+  SSG_LSTORE(0, 0)
+  if (PF2) { const int k1 = min(1, nk - 1); SSG_GLOAD(k1, 1) }
   __syncthreads();
-  for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk) SSG_GLOAD(kt + 1)        // HBM/L2 latency hides under this tile's MFMAs
-    const float* As = lds + (kt & 1) * STAGE;
-    const float* Bs = As + BM * CLD;
-    if constexpr (SPLIT) {
-      // one k-step = 16 channels = two 32-byte [hi8|lo8] groups; half-wave h takes group 2s+h (A and W alike)
-      constexpr int KS = CBK / 16;
-      v8h ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
-#pragma unroll
-      for (int i = 0; i < MT; i++) {
-        const float* q = As + (wm * WM + i * 32 + l32) * CLD + h * 8;
-        ah[0][i] = *reinterpret_cast<const v8h*>(q); al[0][i] = *reinterpret_cast<const v8h*>(q + 4);
-      }
-#pragma unroll
-      for (int j = 0; j < NT; j++) {
-        const float* q = Bs + (wn * WN + j * 32 + l32) * CLD + h * 8;
-        bh[0][j] = *reinterpret_cast<const v8h*>(q); bl[0][j] = *reinterpret_cast<const v8h*>(q + 4);
-      }
-#pragma unroll
-      for (int g = 0; g < KS; g++) {
-        const int cur = g & 1, nxt = cur ^ 1;
-        if (g + 1 < KS) {
-#pragma unroll
-          for (int i = 0; i < MT; i++) {
-            const float* q = As + (wm * WM + i * 32 + l32) * CLD + (g + 1) * 16 + h * 8;
-            ah[nxt][i] = *reinterpret_cast<const v8h*>(q); al[nxt][i] = *reinterpret_cast<const v8h*>(q + 4);
-          }
-#pragma unroll
-          for (int j = 0; j < NT; j++) {
-            const float* q = Bs + (wn * WN + j * 32 + l32) * CLD + (g + 1) * 16 + h * 8;
-            bh[nxt][j] = *reinterpret_cast<const v8h*>(q); bl[nxt][j] = *reinterpret_cast<const v8h*>(q + 4);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[cur][j], al[cur][i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-          for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[cur][j], ah[cur][i], acc[i][j], 0, 0, 0);
-      }
-    } else {
-    // fragments for k-group g+1 are fetched from LDS while the MFMAs of group g run
-    float4 a[2][MT], b[2][NT];
-#pragma unroll
-    for (int i = 0; i < MT; i++) a[0][i] = *reinterpret_cast<const float4*>(As + (wm * WM + i * 32 + l32) * CLD + h * 4);
-#pragma unroll
-    for (int j = 0; j < NT; j++) b[0][j] = *reinterpret_cast<const float4*>(Bs + (wn * WN + j * 32 + l32) * CLD + h * 4);
-#pragma unroll
-    for (int g = 0; g < CBK / 8; g++) {
-      const int cur = g & 1, nxt = cur ^ 1;
-      if (g + 1 < CBK / 8) {
-#pragma unroll
-        for (int i = 0; i < MT; i++) a[nxt][i] = *reinterpret_cast<const float4*>(As + (wm * WM + i * 32 + l32) * CLD + (g + 1) * 8 + h * 4);
-#pragma unroll
-        for (int j = 0; j < NT; j++) b[nxt][j] = *reinterpret_cast<const float4*>(Bs + (wn * WN + j * 32 + l32) * CLD + (g + 1) * 8 + h * 4);
-      }
-      // consecutive MFMAs hit different accumulators (each one is revisited every MT*NT issues)
-#pragma unroll
-      for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].x, a[cur][i].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].y, a[cur][i].y, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].z, a[cur][i].z, acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MT; i++)
-#pragma unroll
-        for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[cur][j].w, a[cur][i].w, acc[i][j], 0, 0, 0);
+  if constexpr (SPLIT) {
+    SplitFrags<MT, NT> f0, f1;
+    split_load_frags<MT, NT, CLD>(Arow0, Brow0, h * 8, f0);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {            // unrolled by two so that the register set of a tile is static
+      { const int kn = min(kt + 2, nk - 1); SSG_GLOAD(kn, 0) }
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch at the top: hipcc otherwise sinks the weight loads to just before their use
+      split_tile_mma<MT, NT, CLD, CBK>(Arow0, Brow0, h, f0, f1, acc, [&]() { SSG_LSTORE(1, 1) });
+      __syncthreads();
+      split_load_frags<MT, NT, CLD>(Arow0 + STAGE, Brow0 + STAGE, h * 8, f0);   // in flight while the loads below are issued
+      { const int kn = min(kt + 3, nk - 1); SSG_GLOAD(kn, 1) }
+      __builtin_amdgcn_sched_barrier(0);
+      split_tile_mma<MT, NT, CLD, CBK>(Arow0 + STAGE, Brow0 + STAGE, h, f0, f1, acc, [&]() { SSG_LSTORE(0, 0) });
+      __syncthreads();
+      split_load_frags<MT, NT, CLD>(Arow0, Brow0, h * 8, f0);
     }
+    if (kt < nk) {                            // odd tile count: the last tile sits in stage 0
+      split_tile_mma<MT, NT, CLD, CBK>(Arow0, Brow0, h, f0, f1, acc, []() {});
+      __syncthreads();
     }
-    if (kt + 1 < nk) SSG_LSTORE((kt + 1) & 1) // other buffer: its readers finished before the last barrier
-    __syncthreads();
+  } else {
+    for (int kt = 0; kt < nk; kt++) {
+      { const int kn = min(kt + 1, nk - 1); SSG_GLOAD(kn, 0) }   // HBM/L2 latency hides under this tile's MFMAs
+      // stage write into the other buffer (its readers finished before the last barrier)
+      conv_tile_mma<MT, NT, CLD, CBK>(Arow0 + (kt & 1) * STAGE, Brow0 + (kt & 1) * STAGE, h, acc, [&]() { SSG_LSTORE((kt + 1) & 1, 0) });
+      __syncthreads();
+    }
   }
 
 #undef SSG_LOAD_A
@@ -603,14 +650,24 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
   if (split) {
     if constexpr (CIN4) { ssg_set_error("conv: the 4-channel stem takes fp32 pixels"); return SSG_ERR_INVALID; }
     else {
-      static int sbk16 = -1;
+      static int sbk16 = -1;   // SSG_SPLIT_BK16=<K>: reductions of at most K use BK=16 stages
       if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 0; }
-      if (!p.in2 && sbk16) return launch_conv_bk<BM, BN, WM, WN, false, 16, true>(p, stream);
+      if (!p.in2 && p.Kpad <= sbk16) return launch_conv_bk<BM, BN, WM, WN, false, 16, true>(p, stream);
       return launch_conv_bk<BM, BN, WM, WN, false, 32, true>(p, stream);
     }
   }
   if (!p.in2 && p.Kpad <= bk16_max) return launch_conv_bk<BM, BN, WM, WN, CIN4, 16, false>(p, stream);
   return launch_conv_bk<BM, BN, WM, WN, CIN4, 32, false>(p, stream);
+}
+
+// Few 128x128 tiles (deep layers: M = B*8*4) leave one workgroup per CU with nothing to overlap its staging
+// with; 128x64 tiles double the workgroup count.  SSG_SPLIT_BN64_MAXTILES=<T>: use them below T tiles.
+static bool conv_prefers_bn64(const ConvParams& p, bool split) {
+  static int maxtiles = -1;
+  if (maxtiles < 0) { const char* e = getenv("SSG_SPLIT_BN64_MAXTILES"); maxtiles = e ? atoi(e) : 0; }
+  if (!split) return false;
+  const int tiles = ((p.M + 127) / 128) * (p.Cout / 128);
+  return tiles < maxtiles;
 }
 
 // Conv2d(bias folded from eval BatchNorm) + optional residual add + optional ReLU, NHWC fp32.
@@ -646,7 +703,7 @@ extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bia
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
   p.nk1 = p.Kpad / 16;   // no second input: every k-tile (of either BK) reads `in`
   if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);
-  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
+  return (Cout % 128 == 0 && !conv_prefers_bn64(p, split)) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
 }
 
 extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W,
@@ -676,7 +733,7 @@ extern "C" int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const vo
   p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0; p.tilemin = nullptr; p.tmin_ld = 0;   // dual input stays on BK=32 (nk1 counts 32-wide tiles)
   p.out_split = (flags & 2) ? 1 : 0; p.res_split = p.out_split; p.acc_scale = acc_scale;
   const bool split = (flags & 1) != 0;
-  return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
+  return (Cout % 128 == 0 && !conv_prefers_bn64(p, split)) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
 }
 
 extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W,

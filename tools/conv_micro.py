@@ -8,12 +8,22 @@ import ssg_amd
 from ssg_amd import _lib
 from ssg_amd._lib import check, ptr, stream
 
+SPLIT = "split" in sys.argv
+
+
 def run(B, H, W, Cin, Cout, k, stride, pad, res, reps=20):
     L = _lib.lib(); dev = torch.device("cuda", 0)
     x = torch.randn(B, H, W, Cin, device=dev); w = torch.randn(Cout, k * k * Cin, device=dev) * 0.02; b = torch.randn(Cout, device=dev)
     OH = (H + 2 * pad - k) // stride + 1; OW = (W + 2 * pad - k) // stride + 1
     out = torch.empty(B, OH, OW, Cout, device=dev); r = torch.randn_like(out) if res else None
-    f = lambda: check(L.ssg_conv2d_nhwc_f32(ptr(x), ptr(w), ptr(b), ptr(r), ptr(out), B, H, W, Cin, Cout, k, k, stride, pad, 1, stream()), "conv")
+    flags, sc = 0, 1.0
+    if SPLIT:
+        from ssg_amd.resnet import _h8l8
+        xs = torch.empty_like(x); check(L.ssg_h8l8_encode(ptr(x), ptr(xs), x.numel(), 1.0, stream()), "enc"); x = xs
+        w = _h8l8(w.cpu() * 256.0).to(dev); sc = 1.0 / 256.0; flags = 3
+        if res:
+            rs = torch.empty_like(r); check(L.ssg_h8l8_encode(ptr(r), ptr(rs), r.numel(), 1.0, stream()), "enc"); r = rs
+    f = lambda: check(L.ssg_conv2d_nhwc_x(ptr(x), ptr(w), ptr(b), ptr(r), ptr(out), B, H, W, Cin, Cout, k, k, stride, pad, 1, flags, sc, stream()), "conv")
     f(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -25,6 +35,10 @@ def run(B, H, W, Cin, Cout, k, stride, pad, res, reps=20):
 
 if __name__ == "__main__":
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
-    if cfg == "c3": run(512, 16, 8, 256, 256, 3, 1, 1, False, 40)
-    elif cfg == "c1": run(512, 16, 8, 1024, 256, 1, 1, 0, False, 40)
-    elif cfg == "e1": run(512, 64, 32, 64, 256, 1, 1, 0, True, 40)
+    B = 256
+    if cfg == "c3": run(B, 16, 8, 256, 256, 3, 1, 1, False, 40)
+    elif cfg == "c1": run(B, 16, 8, 1024, 256, 1, 1, 0, False, 40)
+    elif cfg == "e1": run(B, 64, 32, 64, 256, 1, 1, 0, True, 40)
+    elif cfg == "c3b": run(B, 32, 16, 128, 128, 3, 1, 1, False, 40)
+    elif cfg == "c3a": run(B, 64, 32, 64, 64, 3, 1, 1, False, 40)
+    elif cfg == "l4": run(B, 8, 4, 512, 512, 3, 1, 1, False, 40)
