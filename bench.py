@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_FP16_MFMA_TF = 2516.6    # MI355X_MICROARCH.md: dense fp16/bf16 matrix peak (v_mfma_f32_32x32x16_f16)
 PEAK_FP64_MFMA_TF = 78.6      # SURVEY.md 8d / BASELINE.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 FLOP_PER_IMAGE = 10.68e9      # 2 forwards x 2 x 2.669 GMAC
@@ -130,6 +131,7 @@ def main():
 
     # ---- inputs resident in HBM before the timed region
     model = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1).cuda(local).eval()
+    precision = model.precision
     t_lo, t_hi = sdist.shard_bounds(args.N, rank, world)
     s_lo, s_hi = sdist.shard_bounds(args.Ns, rank, world)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -193,14 +195,25 @@ def main():
         return
     n_img = args.N + args.Ns
     # ---- roofline of the dominant kernel: implicit-GEMM convolution on the fp32 matrix cores
-    convs = [tot[k] for k in ("ssg_conv2d_nhwc_f32", "ssg_conv1x1_dual_nhwc_f32") if k in tot]
+    convs = [tot[k] for k in ("ssg_conv2d_nhwc_x", "ssg_conv1x1_dual_nhwc_x", "ssg_conv2d_nhwc_f32", "ssg_conv1x1_dual_nhwc_f32") if k in tot]
     n_conv, ms_conv = (sum(c[0] for c in convs), sum(c[1] for c in convs)) if convs else (1, float("nan"))
     imgs_rank = (t_hi - t_lo) + (s_hi - s_lo)
     conv_tf = imgs_rank * args.steps * FLOP_PER_IMAGE / (ms_conv * 1e-3) / 1e12
-    roof = {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2, 53 convs x 2 orientations per image)",
-            "achieved": round(conv_tf, 2), "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s", "frac": round(conv_tf / PEAK_FP32_MFMA_TF, 4),
+    split = precision == "split"
+    # split-half path: every fp32 multiply-add is three fp16-MFMA multiply-adds (xh*wh + xh*wl + xl*wh), so the
+    # fp32-equivalent ceiling of the fp16 matrix cores is a third of their dense peak; frac = executed/peak either way
+    peak = PEAK_FP16_MFMA_TF / 3.0 if split else PEAK_FP32_MFMA_TF
+    roof = {"bound": "mfma",
+            "kernel": ("conv_igemm_kernel, split-half fp32 on v_mfma_f32_32x32x16_f16 (3 MFMA products per multiply, fp32 accumulate; stem on "
+                       "v_mfma_f32_32x32x2_f32), 53 convs x 2 orientations per image" if split else
+                       "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2, 53 convs x 2 orientations per image)"),
+            "achieved": round(conv_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
             "traffic": None, "launches": n_conv, "avg_launch_ms": round(ms_conv / max(n_conv, 1), 4),
             "algorithmic": "10.68 GFLOP per image (2 forwards x 5.34 GFLOP) x %d images per rank-step" % imgs_rank}
+    if split:
+        roof["peak_is"] = "fp16 dense MFMA peak %.1f / 3 products per fp32 multiply" % PEAK_FP16_MFMA_TF
+        roof["executed_fp16_tflops"] = round(3.0 * conv_tf, 1)
+        roof["vs_fp32_mfma_peak"] = round(conv_tf / PEAK_FP32_MFMA_TF, 3)
     nn2 = 2.0 * nrows * args.N   # bytes of one half row block
     hbm = []
     for k, byt, what in (("ssg_topk_rank", nn2, "reads D (2*N^2 B)"), ("ssg_jaccard_rows", nn2, "writes J' (2*N^2 B)"),
@@ -234,7 +247,8 @@ def main():
         "metric": "images/s embed + s/iter for NxN rerank+DBSCAN, N=16k, 1/2/4/8 GPU",
         "value": round(n_img / (ms_step * 1e-3), 2), "unit": "images/s (embedded + grouped per wall second, whole iteration)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f32 (embed, fp32 MFMA) / f64+f16 (distance, re-rank: fp64 MFMA, half semantics)",
+        "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (embed: split-half operands hi+lo on fp16 MFMA, fp32 accumulate, 6e-8 max error vs the fp32 reference features)" if split else
+                                                     "f32 (embed, fp32 MFMA)") + " / f64+f16 (distance, re-rank: fp64 MFMA, half semantics)",
         "data": "synthetic: N(0,1) 256x128 images + seeded Kaiming ResNet-50 weights for the embed leg; clustered unit-norm 2048-d embeddings "
                 "(16 per identity) for the grouping leg (random-init backbone features are degenerate: reid/rerank.py:40 NaN path)",
         "config": {"workload": "BASELINE configs[1]+[2]: N=%d target + Ns=%d source images -> ResNet-50 2048-d embed (orig+flip) -> "

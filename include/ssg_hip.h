@@ -126,7 +126,8 @@ int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int
 
 /* ---- K1/K2 ResNet-50 embedding forward (reid/models/resnet.py:86-111, reid/evaluators.py:18-60) */
 /* Conv2d with eval-BatchNorm folded into (w, bias) + optional residual add + optional ReLU, NHWC
- * float32 on the fp32 matrix cores.  in [B,H,W,Cin]; w [Cout][Kpad], k = (r*KW+s)*Cin + c, rows
+ * float32 on the fp32 matrix cores.  in [B,H,W,Cin]; w [Cout][Kpad], k = ((c/32)*KH*KW + r*KW+s)*32 + c%32
+ * (32-channel chunks outermost: the taps of a chunk re-read cached pixels; stem: k = (r*KW+s)*4 + c), rows
  * zero-padded to Kpad (multiple of 32); res/out [B,OH,OW,Cout].  Cin % 32 == 0 or Cin == 4 (stem:
  * RGB0 pixels, Kpad = 32*ceil(KH*KW/8)); Cout % 64 == 0.  (cuDNN conv+BN+ReLU of base.py:57-93) */
 int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W, int Cin,

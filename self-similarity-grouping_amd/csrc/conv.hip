@@ -6,7 +6,8 @@
 //
 // Every convolution is an implicit GEMM  out[m, n] = sum_k A[m, k] * W[n, k]  with
 //   m = output pixel (b, oh, ow)   -- NHWC activations, so a pixel's channels are contiguous
-//   n = output channel             -- weights stored [Cout][KH*KW*Cin] (k = (r, s, c))
+//   n = output channel             -- weights stored [Cout][K], k = ((c/32)*KH*KW + r*KW + s)*32 + c%32:
+//                                     channel chunks outermost, so that the taps of a chunk re-read cached pixels
 // on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).  Eval-mode BatchNorm is folded into
 // the weights/bias on the host; bias + residual add + ReLU are fused into the epilogue, so a
 // bottleneck block costs 3 (4 with downsample) launches and no elementwise passes.
@@ -176,13 +177,14 @@ __device__ __forceinline__ void conv_tile_mma(const float* Arow, const float* Br
 // with 4 consecutive output channels of one pixel per accumulator quad: bias/residual/output
 // move as float4.
 template <int BM, int BN, int WM, int WN, bool CIN4, int CBK, bool SPLIT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
+__global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) == 4 ? 2 : 1) void conv_igemm_kernel(ConvParams p) {
   constexpr int WCOLS = BN / WN;
-  static_assert((BM / WM) * WCOLS == 4, "4 waves per workgroup");
+  constexpr int NWAVES = (BM / WM) * WCOLS, NTHREADS = NWAVES * 64;
+  static_assert(NWAVES == 4 || NWAVES == 8, "4 or 8 waves per workgroup");
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int CLD = CBK + 4;              // LDS row pitch (floats)
   constexpr int KQ = CBK / 4;               // float4 per tile row
-  constexpr int RPP = 256 / KQ;             // tile rows staged per pass
+  constexpr int RPP = NTHREADS / KQ;        // tile rows staged per pass
   constexpr int AJ = BM / RPP, BJ = BN / RPP; // float4 loads per thread for the A / W tile
   constexpr int STAGE = (BM + BN) * CLD;    // floats per LDS stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // one declaration shared by the unity TU
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
 
   // Staging state is kept in NAMED scalars, not arrays: hipcc left `float4 pb[BJ]` in scratch
   // memory (the prefetch then waited on every load to bounce it through the stack).
-  static_assert((AJ == 4 && (BJ == 4 || BJ == 2)) || (AJ == 2 && (BJ == 2 || BJ == 1)), "staging code is written for BM=128, BN in {64,128}, BK in {16,32}");
+  static_assert((AJ == 4 || AJ == 2) && (BJ == 4 || BJ == 2 || BJ == 1), "staging code is written for 2 or 4 A rows and 1, 2 or 4 W rows per thread");
   int ab0, ab1, ab2 = -1, ab3 = -1, ah0, ah1, ah2 = 0, ah3 = 0, aw0, aw1, aw2 = 0, aw3 = 0;
 #define SSG_ROW_INIT(J)                                                            \
   {                                                                                \
@@ -249,7 +251,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     if ((KT) < p.nk1) {                                                                                 \
       int r, s_, c;                                                                                     \
       if (CIN4) { const int tap = (KT) * KQ + kq; r = tap / p.KW; s_ = tap - r * p.KW; c = 0; if (tap >= p.KH * p.KW) r = -100000; /* -> !ok */ } \
-      else { const int k0 = (KT) * CBK; const int tap = k0 / p.Cin; r = tap / p.KW; s_ = tap - r * p.KW; c = k0 - tap * p.Cin + kq * 4; } \
+      else { /* k order = [32-channel chunk][tap][32]: the 9 taps of a chunk re-read the same few KB (L1/L2 hits) */ \
+        const int ntap = p.KH * p.KW, kt32 = (CBK == 32) ? (KT) : ((KT) >> 1), half = (CBK == 32) ? 0 : ((KT) & 1) * 16; \
+        const int chunk = kt32 / ntap, tap = kt32 - chunk * ntap; r = tap / p.KW; s_ = tap - r * p.KW; c = chunk * 32 + half + kq * 4; } \
       SSG_LOAD_A(0, S) SSG_LOAD_A(1, S) if (AJ == 4) { SSG_LOAD_A(2, S) SSG_LOAD_A(3, S) }              \
     } else {                                                                                            \
       const int c2_ = ((KT) - p.nk1) * CBK + kq * 4;                                                    \
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvParams p) {
     // store instruction covers whole WN*4-byte row segments (the stage buffers are free after the last barrier).
     constexpr int EP = WN + 4;                 // patch pitch (floats): EP/4 odd -> conflict-free b128 both ways
     constexpr int CPR = WN / 4, RPI = 64 / CPR, ITS = 32 / RPI;
-    static_assert(4 * 32 * EP <= 2 * (BM + BN) * CLD, "epilogue patch fits in the stage buffers");
+    static_assert(NWAVES * 32 * EP <= 2 * (BM + BN) * CLD, "epilogue patch fits in the stage buffers");
     float* patch = lds + wave * (32 * EP);
     const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
     const int col = tn * BN + wn * WN + chunk * 4;
@@ -637,7 +641,7 @@ static int launch_conv_bk(const ConvParams& p, hipStream_t stream) {
     if (rc) return rc;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK, SPLIT>), dim3(tiles), dim3(256), lds, stream, p);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, CIN4, CBK, SPLIT>), dim3(tiles), dim3((BM / WM) * (BN / WN) * 64), lds, stream, p);
   return ssg_check_hip(hipGetLastError(), "conv_igemm_kernel");
 }
 // BK=16 stages (default): half the LDS of BK=32 -> 3 instead of 2 co-resident workgroups per CU, so one
@@ -651,7 +655,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
     if constexpr (CIN4) { ssg_set_error("conv: the 4-channel stem takes fp32 pixels"); return SSG_ERR_INVALID; }
     else {
       static int sbk16 = -1;   // SSG_SPLIT_BK16=<K>: reductions of at most K use BK=16 stages
-      if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 0; }
+      if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 256; }
       if (!p.in2 && p.Kpad <= sbk16) return launch_conv_bk<BM, BN, WM, WN, false, 16, true>(p, stream);
       return launch_conv_bk<BM, BN, WM, WN, false, 32, true>(p, stream);
     }
@@ -662,16 +666,26 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
 
 // Few 128x128 tiles (deep layers: M = B*8*4) leave one workgroup per CU with nothing to overlap its staging
 // with; 128x64 tiles double the workgroup count.  SSG_SPLIT_BN64_MAXTILES=<T>: use them below T tiles.
+// 128x256 tiles (8 waves) read the pixel tile once for 256 output channels: 3/4 of the global->LDS bytes per flop of
+// the 128x128 tile, which is what bounds the split kernels.  SSG_SPLIT_WIDE_MINTILES=<T>: use them when at least T
+// such tiles exist (0 = never).
+static bool conv_prefers_wide(const ConvParams& p, bool split) {
+  static int mintiles = -1;
+  if (mintiles < 0) { const char* e = getenv("SSG_SPLIT_WIDE_MINTILES"); mintiles = e ? atoi(e) : 256; }
+  if (!split || mintiles <= 0 || (p.Cout % 256)) return false;
+  return ((p.M + 127) / 128) * (p.Cout / 256) >= mintiles;
+}
+
 static bool conv_prefers_bn64(const ConvParams& p, bool split) {
   static int maxtiles = -1;
-  if (maxtiles < 0) { const char* e = getenv("SSG_SPLIT_BN64_MAXTILES"); maxtiles = e ? atoi(e) : 0; }
+  if (maxtiles < 0) { const char* e = getenv("SSG_SPLIT_BN64_MAXTILES"); maxtiles = e ? atoi(e) : 300; }
   if (!split) return false;
   const int tiles = ((p.M + 127) / 128) * (p.Cout / 128);
   return tiles < maxtiles;
 }
 
 // Conv2d(bias folded from eval BatchNorm) + optional residual add + optional ReLU, NHWC fp32.
-//   in  [B,H,W,Cin]; w [Cout][Kpad] with k = (r*KW + s)*Cin + c, rows zero-padded to Kpad
+//   in  [B,H,W,Cin]; w [Cout][Kpad] with k = ((c/32)*KH*KW + r*KW + s)*32 + c%32, rows zero-padded to Kpad
 //   (multiple of 32); bias [Cout]; res/out [B,OH,OW,Cout].  Cin % 32 == 0, or Cin == 4 (stem:
 //   RGB0 pixels, Kpad = 32*ceil(KH*KW/8)).  Cout % 64 == 0.
 //
@@ -703,6 +717,7 @@ extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bia
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
   p.nk1 = p.Kpad / 16;   // no second input: every k-tile (of either BK) reads `in`
   if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);
+  if (conv_prefers_wide(p, split)) return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
   return (Cout % 128 == 0 && !conv_prefers_bn64(p, split)) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
 }
 
@@ -733,6 +748,7 @@ extern "C" int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const vo
   p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0; p.tilemin = nullptr; p.tmin_ld = 0;   // dual input stays on BK=32 (nk1 counts 32-wide tiles)
   p.out_split = (flags & 2) ? 1 : 0; p.res_split = p.out_split; p.acc_scale = acc_scale;
   const bool split = (flags & 1) != 0;
+  if (conv_prefers_wide(p, split)) return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
   return (Cout % 128 == 0 && !conv_prefers_bn64(p, split)) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
 }
 

@@ -106,6 +106,13 @@ def _weight_scale(w):
     return 256.0 if mx == 0 else float(min(256.0, 2.0 ** math.floor(math.log2(16384.0 / mx))))
 
 
+def pack_weight_khwc(w):
+    """[Cout, KH, KW, Cin] (Cin % 32 == 0) -> [Cout, K] in the kernels' reduction order
+    k = ((c // 32) * KH*KW + r*KW + s) * 32 + c % 32  (include/ssg_hip.h, ssg_conv2d_nhwc_f32)."""
+    cout, kh, kw, cin = w.shape
+    return w.reshape(cout, kh * kw, cin // 32, 32).permute(0, 2, 1, 3).reshape(cout, kh * kw * cin).contiguous()
+
+
 def _fold(sd, conv_name, bn_name, stride, pad, device, split=False):
     """conv + eval BatchNorm -> (w [Cout][Kpad] with k=(r,s,c), bias [Cout]); float64 fold.
     split=True: w in the h8l8 split-half layout, pre-multiplied by 1/acc_scale."""
@@ -123,7 +130,7 @@ def _fold(sd, conv_name, bn_name, stride, pad, device, split=False):
         kpad = 32 * ((k * k + 7) // 8)
         w = torch.nn.functional.pad(w.reshape(cout, k * k * 4), (0, kpad - k * k * 4))
     else:
-        w = w.reshape(cout, k * k * cin)
+        w = pack_weight_khwc(w)
     f = _FoldedConv()
     w = w.float().contiguous()
     f.split, f.acc_scale = bool(split), 1.0

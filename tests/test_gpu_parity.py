@@ -296,7 +296,8 @@ def test_conv_vs_torch(cfg, L, dev):
         wk = torch.nn.functional.pad(wk, (0, 32 * ((k * k + 7) // 8) - k * k * 4)).contiguous()
         cin = 4
     else:
-        xin = x.permute(0, 2, 3, 1).contiguous(); wk = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous(); cin = Cin
+        from ssg_amd.resnet import pack_weight_khwc
+        xin = x.permute(0, 2, 3, 1).contiguous(); wk = pack_weight_khwc(w.permute(0, 2, 3, 1)); cin = Cin
     OH, OW = ref.shape[2], ref.shape[3]
     out = torch.empty(B, OH, OW, Cout, device=dev)
     xin, wk, bias_d = xin.to(dev), wk.to(dev), bias.to(dev)
@@ -335,7 +336,8 @@ def test_conv_split_half_vs_fp64(cfg, L, dev):
         ref = ref + res.double()
     if relu:
         ref = torch.relu(ref)
-    xin = x.permute(0, 2, 3, 1).contiguous().to(dev); wk = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    from ssg_amd.resnet import pack_weight_khwc
+    xin = x.permute(0, 2, 3, 1).contiguous().to(dev); wk = pack_weight_khwc(w.permute(0, 2, 3, 1))
     OH, OW = ref.shape[2], ref.shape[3]
     bias_d = bias.to(dev)
     res_d = res.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
