@@ -150,6 +150,9 @@ int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bias, const vo
                       int Cout, int KH, int KW, int stride, int pad, int relu, int flags, float acc_scale, ssg_stream_t stream);
 int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const void* w, const float* bias, void* out, int B, int H, int W, int Cin,
                             int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, ssg_stream_t stream);
+/* stem input for the split path: [B,3,H,W] NCHW fp32 -> [B,H,W] pixels of 16 bytes [4 x half hi][4 x half lo] ("h4l4",
+ * 4th channel 0); ssg_conv2d_nhwc_x with Cin = 4 and SSG_CONV_IN_SPLIT takes these, with w in the same per-tap layout */
+int ssg_nchw_to_nhwc4_h4l4(const float* in, void* out, int B, int H, int W, int flip, ssg_stream_t stream);
 /* MaxPool2d(3,2,1) and the global/stripe average pool on h8l8 maps (the averages come out as fp32) */
 int ssg_maxpool3x3s2_h8l8(const void* in, void* out, int B, int H, int W, int C, ssg_stream_t stream);
 int ssg_gap_stripes_h8l8(const void* in, float* out, int B, int H, int W, int C, int num_split, ssg_stream_t stream);

@@ -81,17 +81,28 @@ __device__ __forceinline__ int conv_xcd_remap(int b, int nwg) {
 // MFMAs of step s run, and the first step of a tile right after the barrier that published it.
 template <int MT, int NT> struct SplitFrags { v8h ah[MT], al[MT], bh[NT], bl[NT]; };
 
-template <int MT, int NT, int CLD>
+typedef float v4f __attribute__((ext_vector_type(4)));
+// TAP4 (stem): a 16-byte unit is one filter tap of a 4-channel pixel, [4 x half hi][4 x half lo] ("h4l4"); the 8 hi
+// halves of a fragment are the hi parts of two consecutive taps.
+template <int MT, int NT, int CLD, bool TAP4>
 __device__ __forceinline__ void split_load_frags(const float* Arow, const float* Brow, const int kofs, SplitFrags<MT, NT>& f) {
 #pragma unroll
   for (int i = 0; i < MT; i++) {
     const float* q = Arow + i * 32 * CLD + kofs;
-    f.ah[i] = *reinterpret_cast<const v8h*>(q); f.al[i] = *reinterpret_cast<const v8h*>(q + 4);
+    if (TAP4) {
+      const float4 t0 = *reinterpret_cast<const float4*>(q), t1 = *reinterpret_cast<const float4*>(q + 4);
+      const v4f hi = {t0.x, t0.y, t1.x, t1.y}, lo = {t0.z, t0.w, t1.z, t1.w};
+      f.ah[i] = __builtin_bit_cast(v8h, hi); f.al[i] = __builtin_bit_cast(v8h, lo);
+    } else { f.ah[i] = *reinterpret_cast<const v8h*>(q); f.al[i] = *reinterpret_cast<const v8h*>(q + 4); }
   }
 #pragma unroll
   for (int j = 0; j < NT; j++) {
     const float* q = Brow + j * 32 * CLD + kofs;
-    f.bh[j] = *reinterpret_cast<const v8h*>(q); f.bl[j] = *reinterpret_cast<const v8h*>(q + 4);
+    if (TAP4) {
+      const float4 t0 = *reinterpret_cast<const float4*>(q), t1 = *reinterpret_cast<const float4*>(q + 4);
+      const v4f hi = {t0.x, t0.y, t1.x, t1.y}, lo = {t0.z, t0.w, t1.z, t1.w};
+      f.bh[j] = __builtin_bit_cast(v8h, hi); f.bl[j] = __builtin_bit_cast(v8h, lo);
+    } else { f.bh[j] = *reinterpret_cast<const v8h*>(q); f.bl[j] = *reinterpret_cast<const v8h*>(q + 4); }
   }
 }
 
@@ -114,11 +125,11 @@ __device__ __forceinline__ void split_mma_step(const SplitFrags<MT, NT>& f, v16f
 
 // One K tile on the split path.  f0 already holds step 0.  `mid` (the next tile's LDS stores) is issued after the
 // first step's MFMAs, when the matrix pipe has 12 x 32 cycles of work queued.
-template <int MT, int NT, int CLD, int CBK, typename F>
+template <int MT, int NT, int CLD, int CBK, bool TAP4, typename F>
 __device__ __forceinline__ void split_tile_mma(const float* Arow, const float* Brow, const int h, SplitFrags<MT, NT>& f0, SplitFrags<MT, NT>& f1,
                                                v16f (&acc)[MT][NT], F mid) {
   constexpr int KS = CBK / 16;
-  if (KS == 2) split_load_frags<MT, NT, CLD>(Arow, Brow, 16 + h * 8, f1);
+  if (KS == 2) split_load_frags<MT, NT, CLD, TAP4>(Arow, Brow, 16 + h * 8, f1);
   __builtin_amdgcn_sched_barrier(0);
   split_mma_step<MT, NT>(f0, acc);
   __builtin_amdgcn_sched_barrier(0);
@@ -311,22 +322,22 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
   __syncthreads();
   if constexpr (SPLIT) {
     SplitFrags<MT, NT> f0, f1;
-    split_load_frags<MT, NT, CLD>(Arow0, Brow0, h * 8, f0);
+    split_load_frags<MT, NT, CLD, CIN4>(Arow0, Brow0, h * 8, f0);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {            // unrolled by two so that the register set of a tile is static
       { const int kn = min(kt + 2, nk - 1); SSG_GLOAD(kn, 0) }
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetch at the top: hipcc otherwise sinks the weight loads to just before their use
-      split_tile_mma<MT, NT, CLD, CBK>(Arow0, Brow0, h, f0, f1, acc, [&]() { SSG_LSTORE(1, 1) });
+      split_tile_mma<MT, NT, CLD, CBK, CIN4>(Arow0, Brow0, h, f0, f1, acc, [&]() { SSG_LSTORE(1, 1) });
       __syncthreads();
-      split_load_frags<MT, NT, CLD>(Arow0 + STAGE, Brow0 + STAGE, h * 8, f0);   // in flight while the loads below are issued
+      split_load_frags<MT, NT, CLD, CIN4>(Arow0 + STAGE, Brow0 + STAGE, h * 8, f0);   // in flight while the loads below are issued
       { const int kn = min(kt + 3, nk - 1); SSG_GLOAD(kn, 1) }
       __builtin_amdgcn_sched_barrier(0);
-      split_tile_mma<MT, NT, CLD, CBK>(Arow0 + STAGE, Brow0 + STAGE, h, f0, f1, acc, [&]() { SSG_LSTORE(0, 0) });
+      split_tile_mma<MT, NT, CLD, CBK, CIN4>(Arow0 + STAGE, Brow0 + STAGE, h, f0, f1, acc, [&]() { SSG_LSTORE(0, 0) });
       __syncthreads();
-      split_load_frags<MT, NT, CLD>(Arow0, Brow0, h * 8, f0);
+      split_load_frags<MT, NT, CLD, CIN4>(Arow0, Brow0, h * 8, f0);
     }
     if (kt < nk) {                            // odd tile count: the last tile sits in stage 0
-      split_tile_mma<MT, NT, CLD, CBK>(Arow0, Brow0, h, f0, f1, acc, []() {});
+      split_tile_mma<MT, NT, CLD, CBK, CIN4>(Arow0, Brow0, h, f0, f1, acc, []() {});
       __syncthreads();
     }
   } else {
@@ -507,6 +518,19 @@ __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ in, float* __rest
   }
 }
 
+// same, pixels written as split halves [h0 h1 h2 h3 | l0 l1 l2 l3] ("h4l4", 16 bytes per pixel)
+__global__ void nchw_to_nhwc4_h4l4_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int flip) {
+  const int64_t total = (int64_t)B * H * W;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(x % W); const int64_t t = x / W; const int hh = (int)(t % H); const int b = (int)(t / H);
+    const int ws = flip ? (W - 1 - w) : w;
+    const int64_t plane = (int64_t)H * W, base = (int64_t)b * 3 * plane + (int64_t)hh * W + ws;
+    uint2 hi, lo;
+    split_encode4(make_float4(in[base], in[base + plane], in[base + 2 * plane], 0.f), hi, lo);
+    reinterpret_cast<uint4*>(out)[x] = make_uint4(hi.x, hi.y, lo.x, lo.y);
+  }
+}
+
 // MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (reid/models/base.py:105); C % 4 == 0
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C, int OH, int OW) {
   const int C4 = C / 4;
@@ -652,7 +676,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
   static int bk16_max = -1;   // measured on MI355X: BK=16 wins for every ResNet-50 layer (9.1k -> 9.8k img/s)
   if (bk16_max < 0) { const char* e = getenv("SSG_CONV_BK16_MAXK"); bk16_max = e ? atoi(e) : 0x7fffffff; }
   if (split) {
-    if constexpr (CIN4) { ssg_set_error("conv: the 4-channel stem takes fp32 pixels"); return SSG_ERR_INVALID; }
+    if constexpr (CIN4) return launch_conv_bk<BM, BN, WM, WN, true, 16, true>(p, stream);   // one k-step = 4 taps
     else {
       static int sbk16 = -1;   // SSG_SPLIT_BK16=<K>: reductions of at most K use BK=16 stages
       if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 256; }
@@ -700,7 +724,7 @@ extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bia
   p.OH = (H + 2 * pad - KH) / stride + 1; p.OW = (W + 2 * pad - KW) / stride + 1;
   const int64_t M = (int64_t)B * p.OH * p.OW;
   const bool split = (flags & 1) != 0;
-  if (B <= 0 || M <= 0 || M > 0x7fffffff || (Cout % 64) || !((Cin % 32) == 0 || (Cin == 4 && !split)) || stride < 1) {
+  if (B <= 0 || M <= 0 || M > 0x7fffffff || (Cout % 64) || !((Cin % 32) == 0 || Cin == 4) || stride < 1) {
     ssg_set_error("ssg_conv2d_nhwc: unsupported shape B=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d s=%d p=%d flags=%d", B, H, W, Cin, Cout, KH, KW, stride, pad, flags);
     return SSG_ERR_INVALID;
   }
@@ -716,7 +740,7 @@ extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bia
   const bool cin4 = (Cin == 4);
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
   p.nk1 = p.Kpad / 16;   // no second input: every k-tile (of either BK) reads `in`
-  if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream) : launch_conv<128, 64, 64, 32, true>(p, stream);
+  if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream, split) : launch_conv<128, 64, 64, 32, true>(p, stream, split);
   if (conv_prefers_wide(p, split)) return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
   return (Cout % 128 == 0 && !conv_prefers_bn64(p, split)) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
 }
@@ -883,6 +907,13 @@ extern "C" int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int 
   if (B <= 0 || H <= 0 || W <= 0) { ssg_set_error("ssg_nchw_to_nhwc4: empty"); return SSG_ERR_INVALID; }
   hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(4096), dim3(256), 0, stream, in, out, B, H, W, flip);
   SSG_LAUNCH_CHECK("nchw_to_nhwc4_kernel");
+  return SSG_OK;
+}
+
+extern "C" int ssg_nchw_to_nhwc4_h4l4(const float* in, void* out, int B, int H, int W, int flip, hipStream_t stream) {
+  if (B <= 0 || H <= 0 || W <= 0) { ssg_set_error("ssg_nchw_to_nhwc4_h4l4: empty"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(nchw_to_nhwc4_h4l4_kernel, dim3(4096), dim3(256), 0, stream, in, (float*)out, B, H, W, flip);
+  SSG_LAUNCH_CHECK("nchw_to_nhwc4_h4l4_kernel");
   return SSG_OK;
 }
 

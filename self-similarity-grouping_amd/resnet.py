@@ -100,6 +100,15 @@ def _h8l8(v):
     return g.reshape(rows, 2 * K).contiguous().view(torch.float32)
 
 
+def _h4l4(v):
+    """stem layout: per filter tap (4 channels) 16 bytes = [4 x half hi][4 x half lo]"""
+    rows, K = v.shape
+    hi = v.half()
+    lo = (v - hi.float()).half()
+    g = torch.stack([hi.view(rows, K // 4, 4), lo.view(rows, K // 4, 4)], dim=2)      # [rows, K/4, 2, 4]
+    return g.reshape(rows, 2 * K).contiguous().view(torch.float32)
+
+
 def _weight_scale(w):
     """power of two that lifts the weights towards 1 (out of the half subnormals) without overflow"""
     mx = float(w.abs().max())
@@ -135,10 +144,8 @@ def _fold(sd, conv_name, bn_name, stride, pad, device, split=False):
     w = w.float().contiguous()
     f.split, f.acc_scale = bool(split), 1.0
     if split:
-        if cin == 4:
-            raise ValueError("the stem convolution takes fp32 pixels")
         sc = _weight_scale(w)
-        w = _h8l8(w * sc)
+        w = _h4l4(w * sc) if cin == 4 else _h8l8(w * sc)
         f.acc_scale = 1.0 / sc
     f.w = w.to(device); f.bias = bias.float().contiguous().to(device)
     f.cin, f.cout, f.k, f.stride, f.pad = cin, cout, k, stride, pad
@@ -217,7 +224,7 @@ class ResNet:
             raise _lib.SSGError("the embedder runs on the GPU only: call model.cuda() first (no CPU fallback)")
         sd, dev = self._sd, self.device
         sp = self.precision == "split"
-        net = dict(stem=_fold(sd, "base.conv1", "base.bn1", 2, 3, dev), blocks=[], split=sp)
+        net = dict(stem=_fold(sd, "base.conv1", "base.bn1", 2, 3, dev, split=sp), blocks=[], split=sp)
         for blk in _arch(self.depth):
             p = blk["prefix"]
             if blk["down"]:
@@ -275,7 +282,10 @@ class ResNet:
         if C != 3:
             raise ValueError("expected RGB images [B,3,H,W]")
         x4 = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
-        check(L.ssg_nchw_to_nhwc4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4")
+        if sp:
+            check(L.ssg_nchw_to_nhwc4_h4l4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4_h4l4")
+        else:
+            check(L.ssg_nchw_to_nhwc4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4")
         y = self._conv(L, x4, net["stem"], out_split=sp)
         _, H2, W2, _ = y.shape
         p = torch.empty((B, (H2 + 1) // 2, (W2 + 1) // 2, 64), dtype=torch.float32, device=self.device)
