@@ -58,9 +58,12 @@ int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const float* src
 /* Same result by filter-and-refine: a float32 MFMA pass bounds every target-source distance per row and
  * 8-source granule, float64 re-evaluates only the granules within `tol` of the row's bound (tol >= float32
  * error of the bound).  src has Ns_pad rows (rows >= Ns padding), d % 32 == 0, Ns_pad % 128 == 0;
- * ws = nrows + Ns_pad + nrows*Ns_pad/8 floats (row norms + the per-row bounds of every 8-source granule). */
-int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float* ws,
-                               uint32_t* rowmin, ssg_stream_t stream);
+ * ws = nrows + Ns_pad + nrows*Ns_pad/8 floats (row norms + the per-row bounds of every 8-source granule).
+ * scale_t, scale_s > 0: the bound pass runs on the fp16 matrix cores over split-half (h8l8) copies of
+ * tgt*scale_t and src*scale_s (powers of two with max|x|*scale < 65504; ws grows by (nrows + Ns_pad)*d floats)
+ * and tol must cover that pass's error; 0 = float32 MFMA bound pass. */
+int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t,
+                               float scale_s, float* ws, uint32_t* rowmin, ssg_stream_t stream);
 /* v = half(1-exp(-rowmin)); *max_bits = max(v); v /= max(v)   (rerank.py:38-40).  A zero
  * max means the reference would produce NaNs (0/0): the caller must raise. */
 int ssg_source_vec_finish(const uint32_t* rowmin, int N, uint16_t* v, uint32_t* max_bits, ssg_stream_t stream);

@@ -879,9 +879,11 @@ __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restr
 // of the row's bound.  Same result as ssg_source_rowmin_f16 (exact min of the half-rounded float64 distances)
 // whenever tol >= the float32 error of the bound (callers pass 8*d*2^-24*max|x|*max|y| + margin).
 // tgt [nrows,d], src [Ns_pad,d] (rows >= Ns are padding), d % 32 == 0, Ns_pad % 128 == 0.
-// ws: nrows + Ns_pad + nrows*(Ns_pad/8) floats.
-extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float* ws,
-                                          uint32_t* rowmin, hipStream_t stream) {
+// ws: nrows + Ns_pad + nrows*(Ns_pad/8) floats, plus (nrows + Ns_pad)*d floats when scale_t, scale_s > 0: the bound
+// pass then runs on the fp16 matrix cores over split-half copies of tgt*scale_t and src*scale_s (powers of two that
+// keep max|x|*scale < 65504); the caller's tol must cover that pass's error (3 products, 3d-term accumulation).
+extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
+                                          float* ws, uint32_t* rowmin, hipStream_t stream) {
   if (nrows <= 0 || Ns <= 0 || Ns_pad < Ns || (Ns_pad % 128) || (d % 32) || (int64_t)nrows * d * 4 > 0x7fffffffLL) {
     ssg_set_error("ssg_source_rowmin_filtered: bad shape nrows=%d Ns=%d Ns_pad=%d d=%d", nrows, Ns, Ns_pad, d);
     return SSG_ERR_INVALID;
@@ -891,12 +893,21 @@ extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, in
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
   if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
+  const bool split = scale_t > 0.f && scale_s > 0.f;
+  const float* gt = tgt; const float* gs = src;
+  if (split) {   // bound pass on the fp16 matrix cores: split-half copies of both operand sets (scaled into the half range)
+    float* ts = tilemin + (int64_t)nrows * ntiles; float* ss = ts + (int64_t)nrows * d;
+    hipLaunchKernelGGL(h8l8_encode_kernel, dim3(4096), dim3(256), 0, stream, tgt, ts, (int64_t)nrows * d / 8, scale_t);
+    hipLaunchKernelGGL(h8l8_encode_kernel, dim3(4096), dim3(256), 0, stream, src, ss, (int64_t)Ns_pad * d / 8, scale_s);
+    gt = ts; gs = ss;
+  }
   ConvParams p;
-  p.in = tgt; p.w = src; p.bias = colterm; p.res = nullptr; p.out = nullptr;
+  p.in = gt; p.w = gs; p.bias = colterm; p.res = nullptr; p.out = nullptr;
   p.B = nrows; p.H = 1; p.W = 1; p.Cin = d; p.Cout = Ns_pad; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
   p.M = nrows; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)nrows * d * 4);
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles; p.out_split = p.res_split = 0; p.acc_scale = 1.f;
-  int rc = launch_conv<128, 128, 64, 64, false>(p, stream);   // wave tile = 64 columns = one tilemin entry
+  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles; p.out_split = p.res_split = 0;
+  p.acc_scale = split ? 1.f / (scale_t * scale_s) : 1.f;
+  int rc = split ? launch_conv_bk<128, 128, 64, 64, false, 32, true>(p, stream) : launch_conv<128, 128, 64, 64, false>(p, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
   SSG_LAUNCH_CHECK("source_refine_kernel");

@@ -77,9 +77,10 @@ def _as_dev_f32(x, device):
 def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
     """reid/rerank.py:35-40 on device -> (rowmin uint32-as-int32 [nrows]) for a row block.
 
-    Default: filter-and-refine (float32 MFMA bound per 64-source tile, float64 re-evaluation of the
-    tiles that can still hold the minimum) -- the exact minimum of the half-rounded float64 distances
-    at about half the cost of the full float64 Gram.  exact_gemm=True (or SSG_SOURCE_EXACT_GEMM=1)
+    Default: filter-and-refine (a matrix-core pass bounds every distance per 8-source granule -- split-half
+    operands on the fp16 cores, or float32 MFMA with SSG_SOURCE_BOUND=f32 -- then float64 re-evaluates the
+    granules that can still hold the minimum): the exact minimum of the half-rounded float64 distances
+    at a fraction of the cost of the full float64 Gram.  exact_gemm=True (or SSG_SOURCE_EXACT_GEMM=1)
     forces the full fp64-MFMA pass."""
     import os
     L = _lib.lib()
@@ -98,10 +99,25 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
         # norms come from a 32-term chain + 6-level tree (38 u relative); a few ulps for the final adds.
         nx = float(tblk.norm(dim=1).max().item()); ny = float(src.norm(dim=1).max().item())
         u = 2.0 ** -24
-        gam = d * u / (1.0 - d * u)
-        tol = 2.0 * (2.0 * gam * nx * ny + 40.0 * u * (nx * nx + ny * ny)) + 8.0 * u * (nx + ny) ** 2
-        ws = torch.empty(nrows + Ns + npad + nrows * ((Ns + npad) // 8), dtype=torch.float32, device=tgt.device)
-        check(L.ssg_source_rowmin_filtered(ptr(tblk), ptr(srcp), nrows, Ns, Ns + npad, d, tol, ptr(ws), ptr(rowmin), stream()),
+        split = os.environ.get("SSG_SOURCE_BOUND", "split") == "split"
+        st = ss = 0.0
+        if split:
+            # bound pass on the fp16 matrix cores (split-half operands): per product 3*2^-22 relative (two operand
+            # representations + the dropped lo*lo term) + 2^-24 absolute per operand below the half normals; the
+            # accumulation is at most a 3d-term chain (three MFMA products per term), whatever order the hardware adds in
+            import math
+            mt = float(tblk.abs().max().item()); ms = float(src.abs().max().item())
+            st = 256.0 if mt == 0 else min(256.0, 2.0 ** math.floor(math.log2(16384.0 / mt)))
+            ss = 256.0 if ms == 0 else min(256.0, 2.0 ** math.floor(math.log2(16384.0 / ms)))
+            gam = 3.0 * d * u * 1.01 / (1.0 - 3.0 * d * u)
+            dot_err = (gam + 12.0 * u) * nx * ny + u * math.sqrt(d) * (nx / ss + ny / st) * 1.01
+        else:
+            gam = d * u / (1.0 - d * u)
+            dot_err = gam * nx * ny
+        tol = 2.0 * (2.0 * dot_err + 40.0 * u * (nx * nx + ny * ny)) + 8.0 * u * (nx + ny) ** 2
+        nws = nrows + Ns + npad + nrows * ((Ns + npad) // 8) + ((nrows + Ns + npad) * d if split else 0)
+        ws = torch.empty(nws, dtype=torch.float32, device=tgt.device)
+        check(L.ssg_source_rowmin_filtered(ptr(tblk), ptr(srcp), nrows, Ns, Ns + npad, d, tol, st, ss, ptr(ws), ptr(rowmin), stream()),
               "ssg_source_rowmin_filtered")
         return rowmin
     ntgt = torch.empty(N, dtype=torch.float64, device=tgt.device)
