@@ -210,6 +210,17 @@ def main():
             "achieved": round(conv_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
             "traffic": None, "launches": n_conv, "avg_launch_ms": round(ms_conv / max(n_conv, 1), 4),
             "algorithmic": "10.68 GFLOP per image (2 forwards x 5.34 GFLOP) x %d images per rank-step" % imgs_rank}
+    # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, collected on this
+    # kernel set at the same batch size); null when the configuration differs from the profiled one
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
+        if split and pm["batch"] == args.batch:
+            per = (pm["fetch_bytes_per_forward"] + pm["write_bytes_per_forward"]) / pm["launches_per_forward"]
+            roof["traffic"] = round(per)
+            roof["traffic_note"] = ("HBM bytes per conv launch (average over the %d launches of a forward, batch %d) from %s; algorithmic %.0f"
+                                    % (pm["launches_per_forward"], pm["batch"], pm["source"], pm["algorithmic_bytes_per_forward"] / pm["launches_per_forward"]))
+    except (OSError, KeyError, ValueError):
+        pass
     if split:
         roof["peak_is"] = "fp16 dense MFMA peak %.1f / 3 products per fp32 multiply" % PEAK_FP16_MFMA_TF
         roof["executed_fp16_tflops"] = round(3.0 * conv_tf, 1)
