@@ -175,6 +175,16 @@ int ssg_gap_stripes(const float* in, float* out, int B, int H, int W, int C, int
 /* out = (a+b)/||a+b||_2 per row (evaluators.py:31-35: original + flipped features, L2 norm) */
 int ssg_flip_sum_l2norm(const float* a, const float* b, float* out, int rows, int C, ssg_stream_t stream);
 
+/* ---- retrieval metrics of the evaluation step (reid/evaluators.py:88-129 evaluate_all ->
+ * reid/evaluation_metrics/ranking.py:18-79 cmc, :82-115 mean_ap + sklearn average_precision_score) */
+/* dist [m, ld] float32 query x gallery block; ids / cams int32.  first_rank[q] = number of valid gallery entries
+ * (different id or different camera; separate_cams != 0: different camera only, ranking.py:49-51) ordered before
+ * the first true match of query q in (distance, gallery index) order, -1 when q has no valid true match;
+ * ap[q] = its average precision (step-wise over distinct match distances like sklearn; NaN likewise).
+ * *overflow = number of queries with more than 2048 true matches (not evaluated). */
+int ssg_rank_metrics(const float* dist, int m, int n, int64_t ld, const int32_t* qid, const int32_t* qcam, const int32_t* gid,
+                     const int32_t* gcam, int separate_cams, int32_t* first_rank, double* ap, int32_t* overflow, ssg_stream_t stream);
+
 /* ---- float32 re-ranking variant "re_ranking_init" (reid/rerank.py:171-234 == reid/rerank_initial.py:40-99) */
 /* out[i,j] = 2 - 2<x_i,y_j> (rerank.py:174-182); d % 32 == 0, n % 64 == 0; zeros = n floats of 0 */
 int ssg_cosine_dist_f32(const float* x, const float* y, int m, int n, int d, const float* zeros, float* out, ssg_stream_t stream);

@@ -21,9 +21,12 @@ def __getattr__(name):   # lazy: torch import only when the compute surface is t
     if name in ("compute_dist", "generate_selflabel", "select_labeled"):
         from . import selftraining
         return getattr(selftraining, name)
-    if name in ("extract_features", "extract_embeddings", "extract_cnn_feature", "fliplr", "pairwise_distance"):
+    if name in ("extract_features", "extract_embeddings", "extract_cnn_feature", "fliplr", "pairwise_distance", "pairwise_distance_device"):
         from . import evaluators
         return getattr(evaluators, name)
+    if name in ("cmc", "mean_ap", "evaluate_all", "Evaluator"):
+        from . import ranking
+        return getattr(ranking, name)
     if name in ("create", "ResNet", "synthetic_state_dict"):
         from . import resnet
         return getattr(resnet, name)

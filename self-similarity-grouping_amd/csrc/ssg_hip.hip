@@ -8,3 +8,4 @@
 #include "cluster.hip"
 #include "conv.hip"
 #include "rerank_init.hip"
+#include "ranking.hip"

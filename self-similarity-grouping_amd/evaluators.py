@@ -105,16 +105,21 @@ def pairwise_distance(features, query=None, gallery=None, metric=None):
     """reid/evaluators.py:63-85 on the GPU (float32 squared L2; returns a CPU tensor like the
     reference).  The query=None branch keeps the reference's 2|x_i|^2 - 2<x_i,x_j> form (:64-72),
     which equals the squared distance only for unit-norm rows."""
+    return pairwise_distance_device(features, query, gallery, metric).cpu()
+
+
+def pairwise_distance_device(features, query=None, gallery=None, metric=None):
+    """pairwise_distance with the result left on the GPU (consumed by ssg_amd.ranking.evaluate_all)."""
     if query is None and gallery is None:
         n = len(features)
         x = torch.cat([f.view(1, -1) for f in features.values()]).view(n, -1)
         if metric is not None:
             x = metric.transform(x)
-        return _sqdist(x, x, self_form=True).cpu()
+        return _sqdist(x, x, self_form=True)
     x = torch.cat([features[f].unsqueeze(0) for f, _, _ in query], 0)
     y = torch.cat([features[f].unsqueeze(0) for f, _, _ in gallery], 0)
     m, n = x.size(0), y.size(0)
     x = x.view(m, -1); y = y.view(n, -1)
     if metric is not None:
         x = metric.transform(x); y = metric.transform(y)
-    return _sqdist(x, y).cpu()
+    return _sqdist(x, y)

@@ -508,3 +508,72 @@ def test_re_ranking_init_vs_reference_golden(golden, dev, ora):
     out = ssg_amd.re_ranking_init(x[:333], x[333:], k1=20, k2=6, lambda_value=0.3)
     ref = ora.re_ranking_init(x[:333], x[333:], k1=20, k2=6, lambda_value=0.3)
     assert out.shape == (333, 1000) and np.abs(out - ref).max() < 2e-5
+
+
+# ------------------------------------------------------------------ retrieval metrics
+def test_rank_metrics_vs_reference_golden(golden, dev):
+    """HIP cmc / mean_ap vs the reference's own outputs (tests/golden/eval_cases.npz).  CMC curves are exact
+    (integer counts / count); AP is a float64 sum of at most |matches| terms in a different order than sklearn's
+    pairwise np.sum -> 1e-12."""
+    import io, contextlib
+    from ssg_amd import ranking
+    g = golden("eval_cases.npz")
+    for tag in "abc":
+        args = (g["dist_" + tag], g["qid_" + tag], g["gid_" + tag], g["qcam_" + tag], g["gcam_" + tag])
+        first, ap = ranking.per_query(*args)
+        assert np.array_equal(first.cpu().numpy(), g["first_" + tag])
+        ref_ap = g["ap_" + tag]
+        assert np.array_equal(np.isnan(ap.cpu().numpy()), np.isnan(ref_ap))
+        assert np.nanmax(np.abs(ap.cpu().numpy() - ref_ap)) < 1e-12
+        assert abs(ranking.mean_ap(*args) - float(g["map_" + tag])) < 1e-12
+        assert np.array_equal(ranking.cmc(*args, first_match_break=True), g["cmc_" + tag])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            top1 = ranking.evaluate_all(torch.from_numpy(args[0]).to(dev), query_ids=args[1], gallery_ids=args[2], query_cams=args[3], gallery_cams=args[4])
+        assert top1 == g["cmc_" + tag][0] and "Mean AP" in buf.getvalue() and "top-1" in buf.getvalue()
+    with pytest.raises(NotImplementedError):
+        ranking.cmc(*args)                      # fractional 'allshots' accumulation is not on the path
+    with pytest.raises(RuntimeError):
+        ranking.mean_ap(np.array([[0.1, 0.2, 0.3]], np.float32), [1], [1, 2, 3], [0], [0, 1, 1])
+
+
+def test_rank_metrics_large_vs_oracle(dev):
+    """Market-sized block (3368 x 15913 in the real set; 700 x 6000 here so the CPU oracle stays in seconds) with
+    duplicated gallery rows (exact ties), a strided (padded) device distance block and the separate-camera protocol."""
+    from oracle import eval_oracle
+    from ssg_amd import ranking
+    rng = np.random.default_rng(5)
+    m, n, nid = 700, 6000, 150
+    gid = rng.integers(0, nid, n).astype(np.int32); gcam = rng.integers(0, 6, n).astype(np.int32)
+    qid = rng.integers(0, nid + 5, m).astype(np.int32); qcam = rng.integers(0, 6, m).astype(np.int32)
+    c = rng.standard_normal((nid + 5, 24)); gf = (c[gid] + 1.3 * rng.standard_normal((n, 24))).astype(np.float32)
+    qf = (c[qid] + 1.3 * rng.standard_normal((m, 24))).astype(np.float32)
+    gf[3000:3100] = gf[:100]; gid[3000:3100] = gid[:100]
+    dist = ((qf ** 2).sum(1)[:, None] + (gf ** 2).sum(1)[None, :] - 2 * qf @ gf.T).astype(np.float32)
+    padded = torch.zeros(m, n + 64, device=dev); padded[:, :n] = torch.from_numpy(dist).to(dev)
+    first, ap = ranking.per_query(padded[:, :n], qid, gid, qcam, gcam)
+    ofirst, oap = eval_oracle.per_query(dist, qid, gid, qcam, gcam)
+    assert np.array_equal(first.cpu().numpy(), ofirst)
+    assert np.nanmax(np.abs(ap.cpu().numpy() - oap)) < 1e-12
+    assert np.array_equal(ranking.cmc(dist, qid, gid, qcam, gcam, first_match_break=True, separate_camera_set=True),
+                          eval_oracle.cmc(dist, qid, gid, qcam, gcam, first_match_break=True, separate_camera_set=True))
+
+
+def test_evaluator_dropin(golden, dev):
+    """reid/evaluators.py:183-192 Evaluator(model).evaluate(loader, query, gallery): embed -> query x gallery block -> metrics."""
+    import io, contextlib
+    import ssg_amd
+    from oracle import eval_oracle
+    g = golden("embed_ref.npz")
+    imgs = torch.randn(4, 3, 256, 128, generator=torch.Generator().manual_seed(int(g["image_seed"])))
+    imgs = torch.cat([imgs, imgs.flip(0) * 0.9], 0)           # 8 images, two per "identity"
+    names = ["i%d" % i for i in range(8)]; pids = [0, 1, 2, 3, 3, 2, 1, 0]; cams = [0, 0, 0, 0, 1, 1, 1, 1]
+    m = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=int(g["weight_seed"])).cuda()
+    loader = [(imgs, names, pids, cams)]
+    query = [(names[i], pids[i], cams[i]) for i in range(4)]; gallery = [(names[i], pids[i], cams[i]) for i in range(8)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        top1 = ssg_amd.Evaluator(m, print_freq=1).evaluate(loader, query, gallery)
+        feats, _ = ssg_amd.extract_features(m, loader)
+        dist = ssg_amd.pairwise_distance(feats, query, gallery).numpy()
+    _, oscores, otop1 = eval_oracle.evaluate_all(dist, pids[:4], pids, cams[:4], cams)
+    assert top1 == otop1

@@ -117,3 +117,23 @@ def test_re_ranking_init_oracle_vs_reference_golden(golden, ora):
         ref = g["final_" + tag]
         assert out.shape == ref.shape and out.dtype == np.float32
         assert np.abs(out - ref).max() < 5e-6
+
+
+def test_eval_oracle_matches_reference_golden(golden):
+    """cmc / mean_ap restatement (oracle/eval_oracle.py) vs the values the reference functions produced
+    (tools/make_golden.py eval_fixture): bitwise for mAP and the CMC curves."""
+    from oracle import eval_oracle
+    g = golden("eval_cases.npz")
+    for tag in "abc":
+        args = (g["dist_" + tag], g["qid_" + tag], g["gid_" + tag], g["qcam_" + tag], g["gcam_" + tag])
+        assert eval_oracle.mean_ap(*args) == float(g["map_" + tag])
+        assert np.array_equal(eval_oracle.cmc(*args, first_match_break=True), g["cmc_" + tag])
+        assert np.array_equal(eval_oracle.cmc(*args), g["cmc_all_" + tag])
+        first, ap = eval_oracle.per_query(*args)
+        assert np.array_equal(first, g["first_" + tag]) and np.array_equal(np.isnan(ap), np.isnan(g["ap_" + tag]))
+        mAP, scores, ret = eval_oracle.evaluate_all(*args)
+        assert ret == g["cmc_" + tag][0]
+    # a query whose only same-id gallery entries share its camera is skipped; none valid -> RuntimeError like the reference
+    d = np.array([[0.1, 0.2, 0.3]], np.float32)
+    with pytest.raises(RuntimeError):
+        eval_oracle.mean_ap(d, [1], [1, 2, 3], [0], [0, 1, 1])

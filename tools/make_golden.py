@@ -125,14 +125,11 @@ def exp_quirk_inputs():
     return allh, npx, cr, bad
 
 
-def embed_fixture():
-    """Embedding golden: the REAL reference model (reid.models.create + reid.evaluators.
-    extract_features) under stub torchvision/h5py/metric_learn modules (SURVEY Appendix A),
-    loaded with the build's seeded synthetic weights, on 4 seeded 256x128 images."""
+def import_reid():
+    """import the reference package under stub torchvision / h5py / metric_learn modules"""
     import types
-    import torch
-    import ssg_amd
-    from oracle import embed_oracle
+    if "reid" in sys.modules:
+        return sys.modules["reid"]
     spec = importlib.util.spec_from_file_location("ref_base", os.path.join(REF, "reid", "models", "base.py"))
     base = importlib.util.module_from_spec(spec); spec.loader.exec_module(base)
     tv = types.ModuleType("torchvision"); tvm = types.ModuleType("torchvision.models"); tvt = types.ModuleType("torchvision.transforms")
@@ -151,7 +148,19 @@ def embed_fixture():
     sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.transforms": tvt, "h5py": h5,
                         "metric_learn": ml, "metric_learn.base_metric": mlb})
     sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
     import reid
+    return reid
+
+
+def embed_fixture():
+    """Embedding golden: the REAL reference model (reid.models.create + reid.evaluators.
+    extract_features) under stub torchvision/h5py/metric_learn modules (SURVEY Appendix A),
+    loaded with the build's seeded synthetic weights, on 4 seeded 256x128 images."""
+    import torch
+    import ssg_amd
+    from oracle import embed_oracle
+    reid = import_reid()
     torch.manual_seed(0)
     ok = True
     rec = {}
@@ -178,6 +187,50 @@ def embed_fixture():
     return ok
 
 
+def eval_fixture():
+    """Retrieval metrics (reid/evaluators.py:88-129 evaluate_all -> reid/evaluation_metrics/ranking.py cmc, mean_ap with
+    sklearn's average_precision_score): random query x gallery float32 distance blocks with Market-like id / camera
+    structure (same-camera true matches that must be filtered, queries without any valid match, duplicate gallery
+    vectors -> equal distances)."""
+    import contextlib
+    import io
+    from oracle import eval_oracle
+    reid = import_reid()
+    from reid.evaluation_metrics import ranking
+    import reid.evaluators as rev
+    ok = True
+    rec = {}
+    for tag, m, n, nid, ncam, seed, dup in (("a", 40, 300, 25, 6, 41, False), ("b", 64, 500, 30, 2, 42, True), ("c", 16, 120, 40, 3, 43, False)):
+        rng = np.random.default_rng(seed)
+        gid = rng.integers(0, nid, n); gcam = rng.integers(0, ncam, n)
+        qid = rng.integers(0, nid + (3 if tag == "c" else 0), m); qcam = rng.integers(0, ncam, m)   # case c: some ids absent from the gallery
+        centres = rng.standard_normal((nid + 3, 16))
+        gf = (centres[gid] + 1.6 * rng.standard_normal((n, 16))).astype(np.float32)
+        qf = (centres[qid] + 1.6 * rng.standard_normal((m, 16))).astype(np.float32)
+        if dup:
+            gf[n // 2:n // 2 + 20] = gf[:20]          # duplicated gallery vectors: exactly equal distances
+            gid[n // 2:n // 2 + 20] = gid[:20]        # (same identity, so cmc does not depend on the tie order)
+        dist = ((qf[:, None, :] - gf[None, :, :]) ** 2).sum(-1).astype(np.float32)
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref_map = ranking.mean_ap(dist, qid, gid, qcam, gcam)
+            ref_cmc = ranking.cmc(dist, qid, gid, qcam, gcam, separate_camera_set=False, single_gallery_shot=False, first_match_break=True)
+            ref_cmc_all = ranking.cmc(dist, qid, gid, qcam, gcam)                               # 'allshots' configuration
+            ref_ret = rev.evaluate_all(dist, query_ids=qid, gallery_ids=gid, query_cams=qcam, gallery_cams=gcam)
+        o_map = eval_oracle.mean_ap(dist, qid, gid, qcam, gcam)
+        o_cmc = eval_oracle.cmc(dist, qid, gid, qcam, gcam, first_match_break=True)
+        o_cmc_all = eval_oracle.cmc(dist, qid, gid, qcam, gcam)
+        good = (o_map == ref_map) and np.array_equal(o_cmc, ref_cmc) and np.array_equal(o_cmc_all, ref_cmc_all) and ref_ret == ref_cmc[0]
+        first, ap = eval_oracle.per_query(dist, qid, gid, qcam, gcam)
+        print("eval %s: m=%d n=%d mAP=%.6f top1=%.4f valid queries=%d  oracle==reference (bitwise): %s" % (
+            tag, m, n, ref_map, ref_cmc[0], int((first >= 0).sum()), good))
+        ok = ok and bool(good)
+        rec.update({"dist_" + tag: dist, "qid_" + tag: qid.astype(np.int32), "gid_" + tag: gid.astype(np.int32), "qcam_" + tag: qcam.astype(np.int32),
+                    "gcam_" + tag: gcam.astype(np.int32), "map_" + tag: np.float64(ref_map), "cmc_" + tag: ref_cmc, "cmc_all_" + tag: ref_cmc_all,
+                    "first_" + tag: first, "ap_" + tag: ap})
+    np.savez_compressed(os.path.join(OUT, "eval_cases.npz"), **rec)
+    return ok
+
+
 def init_fixture(mod):
     """re_ranking_init (float32 cosine variant, rerank.py:171-234 / rerank_initial.py:40-99)."""
     spec = importlib.util.spec_from_file_location("ref_init", os.path.join(REF, "reid", "rerank_initial.py"))
@@ -200,6 +253,10 @@ def init_fixture(mod):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-eval" in sys.argv:         # regenerate just tests/golden/eval_cases.npz
+        ok = eval_fixture()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     ora.build(force=True)
     mod = load_ref_rerank()
     ok = True
@@ -308,6 +365,7 @@ def main():
 
     ok = init_fixture(mod) and ok
     ok = embed_fixture() and ok
+    ok = eval_fixture() and ok
     print("ALL OK" if ok else "ORACLE MISMATCH")
     sys.exit(0 if ok else 1)
 
