@@ -696,7 +696,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
 static bool conv_prefers_wide(const ConvParams& p, bool split) {
   static int mintiles = -1;
   if (mintiles < 0) { const char* e = getenv("SSG_SPLIT_WIDE_MINTILES"); mintiles = e ? atoi(e) : 256; }
-  if (!split || mintiles <= 0 || (p.Cout % 256)) return false;
+  if (!split || mintiles <= 0 || (p.Cout % 256) || p.Kpad < 128) return false;   // short reductions: more, smaller workgroups overlap better
   return ((p.M + 127) / 128) * (p.Cout / 256) >= mintiles;
 }
 

@@ -31,11 +31,12 @@ def run(B, H, W, Cin, Cout, k, stride, pad, res, reps=20):
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * B * OH * OW * Cout * k * k * Cin
-    print("B=%d %dx%d cin=%d cout=%d k=%d s=%d res=%d: %.3f ms %.1f TF/s" % (B, H, W, Cin, Cout, k, stride, int(res), ms, fl / ms / 1e9))
+    byt = 4.0 * (x.numel() + out.numel() * (2 if res else 1))
+    print("B=%d %dx%d cin=%d cout=%d k=%d s=%d res=%d: %.3f ms %.1f TF/s %.2f TB/s" % (B, H, W, Cin, Cout, k, stride, int(res), ms, fl / ms / 1e9, byt / ms / 1e9))
 
 if __name__ == "__main__":
     cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
-    B = 256
+    B = int(os.environ.get("MICRO_B", "256"))
     if cfg == "c3": run(B, 16, 8, 256, 256, 3, 1, 1, False, 40)
     elif cfg == "c1": run(B, 16, 8, 1024, 256, 1, 1, 0, False, 40)
     elif cfg == "e1": run(B, 64, 32, 64, 256, 1, 1, 0, True, 40)

@@ -18,6 +18,18 @@ __global__ void flat(const uint4* __restrict__ M, int64_t n, unsigned* out) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { uint4 x = M[i]; acc += x.x ^ x.y ^ x.z ^ x.w; }
   if (acc == 0x12345678u) out[0] = acc;
 }
+__global__ void fill_rows(uint4* __restrict__ M, int N8, int nrows) {
+  const uint4 c = make_uint4(0x39993999u, 0x39993999u, 0x39993999u, 0x39993999u);
+  for (int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6); row < nrows; row += (int)((gridDim.x * blockDim.x) >> 6)) {
+    const int lane = threadIdx.x & 63;
+    uint4* p = M + (int64_t)row * N8;
+    for (int c0 = lane; c0 < N8; c0 += 64) p[c0] = c;
+  }
+}
+__global__ void fill_flat(uint4* __restrict__ M, int64_t n) {
+  const uint4 c = make_uint4(0x39993999u, 0x39993999u, 0x39993999u, 0x39993999u);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) M[i] = c;
+}
 int main() {
   const int N = 16000, nrows = 16000; const int N8 = N / 8;
   uint4* M; unsigned* out; hipMalloc(&M, (size_t)nrows * N8 * 16); hipMalloc(&out, nrows * 4); hipMemset(M, 1, (size_t)nrows * N8 * 16);
@@ -36,6 +48,19 @@ int main() {
       hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
     }
     const char* names[] = {"wave/row grid4000 1-load", "wave/row grid4000 4-loads", "wave/row grid1280 1-load", "wave/row grid2048 4-loads", "flat grid2048", "flat grid8192"};
+    printf("%-28s %.3f ms  %.0f GB/s\n", names[variant], best, gb / best * 1e3);
+  }
+  for (int variant = 0; variant < 4; variant++) {
+    float best = 1e9;
+    for (int rep = 0; rep < 5; rep++) {
+      hipEventRecord(e0);
+      if (variant == 0) hipLaunchKernelGGL(fill_rows, dim3(4000), dim3(256), 0, 0, M, N8, nrows);
+      if (variant == 1) hipLaunchKernelGGL(fill_rows, dim3(1280), dim3(256), 0, 0, M, N8, nrows);
+      if (variant == 2) hipLaunchKernelGGL(fill_flat, dim3(2048), dim3(256), 0, 0, M, (int64_t)nrows * N8);
+      if (variant == 3) hipMemsetAsync(M, 1, (size_t)nrows * N8 * 16, 0);
+      hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+    }
+    const char* names[] = {"fill wave/row grid4000", "fill wave/row grid1280", "fill flat grid2048", "hipMemsetAsync"};
     printf("%-28s %.3f ms  %.0f GB/s\n", names[variant], best, gb / best * 1e3);
   }
   return 0;
