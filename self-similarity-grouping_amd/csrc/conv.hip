@@ -1,4 +1,4 @@
-// conv.hip -- K1/K2: ResNet-50 embedding forward (eval mode) on the FP32 matrix cores.
+// conv.hip -- K1/K2: ResNet-50 embedding forward (eval mode) on the matrix cores.
 //
 // Replaces the cuDNN path under reid/models/resnet.py:86-111 (torchvision ResNet-50 =
 // reid/models/base.py:57-152 Bottleneck x [3,4,6,3]) as driven by
@@ -8,16 +8,19 @@
 //   m = output pixel (b, oh, ow)   -- NHWC activations, so a pixel's channels are contiguous
 //   n = output channel             -- weights stored [Cout][K], k = ((c/32)*KH*KW + r*KW + s)*32 + c%32:
 //                                     channel chunks outermost, so that the taps of a chunk re-read cached pixels
-// on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak).  Eval-mode BatchNorm is folded into
-// the weights/bias on the host; bias + residual add + ReLU are fused into the epilogue, so a
-// bottleneck block costs 3 (4 with downsample) launches and no elementwise passes.
+// Eval-mode BatchNorm is folded into the weights/bias on the host; bias + residual add + ReLU are fused into the
+// epilogue, so a bottleneck block costs 3 launches (the downsample branch rides in conv3's K) and no elementwise passes.
 //
-// Tile: 128x128 (128x64 when Cout = 64) output tile per 256-thread workgroup, 4 waves of 64x64
-// (64x32) = 2x2 (2x1) MFMA tiles, BK = 32, double-buffered LDS.  A and W tiles are staged through LDS as [row][36 floats]
-// (144-byte rows: ds_read_b128 fragment reads and ds_write_b128 staging writes are both
-// bank-conflict free).  Each lane reads 4 consecutive k of its row per ds_read_b128; the k
-// order inside a group of 8 is permuted identically for A and W (lane>>5 selects k0..3 or
-// k4..7), which the reduction does not care about.
+// Two element types share one kernel template (same 4 bytes per value, same addressing, same staging code):
+//   SPLIT = true  (default path): fp32 values carried as hi+lo halves, x*w = xh*wh + xh*wl + xl*wh on
+//                 v_mfma_f32_32x32x16_f16 with fp32 accumulation -- see "split-half activations" below;
+//   SPLIT = false: plain fp32 on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak = 1/16 of the fp16 rate).
+//
+// Tile: 128x256 (8 waves), 128x128 or 128x64 (4 waves) outputs per workgroup, each wave 64x64 (64x32) = 2x2 (2x1)
+// MFMA tiles of 32x32; BK = 32 or 16 fp32-sized values per stage, double-buffered LDS, one barrier per K tile.  A and W
+// tiles are staged through LDS as [row][BK + 4 floats] (pitch/16 B odd: ds_read_b128 fragment reads and ds_write_b128
+// staging writes are both bank-conflict free).  The MFMA is issued as D = W_tile * A_tile^T, the k order inside a
+// k-step is permuted identically for A and W (the reduction does not care).
 #include "ssg_common.h"
 #include <cstdlib>
 
