@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC ssg_hip.hip -o ../libssg_hip.so
 #include "ssg_api.hip"
 #include "pairwise.hip"
+#include "gram_i8.hip"
 #include "topk.hip"
 #include "krecip.hip"
 #include "jaccard.hip"

@@ -10,6 +10,8 @@ matrices D (original distance) and J' (scaled Jaccard), see DESIGN.md.
 returns a `DistHandle` that stays on the GPU (no f64 N x N materialisation, no D2H).
 """
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -152,11 +154,23 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     st = stream()
 
     # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
-    norms = torch.empty(N, dtype=torch.float64, device=dev)
-    check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
     D = torch.empty((nrows, N), dtype=torch.float16, device=dev)
     rowmax = torch.empty(nrows, dtype=torch.int32, device=dev)
-    check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
+    use_i8 = os.environ.get("SSG_SELF_GRAM", "i8") == "i8"
+    if use_i8:
+        # exact integer Gram on the int8 matrix cores (half-rounded features in [-1, 1]: scipy's float64 sum is exact)
+        enc = torch.empty(L.ssg_gram_i8_encoded_bytes(N, d), dtype=torch.int8, device=dev)
+        inorm = torch.empty(N, dtype=torch.int64, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(L.ssg_gram_i8_encode(ptr(tgt), N, d, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
+        use_i8 = int(flag.item()) == 0            # a feature outside [-1, 1]: the fp64-MFMA kernel below handles any range
+        if use_i8:
+            check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, row0, nrows, ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
+        del enc, inorm
+    if not use_i8:
+        norms = torch.empty(N, dtype=torch.float64, device=dev)
+        check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
+        check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
     if no_rerank:
         return DistHandle(N, 1, D, euclid=D, row0=row0, nrows=nrows, group=group)
 
