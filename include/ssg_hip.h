@@ -54,13 +54,14 @@ int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int r
                         ssg_stream_t stream);
 /* The same matrix as an EXACT integer Gram on the int8 matrix cores (csrc/gram_i8.hip): for half-rounded features in
  * [-1, 1] (L2-normalised embeddings) feat*2^24 is an integer and scipy's float64 squared distance is exact, so
- * d2*2^48 = |X_i|^2 + |X_j|^2 - 2<X_i,X_j> in int64 with the dot product on v_mfma_i32_32x32x32_i8 over four radix-128
- * digits gives the identical value.  ssg_gram_i8_encode writes the digits (ssg_gram_i8_encoded_bytes(n, d) bytes) and the
- * exact int64 norms and sets *flag when a feature is outside [-1, 1] or not finite (caller zeroes *flag first and
- * falls back to ssg_sqdist_self_f16 when it is set; ssg_sqdist_self_i8 itself does nothing in that case). */
-size_t ssg_gram_i8_encoded_bytes(int n, int d);
-int ssg_gram_i8_encode(const float* x, int n, int d, void* E, int64_t* norms, int32_t* flag, ssg_stream_t stream);
-int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
+ * d2*2^48 = |X_i|^2 + |X_j|^2 - 2<X_i,X_j> in int64, with the dot product on v_mfma_i32_32x32x32_i8 over ndigits balanced
+ * radix-256 digits (3: |feat| <= 0.498, 9 digit products; 4: |feat| <= 1, 16), gives the identical value.
+ * ssg_gram_i8_encode writes the digits (ssg_gram_i8_encoded_bytes bytes) and the exact int64 norms and sets *flag when a
+ * feature does not fit (caller zeroes *flag first and falls back to ssg_sqdist_self_f16 when it is set;
+ * ssg_sqdist_self_i8 itself does nothing in that case).  d <= 16384. */
+size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits);
+int ssg_gram_i8_encode(const float* x, int n, int d, int ndigits, void* E, int64_t* norms, int32_t* flag, ssg_stream_t stream);
+int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int ndigits, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
                        const int32_t* flag, ssg_stream_t stream);
 /* rowmin[i] = min_s half(cdist(tgt_i, src_s)^2) as half bits in uint32 (rerank.py:36-37,39) */
 int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const float* src, const double* nsrc, int nrows, int Ns, int d,

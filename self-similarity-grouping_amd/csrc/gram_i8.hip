@@ -7,13 +7,14 @@
 // exact number comes out of integer arithmetic:
 //     d2 * 2^48 = |X_i|^2 + |X_j|^2 - 2 <X_i, X_j>            (int64, < 2^51)
 // and the dot product runs on v_mfma_i32_32x32x32_i8 (2x the fp16 rate, 64x the fp64 MFMA rate per multiply) after
-// splitting X into four balanced radix-128 digits  X = d0 + 128 d1 + 128^2 d2 + 128^3 d3,  d0..2 in [-64, 63]:
-//     <X, Y> = sum_w 128^w T_w,   T_w = sum_{a+b=w} sum_k da_k eb_k        (16 digit products, 7 int32 accumulators;
-//                                                                         |T_w| <= 4 * 2048 * 64 * 64 < 2^26 per 2048 terms)
-// The epilogue is the float64 one of pairwise.hip (sqrt -> half -> square -> half, rerank.py:61-62) on the exactly
-// converted integer, so D is bit-identical to the reference by construction (not just with high probability).
-// A feature outside [-1, 1] (or non-finite) raises a device flag: the int8 kernel then does nothing and the caller runs
-// the fp64-MFMA kernel of pairwise.hip instead.
+// splitting X into NL balanced radix-256 digits  X = sum_a 256^a e_a,  e_a in [-128, 127]:
+//     <X, Y> = sum_w 256^w T_w,   T_w = sum_{a+b=w} sum_k ea_k fb_k        (NL^2 digit products, 2 NL - 1 int32 accumulators;
+//                                                                         |T_w| <= NL * d * 2^14 < 2^31 for d <= 16384)
+// NL = 3 covers |feat| <= 0.498 (every real L2-normalised 2048-d embedding): 9 MFMAs per 32x32x32 block; NL = 4 covers
+// |feat| <= 1 (16 MFMAs).  The epilogue is the float64 one of pairwise.hip (sqrt -> half -> square -> half,
+// rerank.py:61-62) on the exactly converted integer, so D is bit-identical to the reference by construction (not just
+// with high probability).  Anything larger than 1 (or non-finite) is left to the fp64-MFMA kernel of pairwise.hip: the
+// caller picks NL from max|feat|; the encoder additionally raises a device flag if a digit does not fit.
 #include "ssg_common.h"
 
 namespace ssg {
@@ -22,17 +23,17 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int GI_T = 64;          // workgroup tile (4 waves, 32x32 outputs each)
-constexpr int GI_PITCH = 144;     // LDS bytes per row of one 32-wide k block: 4 digits x 32 B + 16 B pad (pitch/16 odd)
 
-// One wave per row: digits of feat*2^24 for every 32-wide k block, laid out [row][k block][digit][32 k] (128 B per
+// One wave per row: digits of feat*2^24 for every 32-wide k block, laid out [row][k block][digit][32 k] (32*NL bytes per
 // block: the layout both the global tile loads and the LDS fragment reads use), and the exact squared norm.
+template <int NL>
 __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __restrict__ X, int n, int d, int nkb, int8_t* __restrict__ E,
                                                              long long* __restrict__ norms, int* __restrict__ flag) {
   const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
   if (row >= n) return;
   const int lane = lane_id();
   const float* x = X + (int64_t)row * d;
-  int8_t* e = E + (int64_t)row * nkb * 128;
+  int8_t* e = E + (int64_t)row * nkb * (32 * NL);
   long long acc = 0;
   bool bad = false;
   for (int k0 = 0; k0 < nkb * 32; k0 += 64) {
@@ -42,11 +43,15 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
     if (!(fabsf(v) <= 1.0f)) bad = true;                    // also catches NaN
     const int q = bad ? 0 : (int)(v * 16777216.0f);         // exact: half values <= 1 are multiples of 2^-24
     acc += (long long)q * (long long)q;
-    const int d0 = ((q + 64) & 127) - 64; const int q1 = (q - d0) >> 7;
-    const int d1 = ((q1 + 64) & 127) - 64; const int q2 = (q1 - d1) >> 7;
-    const int d2 = ((q2 + 64) & 127) - 64; const int d3 = (q2 - d2) >> 7;
-    int8_t* p = e + (int64_t)(k >> 5) * 128 + (k & 31);
-    p[0] = (int8_t)d0; p[32] = (int8_t)d1; p[64] = (int8_t)d2; p[96] = (int8_t)d3;
+    int8_t* p = e + (int64_t)(k >> 5) * (32 * NL) + (k & 31);
+    int r = q;
+#pragma unroll
+    for (int L = 0; L < NL; L++) {
+      const int dg = ((r + 128) & 255) - 128;               // balanced digit in [-128, 127]
+      p[32 * L] = (int8_t)dg;
+      r = (r - dg) >> 8;
+    }
+    if (r != 0) bad = true;                                 // |X| beyond NL digits
   }
   for (int sh = 1; sh < 64; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
   if (lane == 0) norms[row] = acc;
@@ -55,12 +60,17 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
 
 // D[i,j] = half(half(sqrt(d2))^2) for rows [rowA0, rowA0+M) x all N columns, atomicMax rowmax.  EA = encoded rows of the
 // row block, EB = encoded rows of the whole set.  symmetric: only tiles on/above the diagonal are launched, mirrored on store.
+template <int NL>
 __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ EA, const int8_t* __restrict__ EB,
                                                          const long long* __restrict__ nA, const long long* __restrict__ nB, int M, int N, int nkb,
                                                          int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric,
                                                          const int* __restrict__ flag) {
-  if (*flag) return;     // some feature left [-1, 1]: the caller falls back to the fp64 kernel
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * GI_PITCH];
+  if (*flag) return;     // a feature did not fit NL digits: the caller falls back to the fp64 kernel
+  constexpr int BLK = 32 * NL;          // bytes of one k block of one row
+  constexpr int PITCH = BLK + 16;       // LDS row pitch: pitch/16 odd (7 or 9) -> conflict-free b128
+  constexpr int CPR = 2 * NL;           // 16-byte chunks per row and k block
+  constexpr int NACC = 2 * NL - 1;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * PITCH];
   const int tiles_n = (N + GI_T - 1) / GI_T, tiles_m = (M + GI_T - 1) / GI_T;
   int tm, tn;
   if (symmetric) {
@@ -77,51 +87,44 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   const bool mirror = symmetric && tn > tm;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
-  // staging: 16-byte chunk c of row r (+32): 8 chunks = the 128 bytes of one k block of one row
-  const int sc = tid & 7, sr = tid >> 3;
-  const int ar0 = min(tm * GI_T + sr, M - 1), ar1 = min(tm * GI_T + sr + 32, M - 1);
-  const int br0 = min(tn * GI_T + sr, N - 1), br1 = min(tn * GI_T + sr + 32, N - 1);
-  const uint4* a0 = reinterpret_cast<const uint4*>(EA + (int64_t)ar0 * nkb * 128) + sc;
-  const uint4* a1 = reinterpret_cast<const uint4*>(EA + (int64_t)ar1 * nkb * 128) + sc;
-  const uint4* b0 = reinterpret_cast<const uint4*>(EB + (int64_t)br0 * nkb * 128) + sc;
-  const uint4* b1 = reinterpret_cast<const uint4*>(EB + (int64_t)br1 * nkb * 128) + sc;
-  uint4 pa0, pa1, pb0, pb1;
-#define SSG_GL(KB) { pa0 = a0[(KB) * 8]; pa1 = a1[(KB) * 8]; pb0 = b0[(KB) * 8]; pb1 = b1[(KB) * 8]; }
-#define SSG_LS(BUF)                                                                                  \
-  {                                                                                                  \
-    unsigned char* As_ = lds + (BUF) * (2 * GI_T * GI_PITCH);                                        \
-    unsigned char* Bs_ = As_ + GI_T * GI_PITCH;                                                      \
-    *reinterpret_cast<uint4*>(As_ + sr * GI_PITCH + sc * 16) = pa0;                                  \
-    *reinterpret_cast<uint4*>(As_ + (sr + 32) * GI_PITCH + sc * 16) = pa1;                           \
-    *reinterpret_cast<uint4*>(Bs_ + sr * GI_PITCH + sc * 16) = pb0;                                  \
-    *reinterpret_cast<uint4*>(Bs_ + (sr + 32) * GI_PITCH + sc * 16) = pb1;                           \
-  }
-  v16i acc[7];
+  // staging: the A tile and the B tile together are 128 rows x CPR chunks of 16 bytes = NL chunks per thread
+  const uint4* gp[NL]; int lo[NL];
 #pragma unroll
-  for (int w = 0; w < 7; w++)
+  for (int p = 0; p < NL; p++) {
+    const int c = tid + 256 * p, mat = c / (GI_T * CPR), rem = c - mat * (GI_T * CPR), row = rem / CPR, ch = rem - row * CPR;
+    const int grow = mat ? min(tn * GI_T + row, N - 1) : min(tm * GI_T + row, M - 1);
+    gp[p] = reinterpret_cast<const uint4*>((mat ? EB : EA) + (int64_t)grow * nkb * BLK) + ch;
+    lo[p] = mat * (GI_T * PITCH) + row * PITCH + ch * 16;
+  }
+  uint4 pf[NL];
+  v16i acc[NACC];
+#pragma unroll
+  for (int w = 0; w < NACC; w++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[w][r] = 0;
 
-  SSG_GL(0)
-  SSG_LS(0)
+#pragma unroll
+  for (int p = 0; p < NL; p++) *reinterpret_cast<uint4*>(lds + lo[p]) = gp[p][0];
   __syncthreads();
   for (int kb = 0; kb < nkb; kb++) {
-    { const int kn = min(kb + 1, nkb - 1); SSG_GL(kn) }      // next block's L2 latency hides under this block's 16 MFMAs
-    const unsigned char* As = lds + (kb & 1) * (2 * GI_T * GI_PITCH) + (wm * 32 + l32) * GI_PITCH + h * 16;
-    const unsigned char* Bs = lds + (kb & 1) * (2 * GI_T * GI_PITCH) + GI_T * GI_PITCH + (wn * 32 + l32) * GI_PITCH + h * 16;
-    v4i a[4], b[4];
+    const int kn = min(kb + 1, nkb - 1);      // next block's L2 latency hides under this block's MFMAs (clamped: branch-free)
 #pragma unroll
-    for (int L = 0; L < 4; L++) { a[L] = *reinterpret_cast<const v4i*>(As + L * 32); b[L] = *reinterpret_cast<const v4i*>(Bs + L * 32); }
+    for (int p = 0; p < NL; p++) pf[p] = gp[p][kn * CPR];
+    const unsigned char* As = lds + (kb & 1) * (2 * GI_T * PITCH) + (wm * 32 + l32) * PITCH + h * 16;
+    const unsigned char* Bs = lds + (kb & 1) * (2 * GI_T * PITCH) + GI_T * PITCH + (wn * 32 + l32) * PITCH + h * 16;
+    v4i a[NL], b[NL];
+#pragma unroll
+    for (int L = 0; L < NL; L++) { a[L] = *reinterpret_cast<const v4i*>(As + L * 32); b[L] = *reinterpret_cast<const v4i*>(Bs + L * 32); }
     // digit products grouped by weight a+b; consecutive MFMAs go to different accumulators
 #pragma unroll
-    for (int La = 0; La < 4; La++)
+    for (int La = 0; La < NL; La++)
 #pragma unroll
-      for (int Lb = 0; Lb < 4; Lb++) acc[La + Lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[La], b[Lb], acc[La + Lb], 0, 0, 0);
-    SSG_LS((kb + 1) & 1)       // other stage: its readers finished before the previous barrier (redundant after the last block)
+      for (int Lb = 0; Lb < NL; Lb++) acc[La + Lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[La], b[Lb], acc[La + Lb], 0, 0, 0);
+    // other stage: its readers finished before the previous barrier (redundant after the last block)
+#pragma unroll
+    for (int p = 0; p < NL; p++) *reinterpret_cast<uint4*>(lds + ((kb + 1) & 1) * (2 * GI_T * PITCH) + lo[p]) = pf[p];
     __syncthreads();
   }
-#undef SSG_GL
-#undef SSG_LS
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31 -> B row (j), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> A row (i).
   const int gj = tn * GI_T + wn * 32 + l32;
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     if (ok) {
       long long dot = 0;
 #pragma unroll
-      for (int w = 6; w >= 0; w--) dot = dot * 128 + (long long)acc[w][r];
+      for (int w = NACC - 1; w >= 0; w--) dot = dot * 256 + (long long)acc[w][r];
       long long d2i = nA[li] + nj - 2 * dot;           // exact squared distance in units of 2^-48
       if (d2i < 0 || rowA0 + li == gj) d2i = 0;         // cannot be negative; cdist(x, x) diagonal is exactly 0
       const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
@@ -162,23 +165,25 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
 
 using namespace ssg;
 
-extern "C" size_t ssg_gram_i8_encoded_bytes(int n, int d) { return (size_t)n * (size_t)((d + 31) / 32) * 128; }
+extern "C" size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits) { return (size_t)n * (size_t)((d + 31) / 32) * 32 * (size_t)ndigits; }
 
-// Digits + exact squared norms of n rows; *flag |= 1 when a half-rounded feature lies outside [-1, 1].  E:
-// ssg_gram_i8_encoded_bytes(n, d) bytes, norms: n int64.  The caller zeroes *flag once per matrix.
-extern "C" int ssg_gram_i8_encode(const float* x, int n, int d, void* E, int64_t* norms, int32_t* flag, hipStream_t stream) {
-  if (n <= 0 || d <= 0) { ssg_set_error("ssg_gram_i8_encode: empty input"); return SSG_ERR_INVALID; }
-  hipLaunchKernelGGL(gram_i8_encode_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, (d + 31) / 32, (int8_t*)E, (long long*)norms, flag);
+// Digits + exact squared norms of n rows.  ndigits = 3 (|feat| <= 0.498) or 4 (|feat| <= 1); *flag |= 1 when a half-rounded
+// feature does not fit.  E: ssg_gram_i8_encoded_bytes(n, d, ndigits) bytes, norms: n int64.  The caller zeroes *flag first.
+extern "C" int ssg_gram_i8_encode(const float* x, int n, int d, int ndigits, void* E, int64_t* norms, int32_t* flag, hipStream_t stream) {
+  if (n <= 0 || d <= 0 || d > 16384 || (ndigits != 3 && ndigits != 4)) { ssg_set_error("ssg_gram_i8_encode: need 0 < d <= 16384, ndigits 3 or 4 (n=%d d=%d ndigits=%d)", n, d, ndigits); return SSG_ERR_INVALID; }
+  const int nkb = (d + 31) / 32;
+  if (ndigits == 3) hipLaunchKernelGGL(gram_i8_encode_kernel<3>, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, nkb, (int8_t*)E, (long long*)norms, flag);
+  else hipLaunchKernelGGL(gram_i8_encode_kernel<4>, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, nkb, (int8_t*)E, (long long*)norms, flag);
   SSG_LAUNCH_CHECK("gram_i8_encode_kernel");
   return SSG_OK;
 }
 
 // Same contract as ssg_sqdist_self_f16 (rows [row0,row0+nrows) x N of the half original distance + row maxima) from the
 // encoded features; does nothing when *flag != 0 (the caller then runs ssg_sqdist_self_f16).
-extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
+extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int ndigits, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
                                   const int32_t* flag, hipStream_t stream) {
-  if (N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N || d <= 0) {
-    ssg_set_error("ssg_sqdist_self_i8: bad shape N=%d d=%d row0=%d nrows=%d", N, d, row0, nrows);
+  if (N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N || d <= 0 || d > 16384 || (ndigits != 3 && ndigits != 4)) {
+    ssg_set_error("ssg_sqdist_self_i8: bad shape N=%d d=%d ndigits=%d row0=%d nrows=%d", N, d, ndigits, row0, nrows);
     return SSG_ERR_INVALID;
   }
   const int nkb = (d + 31) / 32;
@@ -188,8 +193,13 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
   const int64_t tiles = symmetric ? (int64_t)T * (T + 1) / 2 : (int64_t)((nrows + GI_T - 1) / GI_T) * T;
   if (tiles > 0x7fffffff) { ssg_set_error("ssg_sqdist_self_i8: too many tiles"); return SSG_ERR_INVALID; }
   const int8_t* e = (const int8_t*)E;
-  hipLaunchKernelGGL(gram_i8_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, e + (int64_t)row0 * nkb * 128, e, (const long long*)norms + row0,
-                     (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag);
+  const int64_t rowbytes = (int64_t)nkb * 32 * ndigits;
+  if (ndigits == 3)
+    hipLaunchKernelGGL(gram_i8_kernel<3>, dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, (const long long*)norms + row0,
+                       (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag);
+  else
+    hipLaunchKernelGGL(gram_i8_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, (const long long*)norms + row0,
+                       (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag);
   SSG_LAUNCH_CHECK("gram_i8_kernel");
   return SSG_OK;
 }

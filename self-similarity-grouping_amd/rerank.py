@@ -156,16 +156,20 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
     D = torch.empty((nrows, N), dtype=torch.float16, device=dev)
     rowmax = torch.empty(nrows, dtype=torch.int32, device=dev)
-    use_i8 = os.environ.get("SSG_SELF_GRAM", "i8") == "i8"
+    use_i8 = os.environ.get("SSG_SELF_GRAM", "i8") == "i8" and d <= 16384
     if use_i8:
-        # exact integer Gram on the int8 matrix cores (half-rounded features in [-1, 1]: scipy's float64 sum is exact)
-        enc = torch.empty(L.ssg_gram_i8_encoded_bytes(N, d), dtype=torch.int8, device=dev)
+        # exact integer Gram on the int8 matrix cores (half-rounded features in [-1, 1]: scipy's float64 sum is exact);
+        # 3 radix-256 digits cover |feat| <= 0.498 (any real L2-normalised embedding), 4 digits |feat| <= 1
+        mx = float(tgt.abs().max().item())
+        nd = int(os.environ.get("SSG_SELF_GRAM_DIGITS", "0")) or (3 if mx <= 0.49 else 4)
+        use_i8 = mx <= 1.0
+    if use_i8:
+        enc = torch.empty(L.ssg_gram_i8_encoded_bytes(N, d, nd), dtype=torch.int8, device=dev)
         inorm = torch.empty(N, dtype=torch.int64, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        check(L.ssg_gram_i8_encode(ptr(tgt), N, d, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
-        use_i8 = int(flag.item()) == 0            # a feature outside [-1, 1]: the fp64-MFMA kernel below handles any range
-        if use_i8:
-            check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, row0, nrows, ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
+        check(L.ssg_gram_i8_encode(ptr(tgt), N, d, nd, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
+        check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, nd, row0, nrows, ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
+        use_i8 = int(flag.item()) == 0            # never expected after the range check above; the kernel wrote nothing if set
         del enc, inorm
     if not use_i8:
         norms = torch.empty(N, dtype=torch.float64, device=dev)
