@@ -16,6 +16,7 @@
 // with high probability).  Anything larger than 1 (or non-finite) is left to the fp64-MFMA kernel of pairwise.hip: the
 // caller picks NL from max|feat|; the encoder additionally raises a device flag if a digit does not fit.
 #include "ssg_common.h"
+#include <cstdlib>
 
 namespace ssg {
 
@@ -60,20 +61,22 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
 
 // D[i,j] = half(half(sqrt(d2))^2) for rows [rowA0, rowA0+M) x all N columns, atomicMax rowmax.  EA = encoded rows of the
 // row block, EB = encoded rows of the whole set.  symmetric: only tiles on/above the diagonal are launched, mirrored on store.
-template <int NL>
+template <int NL, int KB2>
 __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ EA, const int8_t* __restrict__ EB,
                                                          const long long* __restrict__ nA, const long long* __restrict__ nB, int M, int N, int nkb,
                                                          int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric,
                                                          const int* __restrict__ flag) {
   if (*flag) return;     // a feature did not fit NL digits: the caller falls back to the fp64 kernel
   constexpr int BLK = 32 * NL;          // bytes of one k block of one row
-  constexpr int PITCH = BLK + 16;       // LDS row pitch: pitch/16 odd (7 or 9) -> conflict-free b128
-  constexpr int CPR = 2 * NL;           // 16-byte chunks per row and k block
+  constexpr int SB = KB2 * BLK;         // bytes of one stage row: KB2 consecutive k blocks (one barrier per KB2 * NL^2 MFMAs)
+  constexpr int PITCH = SB + 16;        // LDS row pitch: pitch/16 odd (7, 9, 13, 17) -> conflict-free b128
+  constexpr int CPR = SB / 16;          // 16-byte chunks per row and stage
+  constexpr int NCH = (2 * GI_T * CPR) / 256;   // chunks per thread: A tile + B tile
   constexpr int NACC = 2 * NL - 1;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * PITCH];
   const int tiles_n = (N + GI_T - 1) / GI_T, tiles_m = (M + GI_T - 1) / GI_T;
   int tm, tn;
-  if (symmetric) {
+  if (symmetric & 1) {
     const int T = tiles_n;
     const int t = xcd_remap((int)blockIdx.x, T * (T + 1) / 2);
     int r = (int)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
@@ -84,19 +87,20 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
     tm = tile / tiles_n; tn = tile % tiles_n;
   }
-  const bool mirror = symmetric && tn > tm;
+  const bool mirror = (symmetric & 1) && tn > tm && !(symmetric & 4);
+  const bool abl_epi = symmetric & 2;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
   // staging: the A tile and the B tile together are 128 rows x CPR chunks of 16 bytes = NL chunks per thread
-  const uint4* gp[NL]; int lo[NL];
+  const uint4* gp[NCH]; int lo[NCH];
 #pragma unroll
-  for (int p = 0; p < NL; p++) {
+  for (int p = 0; p < NCH; p++) {
     const int c = tid + 256 * p, mat = c / (GI_T * CPR), rem = c - mat * (GI_T * CPR), row = rem / CPR, ch = rem - row * CPR;
     const int grow = mat ? min(tn * GI_T + row, N - 1) : min(tm * GI_T + row, M - 1);
     gp[p] = reinterpret_cast<const uint4*>((mat ? EB : EA) + (int64_t)grow * nkb * BLK) + ch;
     lo[p] = mat * (GI_T * PITCH) + row * PITCH + ch * 16;
   }
-  uint4 pf[NL];
+  uint4 pf[NCH];
   v16i acc[NACC];
 #pragma unroll
   for (int w = 0; w < NACC; w++)
@@ -104,25 +108,29 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     for (int r = 0; r < 16; r++) acc[w][r] = 0;
 
 #pragma unroll
-  for (int p = 0; p < NL; p++) *reinterpret_cast<uint4*>(lds + lo[p]) = gp[p][0];
+  for (int p = 0; p < NCH; p++) *reinterpret_cast<uint4*>(lds + lo[p]) = gp[p][0];
   __syncthreads();
-  for (int kb = 0; kb < nkb; kb++) {
-    const int kn = min(kb + 1, nkb - 1);      // next block's L2 latency hides under this block's MFMAs (clamped: branch-free)
+  const int nst = nkb / KB2;
+  for (int st = 0; st < nst; st++) {
+    const int sn = min(st + 1, nst - 1);      // next stage's L2 latency hides under this stage's MFMAs (clamped: branch-free)
 #pragma unroll
-    for (int p = 0; p < NL; p++) pf[p] = gp[p][kn * CPR];
-    const unsigned char* As = lds + (kb & 1) * (2 * GI_T * PITCH) + (wm * 32 + l32) * PITCH + h * 16;
-    const unsigned char* Bs = lds + (kb & 1) * (2 * GI_T * PITCH) + GI_T * PITCH + (wn * 32 + l32) * PITCH + h * 16;
-    v4i a[NL], b[NL];
+    for (int p = 0; p < NCH; p++) pf[p] = gp[p][sn * CPR];
+    const unsigned char* As = lds + (st & 1) * (2 * GI_T * PITCH) + (wm * 32 + l32) * PITCH + h * 16;
+    const unsigned char* Bs = lds + (st & 1) * (2 * GI_T * PITCH) + GI_T * PITCH + (wn * 32 + l32) * PITCH + h * 16;
 #pragma unroll
-    for (int L = 0; L < NL; L++) { a[L] = *reinterpret_cast<const v4i*>(As + L * 32); b[L] = *reinterpret_cast<const v4i*>(Bs + L * 32); }
-    // digit products grouped by weight a+b; consecutive MFMAs go to different accumulators
+    for (int q = 0; q < KB2; q++) {
+      v4i a[NL], b[NL];
 #pragma unroll
-    for (int La = 0; La < NL; La++)
+      for (int L = 0; L < NL; L++) { a[L] = *reinterpret_cast<const v4i*>(As + q * BLK + L * 32); b[L] = *reinterpret_cast<const v4i*>(Bs + q * BLK + L * 32); }
+      // digit products grouped by weight a+b; consecutive MFMAs go to different accumulators
 #pragma unroll
-      for (int Lb = 0; Lb < NL; Lb++) acc[La + Lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[La], b[Lb], acc[La + Lb], 0, 0, 0);
-    // other stage: its readers finished before the previous barrier (redundant after the last block)
+      for (int La = 0; La < NL; La++)
 #pragma unroll
-    for (int p = 0; p < NL; p++) *reinterpret_cast<uint4*>(lds + ((kb + 1) & 1) * (2 * GI_T * PITCH) + lo[p]) = pf[p];
+        for (int Lb = 0; Lb < NL; Lb++) acc[La + Lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[La], b[Lb], acc[La + Lb], 0, 0, 0);
+    }
+    // other stage: its readers finished before the previous barrier (redundant after the last stage)
+#pragma unroll
+    for (int p = 0; p < NCH; p++) *reinterpret_cast<uint4*>(lds + ((st + 1) & 1) * (2 * GI_T * PITCH) + lo[p]) = pf[p];
     __syncthreads();
   }
 
@@ -143,8 +151,8 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
       long long d2i = nA[li] + nj - 2 * dot;           // exact squared distance in units of 2^-48
       if (d2i < 0 || rowA0 + li == gj) d2i = 0;         // cannot be negative; cdist(x, x) diagonal is exactly 0
       const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
-      const hbits hh = d2h(sqrt(s));                    // cdist(...).astype(float16)   rerank.py:61
-      dd = h_mul(hh, hh);                               // np.power(half, 2)            rerank.py:62
+      const hbits hh = abl_epi ? (hbits)(d2i >> 30) : d2h(sqrt(s));                    // cdist(...).astype(float16)   rerank.py:61
+      dd = abl_epi ? hh : h_mul(hh, hh);                               // np.power(half, 2)            rerank.py:62
       D[(int64_t)li * N + gj] = (hbits)dd;
       if (mirror) D[(int64_t)gj * N + li] = (hbits)dd;
       cmax = cmax > dd ? cmax : dd;
@@ -188,18 +196,21 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
   }
   const int nkb = (d + 31) / 32;
   hipLaunchKernelGGL(fill_u32_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, rowmax, nrows, 0u);
-  const int symmetric = (row0 == 0 && nrows == N) ? 1 : 0;
+  int symmetric = (row0 == 0 && nrows == N) ? 1 : 0;
+  { const char* e_ = getenv("SSG_I8_ABL"); if (e_ && symmetric) symmetric |= atoi(e_); }
   const int T = (N + GI_T - 1) / GI_T;
   const int64_t tiles = symmetric ? (int64_t)T * (T + 1) / 2 : (int64_t)((nrows + GI_T - 1) / GI_T) * T;
   if (tiles > 0x7fffffff) { ssg_set_error("ssg_sqdist_self_i8: too many tiles"); return SSG_ERR_INVALID; }
   const int8_t* e = (const int8_t*)E;
   const int64_t rowbytes = (int64_t)nkb * 32 * ndigits;
-  if (ndigits == 3)
-    hipLaunchKernelGGL(gram_i8_kernel<3>, dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, (const long long*)norms + row0,
-                       (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag);
-  else
-    hipLaunchKernelGGL(gram_i8_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, (const long long*)norms + row0,
-                       (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag);
+#define SSG_GI_LAUNCH(NL_, KB_) hipLaunchKernelGGL((gram_i8_kernel<NL_, KB_>), dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, \
+    (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag)
+  static int kb2 = -1;
+  if (kb2 < 0) { const char* e_ = getenv("SSG_I8_KB2"); kb2 = e_ ? atoi(e_) : 2; }
+  const bool two = kb2 == 2 && (nkb % 2) == 0;     // two k blocks per LDS stage: half the barriers (53 KB of LDS with 3 digits)
+  if (ndigits == 3) { if (two) SSG_GI_LAUNCH(3, 2); else SSG_GI_LAUNCH(3, 1); }
+  else SSG_GI_LAUNCH(4, 1);
+#undef SSG_GI_LAUNCH
   SSG_LAUNCH_CHECK("gram_i8_kernel");
   return SSG_OK;
 }
