@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * PITCH];
   const int tiles_n = (N + GI_T - 1) / GI_T, tiles_m = (M + GI_T - 1) / GI_T;
   int tm, tn;
-  if (symmetric & 1) {
+  if (symmetric) {
     const int T = tiles_n;
     const int t = xcd_remap((int)blockIdx.x, T * (T + 1) / 2);
     int r = (int)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
@@ -87,8 +87,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
     tm = tile / tiles_n; tn = tile % tiles_n;
   }
-  const bool mirror = (symmetric & 1) && tn > tm && !(symmetric & 4);
-  const bool abl_epi = symmetric & 2;
+  const bool mirror = symmetric && tn > tm;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
   // staging: the A tile and the B tile together are 128 rows x CPR chunks of 16 bytes = NL chunks per thread
@@ -139,9 +138,14 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   const bool jok = gj < N;
   const long long nj = jok ? nB[gj] : 0;
   unsigned cmax = 0;
+  // mirror: the transposed 32x32 half tile goes through a private LDS patch (the stage buffers are free after the last
+  // barrier) so that it is stored as 64-byte row segments like the direct tile, not as scattered 8-byte pieces
+  constexpr int MP = 34;                                   // patch pitch in halves (17 dwords: odd)
+  hbits* patch = reinterpret_cast<hbits*>(lds) + wave * (32 * MP);
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    const int li = tm * GI_T + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int il = (r & 3) + 8 * (r >> 2) + 4 * h;          // row of this accumulator element inside the wave tile
+    const int li = tm * GI_T + wm * 32 + il;
     const bool ok = jok && li < M;
     unsigned dd = 0;
     if (ok) {
@@ -151,16 +155,37 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
       long long d2i = nA[li] + nj - 2 * dot;           // exact squared distance in units of 2^-48
       if (d2i < 0 || rowA0 + li == gj) d2i = 0;         // cannot be negative; cdist(x, x) diagonal is exactly 0
       const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
-      const hbits hh = abl_epi ? (hbits)(d2i >> 30) : d2h(sqrt(s));                    // cdist(...).astype(float16)   rerank.py:61
-      dd = abl_epi ? hh : h_mul(hh, hh);                               // np.power(half, 2)            rerank.py:62
+      const hbits hh = d2h(sqrt(s));                    // cdist(...).astype(float16)   rerank.py:61
+      dd = h_mul(hh, hh);                               // np.power(half, 2)            rerank.py:62
       D[(int64_t)li * N + gj] = (hbits)dd;
-      if (mirror) D[(int64_t)gj * N + li] = (hbits)dd;
       cmax = cmax > dd ? cmax : dd;
     }
+    if (mirror) patch[l32 * MP + il] = (hbits)dd;
     unsigned red = dd;                                  // row maximum over the 32 columns of this half-wave
 #pragma unroll
     for (int sh = 1; sh < 32; sh <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)red, sh, 64); red = red > o ? red : o; }
     if (l32 == 0 && li < M) atomicMax(&rowmax[li], red);
+  }
+  if (mirror) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // patch written and read by this wave only
+    // lane pair (2j, 2j+1) stores the 32 halves of mirrored row j = this tile's column j: 2 x 32 bytes
+    const int mj = lane >> 1, half16 = (lane & 1) * 16;
+    const int grow = tn * GI_T + wn * 32 + mj;            // mirrored row (a column of this tile)
+    const int gcol = tm * GI_T + wm * 32 + half16;        // first of 16 mirrored columns (rows of this tile)
+    if (grow < N) {
+      const hbits* src = patch + mj * MP + half16;
+      hbits* dst = D + (int64_t)grow * N + gcol;
+      if (gcol + 16 <= M && ((((int64_t)grow * N + gcol) & 7) == 0)) {
+        uint4 v0, v1;
+        unsigned w[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[e] = (unsigned)src[2 * e] | ((unsigned)src[2 * e + 1] << 16);
+        v0 = make_uint4(w[0], w[1], w[2], w[3]); v1 = make_uint4(w[4], w[5], w[6], w[7]);
+        reinterpret_cast<uint4*>(dst)[0] = v0; reinterpret_cast<uint4*>(dst)[1] = v1;
+      } else {
+        for (int e = 0; e < 16; e++) if (gcol + e < M) dst[e] = src[e];
+      }
+    }
   }
   if (mirror) {   // mirrored rows are this tile's columns: one lane per column and half-wave
     const unsigned o = (unsigned)__shfl_xor((int)cmax, 32, 64);
@@ -196,8 +221,7 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
   }
   const int nkb = (d + 31) / 32;
   hipLaunchKernelGGL(fill_u32_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, rowmax, nrows, 0u);
-  int symmetric = (row0 == 0 && nrows == N) ? 1 : 0;
-  { const char* e_ = getenv("SSG_I8_ABL"); if (e_ && symmetric) symmetric |= atoi(e_); }
+  const int symmetric = (row0 == 0 && nrows == N) ? 1 : 0;
   const int T = (N + GI_T - 1) / GI_T;
   const int64_t tiles = symmetric ? (int64_t)T * (T + 1) / 2 : (int64_t)((nrows + GI_T - 1) / GI_T) * T;
   if (tiles > 0x7fffffff) { ssg_set_error("ssg_sqdist_self_i8: too many tiles"); return SSG_ERR_INVALID; }
