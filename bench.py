@@ -32,6 +32,7 @@ import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_FP16_MFMA_TF = 2516.6    # MI355X_MICROARCH.md: dense fp16/bf16 matrix peak (v_mfma_f32_32x32x16_f16)
+PEAK_INT8_MFMA_TOPS = 5033.2  # dense int8 matrix peak (v_mfma_i32_32x32x32_i8 = 2x the fp16 rate)
 PEAK_FP64_MFMA_TF = 78.6      # SURVEY.md 8d / BASELINE.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 FLOP_PER_IMAGE = 10.68e9      # 2 forwards x 2 x 2.669 GMAC
@@ -251,12 +252,22 @@ def main():
             tf = flop * n / (ms * 1e-3) / 1e12
             hbm.append({"kernel": k, "bound": "mfma", "what": "fp64 Gram (v_mfma_f64_16x16x4); executed flops (self term: upper-triangle tiles only on 1 GPU)", "launches": n, "avg_launch_ms": round(ms / n, 4),
                         "achieved": round(tf, 2), "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_MFMA_TF, 4)})
+    if "ssg_sqdist_self_i8" in tot:
+        n, ms = tot["ssg_sqdist_self_i8"]
+        t64 = (args.N + 63) // 64
+        alg = ((t64 * (t64 + 1) // 2) * 64 * 64 if world == 1 else nrows * args.N) * 2.0 * 2048      # executed tiles (upper triangle on 1 GPU)
+        tops = 9.0 * alg * n / (ms * 1e-3) / 1e12                                                     # 3 x 3 digit products per multiply
+        hbm.append({"kernel": "ssg_sqdist_self_i8", "bound": "mfma", "what": "exact integer Gram on v_mfma_i32_32x32x32_i8: 3 balanced radix-256 digits per "
+                    "feature, 9 digit products per multiply; achieved = executed int8 ops, algorithmic_tflops = the 2*d flop per distance it replaces "
+                    "(fp64 MFMA peak for that: 78.6)", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tops, 1),
+                    "peak": PEAK_INT8_MFMA_TOPS, "unit": "TOP/s", "frac": round(tops / PEAK_INT8_MFMA_TOPS, 4),
+                    "algorithmic_tflops": round(alg * n / (ms * 1e-3) / 1e12, 1)})
     if "ssg_source_rowmin_filtered" in tot:
         n, ms = tot["ssg_source_rowmin_filtered"]
         tf = 2.0 * nrows * args.Ns * 2048 * n / (ms * 1e-3) / 1e12
-        hbm.append({"kernel": "ssg_source_rowmin_filtered", "bound": "mfma", "what": "source term by filter-and-refine: fp32-MFMA bound pass (2*N*Ns*d flop) + fp64 "
-                    "re-evaluation of candidate tiles; time covers both", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
-                    "peak": PEAK_FP32_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP32_MFMA_TF, 4)})
+        hbm.append({"kernel": "ssg_source_rowmin_filtered", "bound": "mfma", "what": "source term by filter-and-refine: split-half fp16-MFMA bound pass (2*N*Ns*d flop, 3 products each) + fp64 "
+                    "re-evaluation of candidate granules; time covers both; peak = fp16 MFMA / 3", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
+                    "peak": round(PEAK_FP16_MFMA_TF / 3.0, 1), "unit": "TFLOP/s", "frac": round(tf / (PEAK_FP16_MFMA_TF / 3.0), 4)})
     hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
                                     "ssg_eps_compact", "ssg_sort_u64", "ssg_eps_mean", "ssg_region_query", "ssg_dbscan_cc") if k in tot) / args.steps
     k5_12 = 8.0 * nrows * args.N / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else float("nan")
@@ -265,7 +276,7 @@ def main():
         "value": round(n_img / (ms_step * 1e-3), 2), "unit": "images/s (embedded + grouped per wall second, whole iteration)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (embed: split-half operands hi+lo on fp16 MFMA, fp32 accumulate, 6e-8 max error vs the fp32 reference features)" if split else
-                                                     "f32 (embed, fp32 MFMA)") + " / f64+f16 (distance, re-rank: fp64 MFMA, half semantics)",
+                                                     "f32 (embed, fp32 MFMA)") + " / exact int64 via int8 MFMA digits + f64 + f16 (distance, re-rank: half semantics, bit-exact)",
         "data": "synthetic: N(0,1) 256x128 images + seeded Kaiming ResNet-50 weights for the embed leg; clustered unit-norm 2048-d embeddings "
                 "(16 per identity) for the grouping leg (random-init backbone features are degenerate: reid/rerank.py:40 NaN path)",
         "config": {"workload": "BASELINE configs[1]+[2]: N=%d target + Ns=%d source images -> ResNet-50 2048-d embed (orig+flip) -> "

@@ -577,3 +577,33 @@ def test_evaluator_dropin(golden, dev):
         dist = ssg_amd.pairwise_distance(feats, query, gallery).numpy()
     _, oscores, otop1 = eval_oracle.evaluate_all(dist, pids[:4], pids, cams[:4], cams)
     assert top1 == otop1
+
+
+# ------------------------------------------------------------------ original distance: int8 exact Gram / fp64 fallback
+@pytest.mark.parametrize("case", [
+    # name, N, d, feature scale, env
+    ("i8_3digits", 700, 128, 1.0, {}),                                   # unit-norm rows: |feat| <= 0.49 -> 3 digits, 2 k blocks per stage
+    ("i8_3digits_odd_blocks", 300, 72, 1.0, {}),                         # d = 72 -> 3 k blocks (one per stage), zero-padded last block
+    ("i8_4digits_forced", 500, 64, 1.0, {"SSG_SELF_GRAM_DIGITS": "4"}),
+    ("i8_4digits_auto", 400, 40, 3.0, {}),                               # max |feat| in (0.49, 1]
+    ("fp64_fallback_range", 400, 64, 9.0, {}),                           # |feat| > 1: the integer path does not apply
+    ("fp64_forced", 500, 96, 1.0, {"SSG_SELF_GRAM": "f64"}),
+])
+def test_self_distance_paths_vs_oracle(case, dev, ora, monkeypatch):
+    """Every way the half 'original distance' (rerank.py:33,61-62) can be produced -- exact integer Gram on the int8 matrix
+    cores with 3 or 4 digits, fp64-MFMA fallback -- against the oracle's cdist restatement, bit for bit, incl. duplicate rows."""
+    from ssg_amd import rerank
+    name, N, d, scale, env = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(len(name))
+    x = rng.standard_normal((N, d)).astype(np.float32); x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x *= np.float32(scale)
+    if scale == 3.0:
+        x = np.clip(x, -1.0, 1.0); x[0, 0] = 0.9
+    x[7] = x[3]                                                          # duplicate rows: distance exactly 0
+    h = rerank.re_ranking_device(torch.from_numpy(x[:50].copy()).to(dev), torch.from_numpy(x).to(dev), no_rerank=True)
+    got = h.euclid.cpu().numpy().view(np.uint16)
+    ref = ora.euclid(x).view(np.uint16)
+    assert np.array_equal(got, ref), (name, int((got != ref).sum()))
+    assert got[7, 3] == 0 and got[3, 7] == 0
