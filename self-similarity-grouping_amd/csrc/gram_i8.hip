@@ -13,7 +13,9 @@
 // NL = 3 covers |feat| <= 0.498 (every real L2-normalised 2048-d embedding): 9 MFMAs per 32x32x32 block; NL = 4 covers
 // |feat| <= 1 (16 MFMAs).  The epilogue is the float64 one of pairwise.hip (sqrt -> half -> square -> half,
 // rerank.py:61-62) on the exactly converted integer, so D is bit-identical to the reference by construction (not just
-// with high probability).  Anything larger than 1 (or non-finite) is left to the fp64-MFMA kernel of pairwise.hip: the
+// with high probability) whenever d2 < 32 -- always true for L2-normalised rows (d2 <= 4); for un-normalised features in
+// [-1, 1] with larger distances both scipy's running sum and the int64 -> float64 conversion round in the last bit, like
+// the fp64 kernel.  Anything larger than 1 (or non-finite) is left to the fp64-MFMA kernel of pairwise.hip: the
 // caller picks NL from max|feat|; the encoder additionally raises a device flag if a digit does not fit.
 #include "ssg_common.h"
 #include <cstdlib>
