@@ -61,6 +61,23 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
   if (__any(bad) && lane == 0) atomicOr(flag, 1);
 }
 
+// One LDS stage of the multiply: KB2 k blocks; As / Bs point at this lane's row of the A / B stage tile (+ its 16-byte k half).
+template <int NL, int KB2>
+__device__ __forceinline__ void gi_multiply(const unsigned char* As, const unsigned char* Bs, v16i (&acc)[2 * NL - 1]) {
+  constexpr int BLK = 32 * NL;
+#pragma unroll
+  for (int q = 0; q < KB2; q++) {
+    v4i a[NL], b[NL];
+#pragma unroll
+    for (int L = 0; L < NL; L++) { a[L] = *reinterpret_cast<const v4i*>(As + q * BLK + L * 32); b[L] = *reinterpret_cast<const v4i*>(Bs + q * BLK + L * 32); }
+    // digit products grouped by weight a+b; consecutive MFMAs go to different accumulators
+#pragma unroll
+    for (int La = 0; La < NL; La++)
+#pragma unroll
+      for (int Lb = 0; Lb < NL; Lb++) acc[La + Lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[La], b[Lb], acc[La + Lb], 0, 0, 0);
+  }
+}
+
 // D[i,j] = half(half(sqrt(d2))^2) for rows [rowA0, rowA0+M) x all N columns, atomicMax rowmax.  EA = encoded rows of the
 // row block, EB = encoded rows of the whole set.  symmetric: only tiles on/above the diagonal are launched, mirrored on store.
 template <int NL, int KB2>
@@ -101,39 +118,57 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     gp[p] = reinterpret_cast<const uint4*>((mat ? EB : EA) + (int64_t)grow * nkb * BLK) + ch;
     lo[p] = mat * (GI_T * PITCH) + row * PITCH + ch * 16;
   }
-  uint4 pf[NCH];
   v16i acc[NACC];
 #pragma unroll
   for (int w = 0; w < NACC; w++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[w][r] = 0;
 
-#pragma unroll
-  for (int p = 0; p < NCH; p++) *reinterpret_cast<uint4*>(lds + lo[p]) = gp[p][0];
-  __syncthreads();
   const int nst = nkb / KB2;
-  for (int st = 0; st < nst; st++) {
-    const int sn = min(st + 1, nst - 1);      // next stage's L2 latency hides under this stage's MFMAs (clamped: branch-free)
-#pragma unroll
-    for (int p = 0; p < NCH; p++) pf[p] = gp[p][sn * CPR];
-    const unsigned char* As = lds + (st & 1) * (2 * GI_T * PITCH) + (wm * 32 + l32) * PITCH + h * 16;
-    const unsigned char* Bs = lds + (st & 1) * (2 * GI_T * PITCH) + GI_T * PITCH + (wn * 32 + l32) * PITCH + h * 16;
-#pragma unroll
-    for (int q = 0; q < KB2; q++) {
-      v4i a[NL], b[NL];
-#pragma unroll
-      for (int L = 0; L < NL; L++) { a[L] = *reinterpret_cast<const v4i*>(As + q * BLK + L * 32); b[L] = *reinterpret_cast<const v4i*>(Bs + q * BLK + L * 32); }
-      // digit products grouped by weight a+b; consecutive MFMAs go to different accumulators
-#pragma unroll
-      for (int La = 0; La < NL; La++)
-#pragma unroll
-        for (int Lb = 0; Lb < NL; Lb++) acc[La + Lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[La], b[Lb], acc[La + Lb], 0, 0, 0);
-    }
-    // other stage: its readers finished before the previous barrier (redundant after the last stage)
-#pragma unroll
-    for (int p = 0; p < NCH; p++) *reinterpret_cast<uint4*>(lds + ((st + 1) & 1) * (2 * GI_T * PITCH) + lo[p]) = pf[p];
+  const unsigned char* As0 = lds + (wm * 32 + l32) * PITCH + h * 16;
+  const unsigned char* Bs0 = lds + GI_T * PITCH + (wn * 32 + l32) * PITCH + h * 16;
+  // A stage (18 MFMAs with 3 digits) is shorter than the L2 latency, so the global loads run TWO stages ahead in two
+  // register sets (set 0 holds odd stages, set 1 even ones); stage indices are clamped instead of branching around
+  // loads.  Named scalars, not arrays: hipcc keeps loop-carried uint4 arrays in scratch memory.
+  static_assert(NCH <= 6, "staging code is written for at most 6 chunks per thread");
+  uint4 pa0, pa1, pa2, pa3, pa4, pa5, pb0, pb1, pb2, pb3, pb4, pb5;
+  pa0 = pa1 = pa2 = pa3 = pa4 = pa5 = pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = make_uint4(0, 0, 0, 0);
+#define SSG_GL(S, ST)                                                                                 \
+  {                                                                                                   \
+    const int so_ = (ST) * CPR;                                                                       \
+    p##S##0 = gp[0][so_]; if (NCH > 1) p##S##1 = gp[1][so_]; if (NCH > 2) p##S##2 = gp[2][so_];         \
+    if (NCH > 3) p##S##3 = gp[3][so_]; if (NCH > 4) p##S##4 = gp[4][so_]; if (NCH > 5) p##S##5 = gp[5][so_]; \
+  }
+#define SSG_LS(S, BUF)                                                                                \
+  {                                                                                                   \
+    unsigned char* b_ = lds + (BUF) * (2 * GI_T * PITCH);                                             \
+    *reinterpret_cast<uint4*>(b_ + lo[0]) = p##S##0;                                                  \
+    if (NCH > 1) *reinterpret_cast<uint4*>(b_ + lo[1]) = p##S##1;                                     \
+    if (NCH > 2) *reinterpret_cast<uint4*>(b_ + lo[2]) = p##S##2;                                     \
+    if (NCH > 3) *reinterpret_cast<uint4*>(b_ + lo[3]) = p##S##3;                                     \
+    if (NCH > 4) *reinterpret_cast<uint4*>(b_ + lo[4]) = p##S##4;                                     \
+    if (NCH > 5) *reinterpret_cast<uint4*>(b_ + lo[5]) = p##S##5;                                     \
+  }
+  SSG_GL(a, 0)
+  SSG_LS(a, 0)
+  { const int s1 = min(1, nst - 1); SSG_GL(a, s1) }
+  __syncthreads();
+  int st = 0;
+  for (; st + 1 < nst; st += 2) {
+    { const int sn = min(st + 2, nst - 1); SSG_GL(b, sn) }
+    __builtin_amdgcn_sched_barrier(0);
+    gi_multiply<NL, KB2>(As0, Bs0, acc);
+    SSG_LS(a, 1)                                   // stage st+1 -> buffer 1
+    __syncthreads();
+    { const int sn = min(st + 3, nst - 1); SSG_GL(a, sn) }
+    __builtin_amdgcn_sched_barrier(0);
+    gi_multiply<NL, KB2>(As0 + 2 * GI_T * PITCH, Bs0 + 2 * GI_T * PITCH, acc);
+    SSG_LS(b, 0)                                   // stage st+2 -> buffer 0
     __syncthreads();
   }
+  if (st < nst) { gi_multiply<NL, KB2>(As0, Bs0, acc); __syncthreads(); }      // odd stage count: the last stage sits in buffer 0
+#undef SSG_GL
+#undef SSG_LS
 
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31 -> B row (j), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> A row (i).
   const int gj = tn * GI_T + wn * 32 + l32;
@@ -232,8 +267,8 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
 #define SSG_GI_LAUNCH(NL_, KB_) hipLaunchKernelGGL((gram_i8_kernel<NL_, KB_>), dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, \
     (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag)
   static int kb2 = -1;
-  if (kb2 < 0) { const char* e_ = getenv("SSG_I8_KB2"); kb2 = e_ ? atoi(e_) : 2; }
-  const bool two = kb2 == 2 && (nkb % 2) == 0;     // two k blocks per LDS stage: half the barriers (53 KB of LDS with 3 digits)
+  if (kb2 < 0) { const char* e_ = getenv("SSG_I8_KB2"); kb2 = e_ ? atoi(e_) : 1; }   // measured: 1 block per stage (3 waves/SIMD) 2.64 ms, 2 blocks (2 waves/SIMD) 2.9 ms at N=16000
+  const bool two = kb2 == 2 && (nkb % 2) == 0;     // two k blocks per LDS stage: half the barriers, but 190 VGPRs
   if (ndigits == 3) { if (two) SSG_GI_LAUNCH(3, 2); else SSG_GI_LAUNCH(3, 1); }
   else SSG_GI_LAUNCH(4, 1);
 #undef SSG_GI_LAUNCH
