@@ -910,7 +910,9 @@ extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, in
   p.M = nrows; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)nrows * d * 4);
   p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles; p.out_split = p.res_split = 0;
   p.acc_scale = split ? 1.f / (scale_t * scale_s) : 1.f;
-  int rc = split ? launch_conv_bk<128, 128, 64, 64, false, 32, true>(p, stream) : launch_conv<128, 128, 64, 64, false>(p, stream);
+  // 128x256 tiles when the padded source count allows: 3/4 of the global->LDS bytes of the 128x128 tile
+  int rc = split ? ((Ns_pad % 256) == 0 ? launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream) : launch_conv_bk<128, 128, 64, 64, false, 32, true>(p, stream))
+                 : launch_conv<128, 128, 64, 64, false>(p, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
   SSG_LAUNCH_CHECK("source_refine_kernel");

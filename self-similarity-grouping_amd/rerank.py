@@ -94,7 +94,7 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
     tblk = tgt[row0:row0 + nrows]
     Ns = src.shape[0]
     if not exact_gemm and (nrows * d * 4) < 2 ** 31:
-        npad = (-Ns) % 128
+        npad = (-Ns) % 256
         srcp = torch.nn.functional.pad(src, (0, 0, 0, npad)) if npad else src
         # rigorous float32 error bound of |x|^2 + |y|^2 - 2<x,y>: the MFMA dot is a d-term fmaf chain
         # (|err| <= gamma_d * sum|x_k y_k| <= gamma_d |x||y|, gamma_d = d*u/(1-d*u), u = 2^-24); the squared
