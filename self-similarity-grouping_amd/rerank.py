@@ -76,14 +76,15 @@ def _as_dev_f32(x, device):
     return x
 
 
-def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
+def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
     """reid/rerank.py:35-40 on device -> (rowmin uint32-as-int32 [nrows]) for a row block.
 
     Default: filter-and-refine (a matrix-core pass bounds every distance per 8-source granule -- split-half
     operands on the fp16 cores, or float32 MFMA with SSG_SOURCE_BOUND=f32 -- then float64 re-evaluates the
     granules that can still hold the minimum): the exact minimum of the half-rounded float64 distances
     at a fraction of the cost of the full float64 Gram.  exact_gemm=True (or SSG_SOURCE_EXACT_GEMM=1)
-    forces the full fp64-MFMA pass."""
+    forces the full fp64-MFMA pass.  stats: optional (max|tgt|, max|src|, max target row norm, max source row norm)
+    upper bounds already on the host (saves the device round trip)."""
     import os
     L = _lib.lib()
     N, d = tgt.shape
@@ -99,7 +100,9 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
         # rigorous float32 error bound of |x|^2 + |y|^2 - 2<x,y>: the MFMA dot is a d-term fmaf chain
         # (|err| <= gamma_d * sum|x_k y_k| <= gamma_d |x||y|, gamma_d = d*u/(1-d*u), u = 2^-24); the squared
         # norms come from a 32-term chain + 6-level tree (38 u relative); a few ulps for the final adds.
-        nx = float(tblk.norm(dim=1).max().item()); ny = float(src.norm(dim=1).max().item())
+        if stats is None:      # (max|tgt|, max|src|, max row norm of the block, max row norm of src): one host read
+            stats = torch.stack([tblk.abs().max(), src.abs().max(), tblk.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
+        mt, ms, nx, ny = (float(s) for s in stats)
         u = 2.0 ** -24
         split = os.environ.get("SSG_SOURCE_BOUND", "split") == "split"
         st = ss = 0.0
@@ -108,7 +111,6 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None):
             # representations + the dropped lo*lo term) + 2^-24 absolute per operand below the half normals; the
             # accumulation is at most a 3d-term chain (three MFMA products per term), whatever order the hardware adds in
             import math
-            mt = float(tblk.abs().max().item()); ms = float(src.abs().max().item())
             st = 256.0 if mt == 0 else min(256.0, 2.0 ** math.floor(math.log2(16384.0 / mt)))
             ss = 256.0 if ms == 0 else min(256.0, 2.0 ** math.floor(math.log2(16384.0 / ms)))
             gam = 3.0 * d * u * 1.01 / (1.0 - 3.0 * d * u)
@@ -156,30 +158,37 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
     D = torch.empty((nrows, N), dtype=torch.float16, device=dev)
     rowmax = torch.empty(nrows, dtype=torch.int32, device=dev)
+    # every range / norm bound the pipeline needs from the host, in ONE device round trip
+    if no_rerank:
+        stats = [float(tgt.abs().max().item())]
+    else:
+        stats = torch.stack([tgt.abs().max(), src.abs().max(), tgt.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
     use_i8 = os.environ.get("SSG_SELF_GRAM", "i8") == "i8" and d <= 16384
+    flag = None
     if use_i8:
         # exact integer Gram on the int8 matrix cores (half-rounded features in [-1, 1]: scipy's float64 sum is exact);
         # 3 radix-256 digits cover |feat| <= 0.498 (any real L2-normalised embedding), 4 digits |feat| <= 1
-        mx = float(tgt.abs().max().item())
+        mx = float(stats[0])
         nd = int(os.environ.get("SSG_SELF_GRAM_DIGITS", "0")) or (3 if mx <= 0.49 else 4)
-        use_i8 = mx <= 1.0
+        use_i8 = mx <= 1.0                       # (False for NaN as well)
     if use_i8:
         enc = torch.empty(L.ssg_gram_i8_encoded_bytes(N, d, nd), dtype=torch.int8, device=dev)
         inorm = torch.empty(N, dtype=torch.int64, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         check(L.ssg_gram_i8_encode(ptr(tgt), N, d, nd, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
         check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, nd, row0, nrows, ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
-        use_i8 = int(flag.item()) == 0            # never expected after the range check above; the kernel wrote nothing if set
-        del enc, inorm
+        del enc, inorm                            # (the flag cannot be set after the range check above; verified below)
     if not use_i8:
         norms = torch.empty(N, dtype=torch.float64, device=dev)
         check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
         check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
     if no_rerank:
+        if flag is not None and int(flag.item()):
+            raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
         return DistHandle(N, 1, D, euclid=D, row0=row0, nrows=nrows, group=group)
 
     # ---- source-domain term (rerank.py:35-40): v half [N]
-    rowmin = _gather_rows(source_vector(src, tgt, row0, nrows), group)
+    rowmin = _gather_rows(source_vector(src, tgt, row0, nrows, stats=stats), group)
     v = torch.empty(N, dtype=torch.float16, device=dev)
     vmax = torch.zeros(1, dtype=torch.int32, device=dev)
     check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
@@ -232,7 +241,10 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
                              om, ptr(Jp), st), "ssg_jaccard_rows")
 
-    if int(vmax.item()) & 0x7FFF == 0:
+    vmax_h, flag_h = torch.cat([vmax, flag if flag is not None else torch.zeros_like(vmax)]).tolist()
+    if flag_h:
+        raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
+    if int(vmax_h) & 0x7FFF == 0:
         raise ReRankNaNError("max(source_dist_vec) == 0: every target->source 1-exp(-d^2) rounds to 0 in float16; the reference "
                              "(reid/rerank.py:40) would return an all-NaN final_dist")
     if stages is not None:
