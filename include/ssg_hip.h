@@ -186,6 +186,17 @@ int ssg_gap_stripes(const float* in, float* out, int B, int H, int W, int C, int
 /* out = (a+b)/||a+b||_2 per row (evaluators.py:31-35: original + flipped features, L2 norm) */
 int ssg_flip_sum_l2norm(const float* a, const float* b, float* out, int rows, int C, ssg_stream_t stream);
 
+/* ---- kNN-set Jaccard re-ranking variant (reid/rerank_plain.py:125-178 re_ranking; shares K3/K4 with rerank.py) */
+/* A_i = { j != i : D[i,j] <= k-th smallest of row i } (:165-170).  rank = ssg_topk_rank of the same rows with rowmax = half(1)
+ * everywhere and K = k; a_idx/a_val [nrows, cap] (a_val = half 1: feed ssg_invert_index), a_nnz [nrows]; *overflow = rows
+ * with more than cap members. */
+int ssg_knn_sets(const uint16_t* D, const int32_t* rank, int N, int row0, int nrows, int K, int cap, int32_t* a_idx, uint16_t* a_val,
+                 int32_t* a_nnz, int32_t* overflow, ssg_stream_t stream);
+/* J'[i,k] = half(half(|A_i xor A_k| / |A_i or A_k|) * half(1-lambda)) (scipy cdist 'jaccard' on booleans, :173-175; 0 for
+ * two empty sets) for rows [row0,row0+nrows); a_idx/a_nnz cover all N rows, colptr/inv_row = ssg_invert_index of them. */
+int ssg_set_jaccard_rows(const int32_t* a_idx, const int32_t* a_nnz, int capA, const int64_t* colptr, const int32_t* inv_row, int N, int row0,
+                         int nrows, uint16_t one_minus_lambda_half, uint16_t* Jp, ssg_stream_t stream);
+
 /* ---- retrieval metrics of the evaluation step (reid/evaluators.py:88-129 evaluate_all ->
  * reid/evaluation_metrics/ranking.py:18-79 cmc, :82-115 mean_ap + sklearn average_precision_score) */
 /* dist [m, ld] float32 query x gallery block; ids / cams int32.  first_rank[q] = number of valid gallery entries

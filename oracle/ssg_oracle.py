@@ -205,3 +205,31 @@ def re_ranking_init_dist(q_g_dist, q_q_dist, g_g_dist, k1=20, k2=6, lambda_value
     out = np.empty((nq, N - nq), np.float32)
     lib().ora_re_ranking_init(_p(dots, _f32p), N, nq, int(k1), int(k2), ctypes.c_float(lambda_value), _p(out, _f32p))
     return out
+
+
+def re_ranking_plain(input_feature_source, input_feature, k=20, lambda_value=0.1, MemorySave=False, Minibatch=2000, stages=False):
+    """Restatement of reid/rerank_plain.py:125-178 re_ranking (kNN-set Jaccard variant): source term and half
+    original distance exactly as rerank.py (same lines), knn_bool[i] = {j != i : D[i,j] <= k-th smallest of row i}
+    (:165-170, np.partition), jaccard = scipy cdist(bool, bool, 'jaccard') = |A xor B| / |A or B| in float64 (0 when
+    both sets are empty) -> half (:173), final = f64(half(J * half(1-lambda))) + f64(half(v_i + v_k)) * lambda (:175).
+    Returns (final_dist, final_dist) like the reference; stages=True adds a dict(knn, jaccard, v, euclid)."""
+    src = _c(input_feature_source, np.float32); tgt = _c(input_feature, np.float32)
+    _, v, _ = source_vec(tgt, src)                       # half [N], already divided by its max
+    D = euclid(tgt)                                      # half [N, N]
+    N = D.shape[0]
+    thr = np.partition(D, k - 1, axis=1)[:, k - 1]
+    knn = D <= thr[:, None]
+    knn[np.arange(N), np.arange(N)] = False
+    A = knn.astype(np.int32)
+    c = A @ A.T                                          # |A_i and A_k|
+    n = A.sum(axis=1)
+    denom = n[:, None] + n[None, :] - c
+    num = denom - c
+    J = np.zeros((N, N), np.float64)
+    np.divide(num, denom, out=J, where=denom != 0)
+    J16 = J.astype(np.float16)
+    source_dist = (v[None, :] + v[:, None]).astype(np.float64)      # half + half -> half, widened
+    final = (J16 * (1 - lambda_value)) + source_dist * lambda_value   # half * python float stays half (NEP 50), then + float64
+    if stages:
+        return final, final, dict(knn=knn, jaccard=J16, v=v, euclid=D)
+    return final, final

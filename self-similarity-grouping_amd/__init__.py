@@ -24,6 +24,9 @@ def __getattr__(name):   # lazy: torch import only when the compute surface is t
     if name in ("extract_features", "extract_embeddings", "extract_cnn_feature", "fliplr", "pairwise_distance", "pairwise_distance_device"):
         from . import evaluators
         return getattr(evaluators, name)
+    if name in ("re_ranking_plain", "re_ranking_plain_device"):
+        from . import rerank_plain
+        return rerank_plain.re_ranking if name == "re_ranking_plain" else rerank_plain.re_ranking_plain_device
     if name in ("cmc", "mean_ap", "evaluate_all", "Evaluator"):
         from . import ranking
         return getattr(ranking, name)

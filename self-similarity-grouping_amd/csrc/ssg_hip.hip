@@ -10,3 +10,4 @@
 #include "conv.hip"
 #include "rerank_init.hip"
 #include "ranking.hip"
+#include "rerank_plain.hip"

@@ -133,6 +133,36 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
     return rowmin
 
 
+def _original_distance(L, tgt, row0, nrows, max_abs, st):
+    """rows [row0,row0+nrows) of the half original distance (rerank.py:33,61-62) + their maxima -> (D, rowmax, flag).
+    max_abs = max|tgt| on the host; flag = device flag of the int8 encoder (None on the fp64 path), to be read with the
+    caller's next host round trip (it cannot be set after the range check here)."""
+    dev = tgt.device
+    N, d = tgt.shape
+    D = torch.empty((nrows, N), dtype=torch.float16, device=dev)
+    rowmax = torch.empty(nrows, dtype=torch.int32, device=dev)
+    use_i8 = os.environ.get("SSG_SELF_GRAM", "i8") == "i8" and d <= 16384
+    flag = None
+    if use_i8:
+        # exact integer Gram on the int8 matrix cores (half-rounded features in [-1, 1]: scipy's float64 sum is exact);
+        # 3 radix-256 digits cover |feat| <= 0.498 (any real L2-normalised embedding), 4 digits |feat| <= 1
+        mx = float(max_abs)
+        nd = int(os.environ.get("SSG_SELF_GRAM_DIGITS", "0")) or (3 if mx <= 0.49 else 4)
+        use_i8 = mx <= 1.0                       # (False for NaN as well)
+    if use_i8:
+        enc = torch.empty(L.ssg_gram_i8_encoded_bytes(N, d, nd), dtype=torch.int8, device=dev)
+        inorm = torch.empty(N, dtype=torch.int64, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(L.ssg_gram_i8_encode(ptr(tgt), N, d, nd, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
+        check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, nd, row0, nrows, ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
+        del enc, inorm
+    else:
+        norms = torch.empty(N, dtype=torch.float64, device=dev)
+        check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
+        check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
+    return D, rowmax, flag
+
+
 from .dist import gather_rows as _gather_rows  # noqa: E402
 
 
@@ -155,33 +185,13 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     d = tgt.shape[1]
     st = stream()
 
-    # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
-    D = torch.empty((nrows, N), dtype=torch.float16, device=dev)
-    rowmax = torch.empty(nrows, dtype=torch.int32, device=dev)
     # every range / norm bound the pipeline needs from the host, in ONE device round trip
     if no_rerank:
         stats = [float(tgt.abs().max().item())]
     else:
         stats = torch.stack([tgt.abs().max(), src.abs().max(), tgt.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
-    use_i8 = os.environ.get("SSG_SELF_GRAM", "i8") == "i8" and d <= 16384
-    flag = None
-    if use_i8:
-        # exact integer Gram on the int8 matrix cores (half-rounded features in [-1, 1]: scipy's float64 sum is exact);
-        # 3 radix-256 digits cover |feat| <= 0.498 (any real L2-normalised embedding), 4 digits |feat| <= 1
-        mx = float(stats[0])
-        nd = int(os.environ.get("SSG_SELF_GRAM_DIGITS", "0")) or (3 if mx <= 0.49 else 4)
-        use_i8 = mx <= 1.0                       # (False for NaN as well)
-    if use_i8:
-        enc = torch.empty(L.ssg_gram_i8_encoded_bytes(N, d, nd), dtype=torch.int8, device=dev)
-        inorm = torch.empty(N, dtype=torch.int64, device=dev)
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        check(L.ssg_gram_i8_encode(ptr(tgt), N, d, nd, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
-        check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, nd, row0, nrows, ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
-        del enc, inorm                            # (the flag cannot be set after the range check above; verified below)
-    if not use_i8:
-        norms = torch.empty(N, dtype=torch.float64, device=dev)
-        check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
-        check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
+    # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
+    D, rowmax, flag = _original_distance(L, tgt, row0, nrows, stats[0], st)
     if no_rerank:
         if flag is not None and int(flag.item()):
             raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")

@@ -607,3 +607,40 @@ def test_self_distance_paths_vs_oracle(case, dev, ora, monkeypatch):
     ref = ora.euclid(x).view(np.uint16)
     assert np.array_equal(got, ref), (name, int((got != ref).sum()))
     assert got[7, 3] == 0 and got[3, 7] == 0
+
+
+# ------------------------------------------------------------------ kNN-set Jaccard variant
+def test_rerank_plain_vs_reference_golden(golden, dev):
+    """HIP rerank_plain.re_ranking vs the reference's float64 final_dist (bitwise), eps and DBSCAN labels on top of it."""
+    import io, contextlib
+    import ssg_amd
+    from ssg_amd import cluster, rerank_plain
+    g = golden("rerank_plain.npz")
+    for tag in "abc":
+        k, lam = int(g["k_" + tag]), float(g["lam_" + tag])
+        st = {}
+        h = rerank_plain.re_ranking_plain_device(torch.from_numpy(g["src_" + tag]).to(dev), torch.from_numpy(g["tgt_" + tag]).to(dev), k=k, lambda_value=lam, stages=st)
+        assert np.array_equal(st["a_nnz"].cpu().numpy(), g["setsize_" + tag])
+        assert np.array_equal(h.final_dist().cpu().numpy(), g["final_" + tag]), tag
+        eps, _, _ = cluster.eps_rule(h, float(g["rho_" + tag]))
+        assert eps == float(g["eps_" + tag])
+        assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h), g["labels_" + tag])
+    with contextlib.redirect_stdout(io.StringIO()):
+        f1, f2 = ssg_amd.re_ranking_plain(g["src_a"], g["tgt_a"], k=int(g["k_a"]), lambda_value=float(g["lam_a"]))
+    assert f1 is f2 and np.array_equal(np.asarray(f1), g["final_a"])
+
+
+def test_rerank_plain_ties_and_chunks_vs_oracle(dev, ora):
+    """Heavy ties at the k-th distance (quantised features -> sets far larger than k, capacity retry), duplicate rows, k=1
+    (possibly empty sets) and N > 32768 columns per LDS pass are not needed for correctness of one chunk but the multi-row
+    persistent path is: N = 3000."""
+    from ssg_amd import rerank_plain
+    rng = np.random.default_rng(9)
+    N, d = 3000, 32
+    tgt = (rng.integers(0, 3, (N, d)) / 8.0).astype(np.float32)          # few distinct distances: large tie groups
+    tgt[11] = tgt[4]
+    src = rng.standard_normal((200, d)).astype(np.float32) * 0.3
+    for k, lam in ((20, 0.1), (1, 0.3)):
+        h = rerank_plain.re_ranking_plain_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k=k, lambda_value=lam)
+        ref, _ = ora.re_ranking_plain(src, tgt, k=k, lambda_value=lam)
+        assert np.array_equal(h.final_dist().cpu().numpy(), ref), (k, lam)

@@ -137,3 +137,16 @@ def test_eval_oracle_matches_reference_golden(golden):
     d = np.array([[0.1, 0.2, 0.3]], np.float32)
     with pytest.raises(RuntimeError):
         eval_oracle.mean_ap(d, [1], [1, 2, 3], [0], [0, 1, 1])
+
+
+def test_rerank_plain_oracle_matches_reference_golden(golden):
+    """kNN-set Jaccard variant (reid/rerank_plain.py:125-178): oracle restatement vs the reference's own output, bitwise."""
+    from oracle import ssg_oracle as ora
+    g = golden("rerank_plain.npz")
+    for tag in "abc":
+        final, final2, st = ora.re_ranking_plain(g["src_" + tag], g["tgt_" + tag], k=int(g["k_" + tag]), lambda_value=float(g["lam_" + tag]), stages=True)
+        assert final is final2 and np.array_equal(final, g["final_" + tag])
+        assert np.array_equal(st["knn"].sum(axis=1), g["setsize_" + tag])
+        eps, _, _ = ora.eps_rule(final, float(g["rho_" + tag]))
+        assert eps == float(g["eps_" + tag])
+        assert np.array_equal(ora.dbscan(final, eps, 4), g["labels_" + tag])

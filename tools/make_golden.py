@@ -231,6 +231,34 @@ def eval_fixture():
     return ok
 
 
+def plain_fixture():
+    """reid/rerank_plain.py re_ranking (kNN-set Jaccard variant): oracle restatement vs the reference."""
+    import contextlib
+    import io
+    spec = importlib.util.spec_from_file_location("ref_plain", os.path.join(REF, "reid", "rerank_plain.py"))
+    mp = importlib.util.module_from_spec(spec); spec.loader.exec_module(mp)
+    ok = True
+    rec = {}
+    for tag, N, Ns, d, seed, lam, k in (("a", 96, 64, 32, 51, 0.1, 20), ("b", 300, 200, 64, 52, 0.3, 12), ("c", 512, 384, 64, 53, 0.1, 20)):
+        tgt = clustered(N, d, seed); src = clustered(Ns, d, seed + 1000, intra=0.6)
+        if tag == "b":
+            tgt[5] = tgt[9]                                  # duplicate rows: ties at distance 0
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref, ref2 = mp.re_ranking(src, tgt, k=k, lambda_value=lam)
+        mine, _, st = ora.re_ranking_plain(src, tgt, k=k, lambda_value=lam, stages=True)
+        good = beq(ref, mine) and ref is ref2
+        sizes = st["knn"].sum(axis=1)
+        print("rerank_plain %s: N=%d k=%d lambda=%.1f set sizes %d..%d  oracle==reference (bitwise): %s" % (tag, N, k, lam, sizes.min(), sizes.max(), good))
+        ok = ok and bool(good)
+        rho = 2e-2 if N < 256 else 1.6e-3
+        eps, cnt, top = eps_rule_ref(ref, rho)
+        labels = DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(ref)
+        rec.update({"src_" + tag: src, "tgt_" + tag: tgt, "k_" + tag: k, "lam_" + tag: lam, "final_" + tag: ref, "rho_" + tag: rho,
+                    "eps_" + tag: np.float64(eps), "labels_" + tag: labels.astype(np.int64), "setsize_" + tag: sizes.astype(np.int32)})
+    np.savez_compressed(os.path.join(OUT, "rerank_plain.npz"), **rec)
+    return ok
+
+
 def init_fixture(mod):
     """re_ranking_init (float32 cosine variant, rerank.py:171-234 / rerank_initial.py:40-99)."""
     spec = importlib.util.spec_from_file_location("ref_init", os.path.join(REF, "reid", "rerank_initial.py"))
@@ -253,6 +281,10 @@ def init_fixture(mod):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if "--only-plain" in sys.argv:        # regenerate just tests/golden/rerank_plain.npz
+        ok = plain_fixture()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     if "--only-eval" in sys.argv:         # regenerate just tests/golden/eval_cases.npz
         ok = eval_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
@@ -366,6 +398,7 @@ def main():
     ok = init_fixture(mod) and ok
     ok = embed_fixture() and ok
     ok = eval_fixture() and ok
+    ok = plain_fixture() and ok
     print("ALL OK" if ok else "ORACLE MISMATCH")
     sys.exit(0 if ok else 1)
 
