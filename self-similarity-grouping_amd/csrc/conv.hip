@@ -65,7 +65,7 @@ struct ConvParams {
   // epilogue mode 1 (pairwise distance, reid/evaluators.py:63-85): out = rowterm[m] + bias[col] - 2*acc
   const float* rowterm; int epi;
   // epilogue mode 3 (distance filter): no matrix store; per output row the minimum of rowterm+bias-2*acc over each
-  // 64-column wave tile goes to tilemin[m * tmin_ld + tile]
+  // 8-column granule goes to tilemin[m * tmin_ld + column / 8]
   float* tilemin; int tmin_ld;
   // split-half format (see "split-half activations" below): which tensors are encoded, and the factor
   // that undoes the operand scaling (weights / features are pre-scaled by a power of two)
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
 //   out[i, j] = rowterm[i] + colterm[j] - 2 * <x_i, y_j>      x [m,d], y [n,d], out [m,n]
 // rowterm/colterm are computed here: |x_i|^2 and |y_j|^2, or (self_form != 0, the reference's
 // query=None branch :64-72) rowterm = 2*|x_i|^2, colterm = 0.  d % 32 == 0, n % 64 == 0 (pad).
-// ws: m + n floats.  Same fp32-MFMA GEMM as the convolutions.
+// ws: m + n floats.  The fp32-MFMA instantiation of the convolution GEMM (SPLIT = false).
 extern "C" int ssg_pairwise_sqdist_f32(const float* x, const float* y, int m, int n, int d, int self_form, float* ws, float* out, hipStream_t stream) {
   if (m <= 0 || n <= 0 || (d % 32) || (n % 64) || (int64_t)m * d * 4 > 0x7fffffffLL) {
     ssg_set_error("ssg_pairwise_sqdist_f32: need d %% 32 == 0, n %% 64 == 0 and x < 2 GiB (m=%d n=%d d=%d)", m, n, d);
@@ -878,7 +878,7 @@ __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restr
 }  // namespace ssg
 
 // Source-term row minimum (reid/rerank.py:36-37,39) by filter-and-refine: a float32 MFMA pass bounds every
-// target-source distance (per row and 64-source tile), a float64 pass re-evaluates only the tiles within `tol`
+// target-source distance (per row and 8-source granule), a float64 pass re-evaluates only the granules within `tol`
 // of the row's bound.  Same result as ssg_source_rowmin_f16 (exact min of the half-rounded float64 distances)
 // whenever tol >= the float32 error of the bound (callers pass 8*d*2^-24*max|x|*max|y| + margin).
 // tgt [nrows,d], src [Ns_pad,d] (rows >= Ns are padding), d % 32 == 0, Ns_pad % 128 == 0.
