@@ -41,6 +41,19 @@ def test_argument_validation_without_gpu():
     assert L.ssg_eps_hist(None, None, 10, 0, 10, 0, 0.1, 0, 51, 12, 1, None, None) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
+    # entry points added with the split-half embedding, the int8 Gram, the evaluation step and the kNN-set variant
+    assert L.ssg_conv2d_nhwc_x(None, None, None, None, None, 2, 8, 8, 48, 64, 1, 1, 1, 0, 1, 3, 1.0, None) == -1          # Cin % 32
+    assert b"unsupported shape" in L.ssg_last_error()
+    assert L.ssg_conv1x1_dual_nhwc_x(None, None, None, None, None, 2, 8, 8, 64, 4, 4, 64, 2, 96, 1, 3, 1.0, None) == -1   # Cout % 64, grid
+    assert L.ssg_h8l8_encode(None, None, 12, 1.0, None) == -1 and L.ssg_h8l8_decode(None, None, 0, 1.0, None) == -1       # n % 8
+    assert L.ssg_gram_i8_encode(None, 4, 64, 5, None, None, None, None) == -1                                             # digits must be 3 or 4
+    assert L.ssg_gram_i8_encode(None, 4, 20000, 3, None, None, None, None) == -1                                          # d > 16384 (int32 headroom)
+    assert L.ssg_sqdist_self_i8(None, None, 8, 64, 3, 4, 8, None, None, None, None) == -1                                 # row block outside N
+    assert L.ssg_gram_i8_encoded_bytes(10, 70, 3) == 10 * 3 * 32 * 3                                                      # 3 k blocks of 32, 3 digits
+    assert L.ssg_source_rowmin_filtered(None, None, 8, 100, 100, 64, 1e-3, 0.0, 0.0, None, None, None) == -1              # Ns_pad % 128
+    assert L.ssg_rank_metrics(None, 4, 10, 8, None, None, None, None, 0, None, None, None, None) == -1                     # ld < n
+    assert L.ssg_knn_sets(None, None, 10, 0, 10, 11, 64, None, None, None, None, None) == -1                              # K > N
+    assert L.ssg_set_jaccard_rows(None, None, 0, None, None, 10, 0, 10, 0, None, None) == -1
 
 
 def test_no_cpu_fallback(monkeypatch):
