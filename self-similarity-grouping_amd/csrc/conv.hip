@@ -509,6 +509,191 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
   }
 }
 
+// ---- LDS-DMA variant of the split-half GEMM (128x256 tile, 8 waves) ----------------------------------------------------
+// The register-staged kernel above runs ONE 8-wave workgroup per CU on its 128x256 tile: two BK=32 stages take 110 KB of
+// LDS and the two prefetch register sets 48 VGPRs.  Here the tiles go global -> LDS directly (buffer_load_dwordx4 ... lds,
+// 16 bytes per lane on gfx950): no staging registers, no ds_write, BK=16 stages of 24 KB in three separate __shared__ arrays
+// (so that the compiler can see that the DMA into one stage does not alias the fragment reads of the other and keeps it
+// in flight under the MFMAs) -> 72 KB of LDS and < 128 VGPRs: two workgroups, 16 waves per CU.
+// The DMA places lane l of a wave at LDS offset 16*l, i.e. rows of 64 bytes without padding; bank conflicts of the
+// fragment reads are avoided by XOR-swizzling the 16-byte chunk index with (row>>2)&3 -- on the global side (a lane loads
+// logical chunk pc ^ g(row) into physical slot pc) and again when the fragments are read.
+#define SSG_LDSP(ptr_) ((__attribute__((address_space(3))) void*)(ptr_))
+
+__global__ __launch_bounds__(512, 4) void conv_dma_kernel(ConvParams p) {   // 4 waves per SIMD: at most 128 VGPRs
+  constexpr int BM = 128, BN = 256, WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
+  constexpr int STAGE_BYTES = (BM + BN) * 64;                       // 24 KB: [A: 128 rows x 64 B][W: 256 rows x 64 B]
+  __shared__ __attribute__((aligned(1024))) unsigned char st0[STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char st1[STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char st2[STAGE_BYTES];
+  const int tiles_n = p.Cout / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int tile = conv_xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+
+  // ---- DMA addressing: this wave fills A rows [16w, 16w+16) and W rows [32w, 32w+32) of every stage
+  const int drow = lane >> 2, pc = lane & 3;                        // row inside a 16-row block, physical 16-byte slot
+  const int lc4 = (pc ^ ((drow >> 2) & 3)) * 4;                     // logical chunk (in fp32-sized units) this lane fetches
+  int ab, ah, aw;
+  {
+    const int m = tm * BM + wave * 16 + drow;
+    if (m < p.M) {
+      const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;
+      ab = b; ah = oh * p.stride - p.pad; aw = ow * p.stride - p.pad;
+    } else { ab = -1; ah = 0; aw = 0; }
+  }
+  const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
+  const unsigned wo0 = (unsigned)(((tn * BN + wave * 32 + drow) * p.Kpad + lc4) * 4), wo1 = wo0 + (unsigned)(16 * p.Kpad * 4);
+  const int ntap = p.KH * p.KW;
+  // second 1x1 input of the fused downsample GEMM (k tiles >= nkA read in2 at (oh*stride2, ow*stride2)); the pixel
+  // coordinates of this lane's row are kept for it
+  const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? p.in2_bytes : 0u, 0x00020000);
+  const int nkA = p.in2 ? p.nk1 * 2 : 0x7fffffff;                    // p.nk1 counts 32-wide tiles on the dual path
+  unsigned a2base = 0x80000000u;
+  if (p.in2 && ab >= 0) {
+    const int oh_ = (ah + p.pad) / p.stride, ow_ = (aw + p.pad) / p.stride;
+    a2base = (unsigned)((((ab * p.H2 + oh_ * p.stride2) * p.W2 + ow_ * p.stride2) * p.Cin2 + lc4) * 4);
+  }
+#define SSG_DMA(KT, ST)                                                                                              \
+  {                                                                                                                  \
+    if ((KT) < nkA) {                                                                                                \
+      const int kt32 = (KT) >> 1, half_ = ((KT) & 1) * 16, chunk_ = kt32 / ntap, tap_ = kt32 - chunk_ * ntap;        \
+      const int r_ = tap_ / p.KW, s__ = tap_ - r_ * p.KW;                                                             \
+      const int ih = ah + r_, iw = aw + s__;                                                                          \
+      const bool ok = ab >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                                          \
+      const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1), bc = max(ab, 0);                      \
+      const unsigned aoff = (unsigned)((((bc * p.H + ihc) * p.W + iwc) * p.Cin + chunk_ * 32 + half_ + lc4) * 4) + (ok ? 0u : 0x80000000u); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, SSG_LDSP(ST + wave * 1024), 16, aoff, 0, 0, 0);               \
+    } else {                                                                                                          \
+      const unsigned aoff = a2base + (unsigned)(((KT) - nkA) * CBK * 4);                                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in2_rsrc, SSG_LDSP(ST + wave * 1024), 16, aoff, 0, 0, 0);              \
+    }                                                                                                                 \
+    const unsigned kb_ = (unsigned)((KT) * CBK * 4);                                                                  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048), 16, wo0 + kb_, 0, 0, 0);   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, 0); \
+  }
+
+  // ---- fragment addressing: lane (row l32 of a 32-row MFMA tile, k half h); swizzle g = (row>>2)&3 depends on l32 only
+  const int g = (l32 >> 2) & 3;
+  const int offh = ((2 * h) ^ g) * 16, offl = ((2 * h + 1) ^ g) * 16;
+  const int arow = (wm * WM + l32) * 64, brow = BM * 64 + (wn * WN + l32) * 64;
+#define SSG_MMA(ST)                                                                                                  \
+  {                                                                                                                  \
+    v8h ah_[MT], al_[MT], bh_[NT], bl_[NT];                                                                          \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                                 \
+      ah_[i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offh); al_[i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offl); } \
+    _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                                 \
+      bh_[j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offh); bl_[j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offl); } \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_[j], al_[i], acc[i][j], 0, 0, 0);                        \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_[j], ah_[i], acc[i][j], 0, 0, 0);                        \
+    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                    \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_[j], ah_[i], acc[i][j], 0, 0, 0);                        \
+  }
+
+  v16f acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  // Three stages, loads two K tiles ahead.  `__syncthreads()` would make hipcc wait for EVERY outstanding DMA (vmcnt(0)),
+  // i.e. for the tile it issued a moment ago; the explicit pair below waits only for the older tile (each tile is 3 DMA
+  // instructions per wave) and then publishes it.  The compiler's own tracking of the DMA -> LDS-array dependencies stays in
+  // force for the fragment reads (separate __shared__ arrays per stage).
+#define SSG_PUBLISH() asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory")
+  const int nk = p.Kpad / CBK;
+  SSG_DMA(0, st0)
+  { const int k1 = min(1, nk - 1); SSG_DMA(k1, st1) }
+  const int nfull = nk / 3 * 3;
+  for (int kt = 0; kt < nfull; kt += 3) {   // tile t lives in stage array t % 3; no exits inside (they doubled the accumulators)
+    SSG_PUBLISH();                        // tile kt landed in st0 for every wave; everybody is done reading st2 (tile kt-1)
+    { const int kn = min(kt + 2, nk - 1); SSG_DMA(kn, st2) }
+    __builtin_amdgcn_sched_barrier(0);    // keep the DMA issue ahead of the multiply
+    SSG_MMA(st0)
+    SSG_PUBLISH();
+    { const int kn = min(kt + 3, nk - 1); SSG_DMA(kn, st0) }
+    __builtin_amdgcn_sched_barrier(0);
+    SSG_MMA(st1)
+    SSG_PUBLISH();
+    { const int kn = min(kt + 4, nk - 1); SSG_DMA(kn, st1) }
+    __builtin_amdgcn_sched_barrier(0);
+    SSG_MMA(st2)
+  }
+  if (nk - nfull >= 1) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st0) }
+  if (nk - nfull == 2) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
+  __syncthreads();                        // drains the (clamped, redundant) tail DMAs before the stages become epilogue patches
+#undef SSG_PUBLISH
+#undef SSG_DMA
+#undef SSG_MMA
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] *= p.acc_scale;
+
+  // ---- epilogue: per (i, j) a 32-pixel x 32-channel patch through LDS (waves 0-3 in st0, 4-7 in st1), then row segments
+  constexpr int EP = 36, CPR = 8, RPI = 8, ITS = 4;
+  float* patch = reinterpret_cast<float*>(wave < 4 ? st0 : st1) + (wave & 3) * (32 * EP);
+  const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
+  const float* __restrict__ resp = p.res;
+  float* __restrict__ outp = p.out;
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    const int mbase = tm * BM + wm * WM + i * 32;
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const int col = tn * BN + wn * WN + j * 32 + chunk * 4;
+      const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
+      float4 rr[ITS];
+      if (resp) {
+#pragma unroll
+        for (int it = 0; it < ITS; it++) {
+          const int m = mbase + it * RPI + prow;
+          rr[it] = *reinterpret_cast<const float4*>(resp + (int64_t)(m < p.M ? m : 0) * p.Cout + col);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        *reinterpret_cast<float4*>(patch + l32 * EP + 8 * q + 4 * h) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+      for (int it = 0; it < ITS; it++) {
+        const int m = mbase + it * RPI + prow;
+        float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + chunk * 4);
+        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        if (resp) {
+          float4 r4 = rr[it];
+          if (p.res_split) {
+            const unsigned s0 = odd ? __float_as_uint(r4.x) : __float_as_uint(r4.z), s1 = odd ? __float_as_uint(r4.y) : __float_as_uint(r4.w);
+            const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+            r4 = odd ? split_decode4(make_uint2(g0, g1), make_uint2(__float_as_uint(r4.z), __float_as_uint(r4.w)))
+                     : split_decode4(make_uint2(__float_as_uint(r4.x), __float_as_uint(r4.y)), make_uint2(g0, g1));
+          }
+          v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+        }
+        if (p.relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+        if (p.out_split) {
+          uint2 hp, lp;
+          split_encode4(v, hp, lp);
+          const uint2 send = odd ? hp : lp;
+          const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 1, 64), (unsigned)__shfl_xor((int)send.y, 1, 64));
+          const uint4 stv = odd ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
+          if (m < p.M) *reinterpret_cast<uint4*>(outp + (int64_t)m * p.Cout + col) = stv;
+        } else if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+}
+
 // NCHW float32 images [B,3,H,W] -> NHWC4 [B,H,W,4] (4th channel 0), optional horizontal flip
 // (reid/evaluators.py:12-16 fliplr fused into the layout change).
 __global__ void nchw_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int flip) {
@@ -703,6 +888,18 @@ static bool conv_prefers_wide(const ConvParams& p, bool split) {
   return ((p.M + 127) / 128) * (p.Cout / 256) >= mintiles;
 }
 
+// the LDS-DMA kernel takes the convolution-epilogue 128x256 launches (SSG_CONV_DMA=0: register-staged kernel)
+static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
+  static int dma = -1;
+  if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }
+  if (dma && p.epi == 0) {
+    const int tiles = ((p.M + 127) / 128) * (p.Cout / 256);
+    hipLaunchKernelGGL(conv_dma_kernel, dim3(tiles), dim3(512), 0, stream, p);
+    return ssg_check_hip(hipGetLastError(), "conv_dma_kernel");
+  }
+  return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
+}
+
 static bool conv_prefers_bn64(const ConvParams& p, bool split) {
   static int maxtiles = -1;
   if (maxtiles < 0) { const char* e = getenv("SSG_SPLIT_BN64_MAXTILES"); maxtiles = e ? atoi(e) : 300; }
@@ -744,7 +941,7 @@ extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bia
   p.Kpad = cin4 ? 32 * ((KH * KW + 7) / 8) : KH * KW * Cin;
   p.nk1 = p.Kpad / 16;   // no second input: every k-tile (of either BK) reads `in`
   if (cin4) return (Cout % 128 == 0) ? launch_conv<128, 128, 64, 64, true>(p, stream, split) : launch_conv<128, 64, 64, 32, true>(p, stream, split);
-  if (conv_prefers_wide(p, split)) return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
+  if (conv_prefers_wide(p, split)) return launch_conv_wide(p, stream);
   return (Cout % 128 == 0 && !conv_prefers_bn64(p, split)) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
 }
 
@@ -775,7 +972,7 @@ extern "C" int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const vo
   p.Kpad = Cin + Cin2; p.nk1 = Cin / 32; p.variant = 0; p.rowterm = nullptr; p.epi = 0; p.tilemin = nullptr; p.tmin_ld = 0;   // dual input stays on BK=32 (nk1 counts 32-wide tiles)
   p.out_split = (flags & 2) ? 1 : 0; p.res_split = p.out_split; p.acc_scale = acc_scale;
   const bool split = (flags & 1) != 0;
-  if (conv_prefers_wide(p, split)) return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
+  if (conv_prefers_wide(p, split)) return launch_conv_wide(p, stream);
   return (Cout % 128 == 0 && !conv_prefers_bn64(p, split)) ? launch_conv<128, 128, 64, 64, false>(p, stream, split) : launch_conv<128, 64, 64, 32, false>(p, stream, split);
 }
 
