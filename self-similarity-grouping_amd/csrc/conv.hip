@@ -520,9 +520,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
 // logical chunk pc ^ g(row) into physical slot pc) and again when the fragments are read.
 #define SSG_LDSP(ptr_) ((__attribute__((address_space(3))) void*)(ptr_))
 
-__global__ __launch_bounds__(512, 4) void conv_dma_kernel(ConvParams p) {   // 4 waves per SIMD: at most 128 VGPRs
-  constexpr int BM = 128, BN = 256, WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
-  constexpr int STAGE_BYTES = (BM + BN) * 64;                       // 24 KB: [A: 128 rows x 64 B][W: 256 rows x 64 B]
+template <int BN>
+__global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
+  constexpr int BM = 128, WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
+  constexpr int WCOLS = BN / WN, NW = 2 * WCOLS;                     // 8 waves (2 x 4) for BN = 256, 4 waves (2 x 2) for BN = 128
+  constexpr int ABLK = BM / 16 / NW;                                 // 16-row A blocks per wave and stage: 1 or 2 (W: always 2)
+  constexpr int STAGE_BYTES = (BM + BN) * 64;                       // [A: 128 rows x 64 B][W: BN rows x 64 B]
   __shared__ __attribute__((aligned(1024))) unsigned char st0[STAGE_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char st1[STAGE_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char st2[STAGE_BYTES];
@@ -530,47 +533,50 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(ConvParams p) {   // 4
   const int tile = conv_xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+  const int wm = wave / WCOLS, wn = wave % WCOLS, l32 = lane & 31, h = lane >> 5;
 
-  // ---- DMA addressing: this wave fills A rows [16w, 16w+16) and W rows [32w, 32w+32) of every stage
+  // ---- DMA addressing: this wave fills A rows [16*ABLK*w, +16*ABLK) and W rows [32w, 32w+32) of every stage
   const int drow = lane >> 2, pc = lane & 3;                        // row inside a 16-row block, physical 16-byte slot
   const int lc4 = (pc ^ ((drow >> 2) & 3)) * 4;                     // logical chunk (in fp32-sized units) this lane fetches
-  int ab, ah, aw;
-  {
-    const int m = tm * BM + wave * 16 + drow;
-    if (m < p.M) {
-      const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);
-      const int oh = rem / p.OW, ow = rem - oh * p.OW;
-      ab = b; ah = oh * p.stride - p.pad; aw = ow * p.stride - p.pad;
-    } else { ab = -1; ah = 0; aw = 0; }
+  const int nkA = p.in2 ? p.nk1 * 2 : 0x7fffffff;                    // p.nk1 counts 32-wide tiles on the dual path
+  int ab0, ah0, aw0, ab1 = -1, ah1 = 0, aw1 = 0;
+  unsigned a2b0 = 0x80000000u, a2b1 = 0x80000000u;
+#define SSG_ROW(J)                                                                                                   \
+  {                                                                                                                  \
+    const int m = tm * BM + (wave * ABLK + J) * 16 + drow;                                                            \
+    if (m < p.M) {                                                                                                   \
+      const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);                                                  \
+      const int oh = rem / p.OW, ow = rem - oh * p.OW;                                                               \
+      ab##J = b; ah##J = oh * p.stride - p.pad; aw##J = ow * p.stride - p.pad;                                       \
+      if (p.in2) a2b##J = (unsigned)((((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cin2 + lc4) * 4);      \
+    } else { ab##J = -1; ah##J = 0; aw##J = 0; }                                                                     \
   }
+  SSG_ROW(0)
+  if (ABLK == 2) SSG_ROW(1)
+#undef SSG_ROW
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? p.in2_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
   const unsigned wo0 = (unsigned)(((tn * BN + wave * 32 + drow) * p.Kpad + lc4) * 4), wo1 = wo0 + (unsigned)(16 * p.Kpad * 4);
   const int ntap = p.KH * p.KW;
-  // second 1x1 input of the fused downsample GEMM (k tiles >= nkA read in2 at (oh*stride2, ow*stride2)); the pixel
-  // coordinates of this lane's row are kept for it
-  const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? p.in2_bytes : 0u, 0x00020000);
-  const int nkA = p.in2 ? p.nk1 * 2 : 0x7fffffff;                    // p.nk1 counts 32-wide tiles on the dual path
-  unsigned a2base = 0x80000000u;
-  if (p.in2 && ab >= 0) {
-    const int oh_ = (ah + p.pad) / p.stride, ow_ = (aw + p.pad) / p.stride;
-    a2base = (unsigned)((((ab * p.H2 + oh_ * p.stride2) * p.W2 + ow_ * p.stride2) * p.Cin2 + lc4) * 4);
+#define SSG_DMA_A(J, ST, KT)                                                                                         \
+  {                                                                                                                  \
+    if ((KT) < nkA) {                                                                                                \
+      const int ih = ah##J + r_, iw = aw##J + s__;                                                                    \
+      const bool ok = ab##J >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                                       \
+      const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1), bc = max(ab##J, 0);                   \
+      const unsigned aoff = (unsigned)((((bc * p.H + ihc) * p.W + iwc) * p.Cin + cch_) * 4) + (ok ? 0u : 0x80000000u); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, 0);   \
+    } else {                                                                                                          \
+      const unsigned aoff = a2b##J + (unsigned)(((KT) - nkA) * CBK * 4);                                               \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in2_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, 0);  \
+    }                                                                                                                 \
   }
 #define SSG_DMA(KT, ST)                                                                                              \
   {                                                                                                                  \
-    if ((KT) < nkA) {                                                                                                \
-      const int kt32 = (KT) >> 1, half_ = ((KT) & 1) * 16, chunk_ = kt32 / ntap, tap_ = kt32 - chunk_ * ntap;        \
-      const int r_ = tap_ / p.KW, s__ = tap_ - r_ * p.KW;                                                             \
-      const int ih = ah + r_, iw = aw + s__;                                                                          \
-      const bool ok = ab >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                                          \
-      const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1), bc = max(ab, 0);                      \
-      const unsigned aoff = (unsigned)((((bc * p.H + ihc) * p.W + iwc) * p.Cin + chunk_ * 32 + half_ + lc4) * 4) + (ok ? 0u : 0x80000000u); \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, SSG_LDSP(ST + wave * 1024), 16, aoff, 0, 0, 0);               \
-    } else {                                                                                                          \
-      const unsigned aoff = a2base + (unsigned)(((KT) - nkA) * CBK * 4);                                               \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(in2_rsrc, SSG_LDSP(ST + wave * 1024), 16, aoff, 0, 0, 0);              \
-    }                                                                                                                 \
+    const int kt32 = (KT) >> 1, half_ = ((KT) & 1) * 16, chunk_ = kt32 / ntap, tap_ = kt32 - chunk_ * ntap;          \
+    const int r_ = tap_ / p.KW, s__ = tap_ - r_ * p.KW, cch_ = chunk_ * 32 + half_ + lc4;                             \
+    SSG_DMA_A(0, ST, KT) if (ABLK == 2) SSG_DMA_A(1, ST, KT)                                                          \
     const unsigned kb_ = (unsigned)((KT) * CBK * 4);                                                                  \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048), 16, wo0 + kb_, 0, 0, 0);   \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, 0); \
@@ -604,10 +610,11 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(ConvParams p) {   // 4
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   // Three stages, loads two K tiles ahead.  `__syncthreads()` would make hipcc wait for EVERY outstanding DMA (vmcnt(0)),
-  // i.e. for the tile it issued a moment ago; the explicit pair below waits only for the older tile (each tile is 3 DMA
+  // i.e. for the tile it issued a moment ago; the explicit pair below waits only for the older tile (each tile is 3 or 4 DMA
   // instructions per wave) and then publishes it.  The compiler's own tracking of the DMA -> LDS-array dependencies stays in
   // force for the fragment reads (separate __shared__ arrays per stage).
-#define SSG_PUBLISH() asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory")
+#define SSG_PUBLISH()                                                                                              \
+  { if (ABLK == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); }
   const int nk = p.Kpad / CBK;
   SSG_DMA(0, st0)
   { const int k1 = min(1, nk - 1); SSG_DMA(k1, st1) }
@@ -631,6 +638,7 @@ __global__ __launch_bounds__(512, 4) void conv_dma_kernel(ConvParams p) {   // 4
   __syncthreads();                        // drains the (clamped, redundant) tail DMAs before the stages become epilogue patches
 #undef SSG_PUBLISH
 #undef SSG_DMA
+#undef SSG_DMA_A
 #undef SSG_MMA
 #pragma unroll
   for (int i = 0; i < MT; i++)
@@ -869,6 +877,15 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
       static int sbk16 = -1;   // SSG_SPLIT_BK16=<K>: reductions of at most K use BK=16 stages
       if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 256; }
       if (!p.in2 && p.Kpad <= sbk16) return launch_conv_bk<BM, BN, WM, WN, false, 16, true>(p, stream);
+      if constexpr (BM == 128 && BN == 128) {   // long reductions on 128x128 tiles: LDS-DMA kernel (SSG_CONV_DMA bit 1)
+        static int dma = -1;
+        if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }   // bit 1 measured neutral (21.42 vs 21.46 k img/s): off by default
+        if ((dma & 2) && p.epi == 0) {
+          const int tiles = ((p.M + 127) / 128) * (p.Cout / 128);
+          hipLaunchKernelGGL(conv_dma_kernel<128>, dim3(tiles), dim3(256), 0, stream, p);
+          return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<128>");
+        }
+      }
       return launch_conv_bk<BM, BN, WM, WN, false, 32, true>(p, stream);
     }
   }
@@ -888,13 +905,14 @@ static bool conv_prefers_wide(const ConvParams& p, bool split) {
   return ((p.M + 127) / 128) * (p.Cout / 256) >= mintiles;
 }
 
-// the LDS-DMA kernel takes the convolution-epilogue 128x256 launches (SSG_CONV_DMA=0: register-staged kernel)
+// the LDS-DMA kernel takes the convolution-epilogue 128x256 launches (SSG_CONV_DMA: bit 0 = 128x256, bit 1 = 128x128
+// launches; 0 = register-staged kernels everywhere)
 static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }
-  if (dma && p.epi == 0) {
+  if ((dma & 1) && p.epi == 0) {
     const int tiles = ((p.M + 127) / 128) * (p.Cout / 256);
-    hipLaunchKernelGGL(conv_dma_kernel, dim3(tiles), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL(conv_dma_kernel<256>, dim3(tiles), dim3(512), 0, stream, p);
     return ssg_check_hip(hipGetLastError(), "conv_dma_kernel");
   }
   return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
