@@ -647,6 +647,29 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] *= p.acc_scale;
 
+  if (p.epi == 3) {
+    // distance filter epilogue (source-term bound pass): per output row the minimum over every 8-column granule, as in
+    // conv_igemm_kernel (same accumulator layout)
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+      const int m = tm * BM + wm * WM + i * 32 + l32;
+      const float rt = p.rowterm[m < p.M ? m : 0];
+#pragma unroll
+      for (int j = 0; j < NT; j++) {
+        float gq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float4 bias = *reinterpret_cast<const float4*>(p.bias + tn * BN + wn * WN + j * 32 + 8 * q + 4 * h);
+          float mn = fminf(fminf((rt + bias.x) - 2.f * acc[i][j][4 * q], (rt + bias.y) - 2.f * acc[i][j][4 * q + 1]),
+                           fminf((rt + bias.z) - 2.f * acc[i][j][4 * q + 2], (rt + bias.w) - 2.f * acc[i][j][4 * q + 3]));
+          gq[q] = fminf(mn, __shfl_xor(mn, 32, 64));
+        }
+        if (h == 0 && m < p.M)
+          *reinterpret_cast<float4*>(p.tilemin + (int64_t)m * p.tmin_ld + (tn * BN + wn * WN + j * 32) / 8) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+      }
+    }
+    return;
+  }
   // ---- epilogue: per (i, j) a 32-pixel x 32-channel patch through LDS (waves 0-3 in st0, 4-7 in st1), then row segments
   constexpr int EP = 36, CPR = 8, RPI = 8, ITS = 4;
   float* patch = reinterpret_cast<float*>(wave < 4 ? st0 : st1) + (wave & 3) * (32 * EP);
@@ -910,7 +933,7 @@ static bool conv_prefers_wide(const ConvParams& p, bool split) {
 static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }
-  if ((dma & 1) && p.epi == 0) {
+  if ((dma & 1) && (p.epi == 0 || p.epi == 3) && (int64_t)p.Cout * p.Kpad * 4 < 0x7fffffffLL) {   // (weights go through a 2 GiB buffer resource)
     const int tiles = ((p.M + 127) / 128) * (p.Cout / 256);
     hipLaunchKernelGGL(conv_dma_kernel<256>, dim3(tiles), dim3(512), 0, stream, p);
     return ssg_check_hip(hipGetLastError(), "conv_dma_kernel");
@@ -1126,7 +1149,7 @@ extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, in
   p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles; p.out_split = p.res_split = 0;
   p.acc_scale = split ? 1.f / (scale_t * scale_s) : 1.f;
   // 128x256 tiles when the padded source count allows: 3/4 of the global->LDS bytes of the 128x128 tile
-  int rc = split ? ((Ns_pad % 256) == 0 ? launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream) : launch_conv_bk<128, 128, 64, 64, false, 32, true>(p, stream))
+  int rc = split ? ((Ns_pad % 256) == 0 ? launch_conv_wide(p, stream) : launch_conv_bk<128, 128, 64, 64, false, 32, true>(p, stream))
                  : launch_conv<128, 128, 64, 64, false>(p, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
