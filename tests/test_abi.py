@@ -1,6 +1,7 @@
 """CPU suite: the C-ABI library loads, exports every symbol include/ssg_hip.h declares, and
 its argument validation / host-only helpers work without a GPU (no compute is launched)."""
 import ctypes
+import math
 import os
 
 import numpy as np
@@ -80,3 +81,33 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "ssg_oracle" not in txt.replace("oracle/ssg_oracle.c", ""), f
+
+
+def test_split_half_host_formats():
+    """Host-side encoders of the split-half embedding path (ssg_amd/resnet.py): layout and value properties that the HIP
+    kernels rely on (include/ssg_hip.h: h8l8 / h4l4, reduction order of the packed weights)."""
+    import torch
+    from ssg_amd.resnet import _h4l4, _h8l8, _weight_scale, pack_weight_khwc
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(3, 32, generator=g) * torch.tensor([1e-3, 1.0, 300.0]).view(3, 1)
+    enc = _h8l8(v)
+    assert enc.dtype == torch.float32 and enc.shape == v.shape                       # same 4 bytes per value, same addressing
+    halves = enc.view(torch.float16).view(3, 4, 2, 8)                                # [row][group of 8][hi | lo][8]
+    hi, lo = halves[:, :, 0, :].reshape(3, 32), halves[:, :, 1, :].reshape(3, 32)
+    assert torch.equal(hi, v.half())                                                 # hi = half(v)
+    assert torch.equal(lo, (v - hi.float()).half())                                  # lo = half(v - hi)
+    rec = hi.float() + lo.float()
+    assert ((rec - v).abs() <= 2.0 ** -21 * v.abs() + 2.0 ** -24).all()              # 22 significand bits, absolute floor 2^-24
+    t4 = _h4l4(v[:, :8]).view(torch.float16).view(3, 2, 2, 4)                        # stem: per tap [hi4 | lo4]
+    assert torch.equal(t4[:, :, 0, :].reshape(3, 8), v[:, :8].half())
+    # weight scale: a power of two that keeps every scaled weight inside the half range
+    for mx in (1e-4, 0.03, 1.0, 90.0, 3000.0):
+        sc = _weight_scale(torch.tensor([mx, -mx / 3]))
+        assert sc <= 256.0 and mx * sc <= 16384.0 and math.log2(sc) == int(math.log2(sc))
+    # reduction order k = ((c // 32) * KH*KW + r*KW + s) * 32 + c % 32
+    cout, kh, kw, cin = 2, 3, 3, 64
+    w = torch.arange(cout * kh * kw * cin, dtype=torch.float32).view(cout, kh, kw, cin)
+    pk = pack_weight_khwc(w)
+    for (o, r, s, c) in ((0, 0, 0, 0), (1, 2, 1, 37), (0, 1, 2, 63), (1, 0, 0, 32)):
+        k = ((c // 32) * kh * kw + r * kw + s) * 32 + c % 32
+        assert pk[o, k] == w[o, r, s, c]
