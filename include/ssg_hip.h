@@ -80,8 +80,19 @@ int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, in
 int ssg_source_vec_finish(const uint32_t* rowmin, int N, uint16_t* v, uint32_t* max_bits, ssg_stream_t stream);
 
 /* ---- K5 ranking (replaces np.argsort in reid/rerank.py:68-70) --------------------------- */
-/* rank[il, 0:K] = the K smallest of half(D[il,:]/rowmax[il]) in (value, column) order. K <= 64 */
+/* rank[il, 0:K] = the K smallest of half(D[il,:]/rowmax[il]) in (value, column) order
+ * (== np.argsort(kind='stable'); opt-in rank_mode='stable'). K <= 64 */
 int ssg_topk_rank(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, ssg_stream_t stream);
+/* The same K columns in the order of the UNMODIFIED reference: np.argsort's default kind (rerank.py:70) is numpy's unstable
+ * introsort on an index array (npysort aquicksort_<half>: median-of-3 Hoare partition, insertion sort below 17 entries,
+ * heapsort past the depth budget), so the column of equal keys depends on the whole partition sequence.  One workgroup per
+ * row replays exactly the partitions that reach columns [0,K) (csrc/topk_intro.hip).  2 <= N <= 262144, K <= 64.
+ * ws: ssg_topk_rank_introsort_ws_bytes(N, nrows) bytes (0 while a row fits in LDS, N <= ~36 k).  A caller that passes
+ * ssg_topk_rank_introsort_arena_bytes(N, nrows) bytes anyway selects the global-arena variant for any N (parity tests). */
+size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows);
+size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows);
+int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws, size_t ws_bytes,
+                            ssg_stream_t stream);
 
 /* ---- K6 k-reciprocal encoding (reid/rerank.py:74-92) ------------------------------------ */
 int ssg_krecip_row_capacity(int k1); /* entries per sparse V row: (k1+1)*(round(k1/2)+2) */

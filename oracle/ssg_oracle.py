@@ -109,11 +109,11 @@ def euclid(tgt):
 
 
 def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.2, MemorySave=False,
-               Minibatch=2000, no_rerank=False, rank_mode="stable", stages=False):
+               Minibatch=2000, no_rerank=False, rank_mode="introsort", stages=False):
     """Restatement of reid/rerank.py:27-127 re_ranking.
 
-    rank_mode: 'stable' = canonical (value, index) order (numpy kind='stable');
-               'introsort' = numpy's default unstable argsort (untouched reference).
+    rank_mode: 'introsort' (default) = numpy's default unstable argsort, i.e. the untouched reference;
+               'stable' = canonical (value, index) order (numpy kind='stable').
     Returns (euclidean_dist half[N,N], final_dist f64[N,N] | None); with stages=True a
     dict of every stage boundary is returned as third element.
     """
@@ -164,7 +164,7 @@ def dbscan(dist, eps, min_samples=4):
     return labels
 
 
-def compute_dist(source_features, target_features, lambda_value, no_rerank, num_split=2, rank_mode="stable"):
+def compute_dist(source_features, target_features, lambda_value, no_rerank, num_split=2, rank_mode="introsort"):
     """selftraining.py:255-277 (numpy in).  Unlike the reference, the euclidean matrices
     are kept when no_rerank=True so that the no-rerank path is runnable."""
     e_list, r_list = [], []

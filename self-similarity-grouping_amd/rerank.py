@@ -166,8 +166,37 @@ def _original_distance(L, tgt, row0, nrows, max_abs, st):
 from .dist import gather_rows as _gather_rows  # noqa: E402
 
 
+RANK_MODES = ("introsort", "stable")
+
+
+def default_rank_mode():
+    """'introsort' = the unmodified reference's np.argsort tie order (reid/rerank.py:70, numpy's unstable introsort replayed on
+    the device); 'stable' = canonical (value, column) order (np.argsort(kind='stable')), cheaper, opt-in (SSG_RANK_MODE=stable)."""
+    mode = os.environ.get("SSG_RANK_MODE", "introsort")
+    if mode not in RANK_MODES:
+        raise ValueError("SSG_RANK_MODE must be one of %r" % (RANK_MODES,))
+    return mode
+
+
+def initial_rank(D, rowmax, N, nrows, K, rank_mode=None, force_arena=False):
+    """rerank.py:68-70 for a row block: int32 [nrows, K] = argsort(half(D / rowmax))[:, :K] in the requested tie order.
+    force_arena (tests): run the introsort kernel from its global-memory arena even when a row fits in LDS."""
+    L = _lib.lib()
+    rank_mode = default_rank_mode() if rank_mode is None else rank_mode
+    rank_blk = torch.empty((nrows, K), dtype=torch.int32, device=D.device)
+    if rank_mode == "stable":
+        check(L.ssg_topk_rank(ptr(D), ptr(rowmax), N, nrows, K, ptr(rank_blk), stream()), "ssg_topk_rank")
+    elif rank_mode == "introsort":
+        nws = int(L.ssg_topk_rank_introsort_arena_bytes(N, nrows) if force_arena else L.ssg_topk_rank_introsort_ws_bytes(N, nrows))
+        ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=D.device)
+        check(L.ssg_topk_rank_introsort(ptr(D), ptr(rowmax), N, nrows, K, ptr(rank_blk), ptr(ws), nws, stream()), "ssg_topk_rank_introsort")
+    else:
+        raise ValueError("rank_mode must be one of %r" % (RANK_MODES,))
+    return rank_blk
+
+
 def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, keep_euclid=True, row0=0, nrows=None,
-                      group=None, stages=None):
+                      group=None, stages=None, rank_mode=None):
     """Fused device pipeline K3..K9 for one feature split.
 
     src [Ns,d], tgt [N,d]: float32 CUDA tensors (replicated on every rank of `group`).
@@ -205,9 +234,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
 
     # ---- initial ranking (rerank.py:68-70)
     K = min(k1 + 1, N)
-    rank_blk = torch.empty((nrows, K), dtype=torch.int32, device=dev)
-    check(L.ssg_topk_rank(ptr(D), ptr(rowmax), N, nrows, K, ptr(rank_blk), st), "ssg_topk_rank")
-    rank = _gather_rows(rank_blk, group)
+    rank = _gather_rows(initial_rank(D, rowmax, N, nrows, K, rank_mode), group)
 
     # ---- k-reciprocal encoding (rerank.py:74-92)
     capV = int(L.ssg_krecip_row_capacity(k1))
@@ -264,12 +291,13 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
 
 
 def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.2, MemorySave=False, Minibatch=2000, no_rerank=False,
-               device=None):
+               device=None, rank_mode=None):
     """Drop-in for reid/rerank.py:27 re_ranking (numpy in, numpy out).
 
     MemorySave / Minibatch are accepted for signature compatibility; row chunking is not
-    needed on a 288 GB device.  Tie order of the initial ranking is the canonical
-    (value, index) order (numpy argsort kind='stable'), see DESIGN.md "ties".
+    needed on a 288 GB device.  Tie order of the initial ranking is the reference's own
+    (np.argsort default = numpy's unstable introsort, replayed on the device); rank_mode='stable'
+    selects the canonical (value, index) order instead, see DESIGN.md "ties".
     """
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     print('computing source distance...')
@@ -278,7 +306,7 @@ def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.
     tgt = _as_dev_f32(np.asarray(input_feature), device)
     if not no_rerank:
         print('starting re_ranking...')
-    h = re_ranking_device(src, tgt, k1=k1, k2=k2, lambda_value=lambda_value, no_rerank=no_rerank)
+    h = re_ranking_device(src, tgt, k1=k1, k2=k2, lambda_value=lambda_value, no_rerank=no_rerank, rank_mode=rank_mode)
     euclid = h.euclid.cpu().numpy()
     if no_rerank:
         return euclid, None

@@ -117,21 +117,18 @@ def test_pairwise_vs_oracle(N, Ns, d, dev, ora):
 
 
 # ------------------------------------------------------------------ full re-rank, stage by stage
-RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_*_stable.npz")))
+RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_n*.npz")) + glob.glob(os.path.join(GOLDEN, "rerank_tiefree_*.npz")))
 
 
-@pytest.mark.parametrize("name", RERANK)
-def test_rerank_stages_vs_reference_golden(name, golden, dev, ora):
-    """HIP path vs the reference's own outputs (golden, argsort pinned to stable) and vs the
-    oracle at every stage boundary.  Bit-exact."""
+def _check_rerank_golden(g, mode, dev, ora):
     from ssg_amd import rerank, cluster
-    g = golden(name)
     src, tgt = g["src"], g["tgt"]
     k1, k2, lam = int(g["k1"]), int(g["k2"]), float(g["lambda_value"])
     N = tgt.shape[0]
     st = {}
-    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k1=k1, k2=k2, lambda_value=lam, stages=st)
-    oe, of, ost = ora.re_ranking(src, tgt, k1=k1, k2=k2, lambda_value=lam, rank_mode="stable", stages=True)
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k1=k1, k2=k2, lambda_value=lam, stages=st,
+                                 rank_mode=mode)
+    oe, of, ost = ora.re_ranking(src, tgt, k1=k1, k2=k2, lambda_value=lam, rank_mode=mode or rerank.default_rank_mode(), stages=True)
     assert np.array_equal(bits(st["D"].cpu().numpy()), bits(oe)), "original distance"
     assert np.array_equal(bits(st["v"].cpu().numpy()), bits(ost["v"])), "source vector"
     assert np.array_equal(st["rank"].cpu().numpy(), g["rank"]), "initial rank (golden)"
@@ -143,6 +140,8 @@ def test_rerank_stages_vs_reference_golden(name, golden, dev, ora):
     if "final" in g.files:
         assert np.array_equal(final, g["final"]), "final_dist vs reference golden"
         assert np.array_equal(bits(st["D"].cpu().numpy()), bits(g["euclid"]))
+        assert np.array_equal(_sparse_to_dense(st["v_idx"], st["v_val"], st["v_nnz"], N), bits(g["V"])), "V vs reference golden"
+        assert np.array_equal(_sparse_to_dense(st["q_idx"], st["q_val"], st["q_nnz"], N), bits(g["V_qe"])), "V_qe vs reference golden"
     eps, cnt, top = cluster.eps_rule(h, float(g["rho"]))
     assert (eps, cnt, top) == (float(g["eps"]), int(g["count"]), int(g["top_num"])), "eps rule"
     labels = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h)
@@ -153,15 +152,95 @@ def test_rerank_stages_vs_reference_golden(name, golden, dev, ora):
     assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(final), g["labels"])
 
 
+@pytest.mark.parametrize("name", RERANK)
+def test_rerank_stages_vs_reference_golden(name, golden, dev, ora):
+    """HIP path vs the reference's own outputs and vs the oracle at every stage boundary, bit-exact.
+    '*_ref' fixtures come from the UNTOUCHED reference (np.argsort's unstable introsort tie order,
+    reid/rerank.py:70): the default rank_mode must reproduce them.  '*_stable' fixtures come from the
+    reference with argsort pinned to kind='stable' (opt-in rank_mode='stable').  Tie-free fixtures
+    (untouched reference) must come out of both modes."""
+    g = golden(name)
+    if bool(g["stable"]):
+        _check_rerank_golden(g, "stable", dev, ora)
+    else:
+        from ssg_amd import rerank
+        assert rerank.default_rank_mode() == "introsort"
+        _check_rerank_golden(g, None, dev, ora)          # default mode
+        if bool(g["tie_free"]):
+            _check_rerank_golden(g, "stable", dev, ora)
+
+
+def _rank_rows(keys, K, dev, mode="introsort", force_arena=False):
+    """rows of order keys (uint16, < 0x3c00) -> device ranking of half(D / 1.0) with D = the keys as half bit patterns"""
+    from ssg_amd import rerank
+    D = torch.from_numpy(np.ascontiguousarray(keys).view(np.int16)).to(dev).view(torch.float16)
+    rowmax = torch.full((keys.shape[0],), 0x3C00, dtype=torch.int32, device=dev)
+    return rerank.initial_rank(D, rowmax, keys.shape[1], keys.shape[0], K, mode, force_arena=force_arena).cpu().numpy()
+
+
+@pytest.mark.parametrize("N", [2, 16, 17, 18, 63, 64, 65, 100, 1000, 1024, 1025, 1027, 1028, 1091, 2500, 5000, 16000, 16522, 30011, 36000, 40000, 70001])
+def test_introsort_rank_vs_numpy_argsort(N, dev, ora):
+    """csrc/topk_intro.hip against np.argsort's default kind on the same half rows (the oracle's sequential restatement of
+    numpy's aquicksort is checked against np.argsort right here as well): tie-heavy, constant, sorted, reversed and
+    tie-free rows; row blocks that start at unaligned addresses; N > 36 k runs from the global arena."""
+    rng = np.random.default_rng(N)
+    rows = []
+    for nv in (1, 2, 3, 7, 40, 300, 5000):
+        rows.append(rng.integers(0, nv, N))
+    rows.append(np.sort(rng.integers(0, 50, N)))
+    rows.append(np.sort(rng.integers(0, 50, N))[::-1])
+    rows.append(rng.permutation(N) % 15000)
+    rows.append(np.arange(N) % 15000)
+    rows.append((N - 1 - np.arange(N)) % 15000)
+    keys = np.stack(rows).astype(np.uint16)
+    if N > 20000:
+        keys = keys[[1, 4, 6, 8, 9]]
+    for K in sorted({1, min(21, N), min(64, N)}):
+        got = _rank_rows(keys, K, dev)
+        for r in range(keys.shape[0]):
+            ref = np.argsort(keys[r].view(np.float16))[:K]
+            if N <= 5000:
+                assert np.array_equal(ora.argsort_half(keys[r].view(np.float16))[:K], ref)
+            assert np.array_equal(got[r], ref), (N, K, r)
+    if N <= 5000:      # the global-arena variant of the kernel on rows that would fit in LDS
+        got = _rank_rows(keys, min(21, N), dev, force_arena=True)
+        for r in range(keys.shape[0]):
+            assert np.array_equal(got[r], np.argsort(keys[r].view(np.float16))[:min(21, N)]), (N, r, "arena")
+    # stable mode on the same rows == np.argsort(kind='stable')
+    K = min(21, N)
+    got = _rank_rows(keys, K, dev, "stable")
+    for r in range(keys.shape[0]):
+        assert np.array_equal(got[r], np.argsort(keys[r].view(np.float16), kind="stable")[:K]), (N, r)
+
+
+@pytest.mark.parametrize("n", [100, 300, 1000, 3000])
+def test_introsort_rank_heapsort_fallback(n, dev):
+    """keys built by an adversary against median-of-3 quicksort (tools/antiqsort.py): numpy's argsort runs out of its
+    depth budget and heapsorts a range that reaches into the first 64 columns -- so must the device kernel."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from antiqsort import killer_keys
+    key = killer_keys(n)
+    keys = np.stack([key, key[::-1].copy()])
+    for K in (21, 64):
+        for arena in (False, True):     # rows in LDS / rows in the global arena (what N > 36 k uses)
+            got = _rank_rows(keys, K, dev, force_arena=arena)
+            for r in range(2):
+                assert np.array_equal(got[r], np.argsort(keys[r].view(np.float16))[:K]), (n, K, r, arena)
+
+
 def test_reranking_dropin_signature(golden, dev):
     """reid/rerank.py:27 call surface: numpy in, (float16 [N,N], float64 [N,N]) out."""
     from ssg_amd import re_ranking, DBSCAN
-    g = golden("rerank_n256_l03_stable.npz")
+    g = golden("rerank_n256_l03_ref.npz")          # the untouched reference's output (default tie order)
     e, f = re_ranking(g["src"], g["tgt"], k1=20, k2=6, lambda_value=0.3)
     assert e.dtype == np.float16 and f.dtype == np.float64 and f.shape == (256, 256)
     assert np.array_equal(np.asarray(f), g["final"]) and np.array_equal(bits(e), bits(g["euclid"]))
     lab = DBSCAN(eps=float(g["eps"]), min_samples=4, metric="precomputed", n_jobs=8).fit_predict(f)
     assert np.array_equal(lab, g["labels"])
+    gs = golden("rerank_n256_l03_stable.npz")      # opt-in canonical (value, index) order
+    _, fs = re_ranking(gs["src"], gs["tgt"], k1=20, k2=6, lambda_value=0.3, rank_mode="stable")
+    assert np.array_equal(np.asarray(fs), gs["final"])
     e2, none = re_ranking(g["src"], g["tgt"], no_rerank=True)
     assert none is None and np.array_equal(bits(e2), bits(e))
 

@@ -279,6 +279,47 @@ def init_fixture(mod):
     return ok
 
 
+def tiefree_fixture(mod):
+    """A fixture from the UNTOUCHED reference on an input whose normalised half distances are distinct inside the
+    first k1+2 columns of every row (SURVEY.md 7 hard part 1a): np.argsort's tie behaviour cannot matter, so every
+    rank mode of the build must reproduce it.  Seeds are searched until the input is tie free."""
+    lam, rho = 0.3, 2e-2
+    for N, Ns, d, k1, k2 in ((40, 32, 48, 6, 3), (48, 40, 64, 4, 2)):
+        for seed in range(1000, 6000):
+            rng = np.random.default_rng(seed)
+            tgt = rng.standard_normal((N, d)); tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+            src = rng.standard_normal((Ns, d)); src /= np.linalg.norm(src, axis=1, keepdims=True)
+            tgt = tgt.astype(np.float32); src = (0.5 * src + 0.5 * tgt[:Ns]).astype(np.float32)
+            f16 = tgt.astype(np.float16).astype(np.float64)
+            from scipy.spatial.distance import cdist
+            D = np.power(cdist(f16, f16).astype(np.float16), 2).astype(np.float16)
+            Dn = np.transpose(D / np.max(D, axis=0))
+            if np.all(np.diff(np.sort(Dn.astype(np.float32), axis=1)[:, : k1 + 2], axis=1) != 0):
+                break
+        else:
+            raise SystemExit("no tie-free seed found")
+        e, f, cap = run_ref(mod, src, tgt, False, k1=k1, k2=k2, lambda_value=lam)
+        e2, f2, cap2 = run_ref(mod, src, tgt, True, k1=k1, k2=k2, lambda_value=lam)
+        assert beq(f, f2) and beq(cap["rank"], cap2["rank"]), "tie-free input must not depend on the argsort kind"
+        ok = True
+        for mode in ("introsort", "stable"):
+            oe, of, st = ora.re_ranking(src, tgt, k1=k1, k2=k2, lambda_value=lam, rank_mode=mode, stages=True)
+            chk = dict(euclid=beq(e, oe), rank=beq(cap["rank"], st["rank"]), V=beq(cap["V"], st["V"]), V_qe=beq(cap["V_qe"], st["V_qe"]),
+                       jaccard=beq(cap["jaccard"], st["jaccard"]), final=beq(f, of))
+            ok = ok and all(chk.values())
+            print("tiefree N=%d seed=%d oracle(%s)==reference: %s" % (N, seed, mode, chk))
+        eps, cnt, top = eps_rule_ref(f, rho)
+        labels = DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(f)
+        ok = ok and beq(labels, ora.dbscan(f, eps, 4)) and (float(eps), cnt, top) == ora.eps_rule(f, rho)
+        np.savez_compressed(os.path.join(OUT, "rerank_tiefree_n%d_ref.npz" % N), src=src, tgt=tgt, k1=k1, k2=k2, lambda_value=lam, rho=rho,
+                            stable=False, rank=cap["rank"].astype(np.int32), eps=np.float64(eps), count=cnt, top_num=top,
+                            labels=labels.astype(np.int64), tie_free=True, exp_quirk=False, v=cap["source_dist_row0"].astype(np.float64),
+                            euclid=e, final=f, V=cap["V"], V_qe=cap["V_qe"], jaccard=cap["jaccard"], seed=seed)
+        if not ok:
+            return False
+    return True
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-plain" in sys.argv:        # regenerate just tests/golden/rerank_plain.npz
@@ -291,7 +332,11 @@ def main():
         sys.exit(0 if ok else 1)
     ora.build(force=True)
     mod = load_ref_rerank()
-    ok = True
+    if "--only-tiefree" in sys.argv:      # regenerate just tests/golden/rerank_tiefree_*.npz
+        ok = tiefree_fixture(mod)
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
+    ok = tiefree_fixture(mod)
 
     # ---- half exp table of this host's numpy + the exceptions vs correct rounding
     allh, npx, cr, bad = exp_quirk_inputs()
