@@ -143,8 +143,6 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if args.N % world:
-        raise SystemExit("N must be divisible by the number of GPUs")
     timer = KernelTimer(_lib.lib())
     _lib._lib = timer
 
@@ -158,8 +156,8 @@ def main():
     src_imgs = torch.randn(s_hi - s_lo, 3, 256, 128, generator=g, device=dev)
     tgt_emb = clustered(args.N, 2048, 1, device=dev)
     src_emb = clustered(args.Ns, 2048, 2, intra=0.7, device=dev)
-    nrows = args.N // world
-    row0 = rank * nrows
+    row0, row1 = sdist.shard_bounds(args.N, rank, world)      # ragged row blocks (N need not divide by the number of GPUs)
+    nrows = row1 - row0
 
     def embed(imgs):
         out = []

@@ -49,8 +49,10 @@ uint16_t ssg_double_to_half_bits(double d);
 int ssg_row_norms_f64(const float* x, int n, int d, int round_to_half, double* norms, ssg_stream_t stream);
 /* D[il, j] = half(half(sqrt(|f16(x_i) - f16(x_j)|^2))^2) for rows i = row0+il (rerank.py:33,61-62)
  * rowmax[il] = max_j D[il, j] as half bits in a uint32 (rerank.py:68 max(original_dist, axis=0)).
- * x [N,d] f32 row-major, d % 4 == 0; norms from ssg_row_norms_f64(x, N, d, 1). */
-int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
+ * x [N,d] f32 row-major, d % 4 == 0; norms from ssg_row_norms_f64(x, N, d, 1).
+ * memory_save != 0: the reference's MemorySave=True branch (rerank.py:49-59) D = half(sqrt(.)^2), squared in float64 and rounded
+ * once (Minibatch only chunks the rows there and does not change a value). */
+int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int row0, int nrows, int memory_save, uint16_t* D, uint32_t* rowmax,
                         ssg_stream_t stream);
 /* The same matrix as an EXACT integer Gram on the int8 matrix cores (csrc/gram_i8.hip): for half-rounded features in
  * [-1, 1] (L2-normalised embeddings) feat*2^24 is an integer and scipy's float64 squared distance is exact, so
@@ -61,7 +63,8 @@ int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int r
  * ssg_sqdist_self_i8 itself does nothing in that case).  d <= 16384. */
 size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits);
 int ssg_gram_i8_encode(const float* x, int n, int d, int ndigits, void* E, int64_t* norms, int32_t* flag, ssg_stream_t stream);
-int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int ndigits, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
+int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int ndigits, int row0, int nrows, int memory_save, uint16_t* D,
+                       uint32_t* rowmax,
                        const int32_t* flag, ssg_stream_t stream);
 /* rowmin[i] = min_s half(cdist(tgt_i, src_s)^2) as half bits in uint32 (rerank.py:36-37,39) */
 int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const float* src, const double* nsrc, int nrows, int Ns, int d,

@@ -171,18 +171,22 @@ uint16_t ora_source_vec(const float* tgt, const float* src, int N, int Ns, int d
 }
 
 /* ------------------------------------------------------------------ rerank.py:33,61-62
- * feat = f16(x); D = f16( f16(cdist_f64(feat,feat))^2 )  -> D [N,N] half */
-void ora_euclid(const float* tgt, int N, int d, uint16_t* D) {
+ * feat = f16(x); D = f16( f16(cdist_f64(feat,feat))^2 )  -> D [N,N] half
+ * memory_save (rerank.py:49-59, MemorySave=True): D = f16( cdist_f64(feat,feat)^2 ), squared in float64, one rounding
+ * (the Minibatch row chunks of that branch do not change any value). */
+void ora_euclid2(const float* tgt, int N, int d, int memory_save, uint16_t* D) {
   double* F = (double*)malloc((size_t)N * d * sizeof(double));
   for (int64_t i = 0; i < (int64_t)N * d; i++) F[i] = (double)h2f(f2h(tgt[i]));
 #pragma omp parallel for schedule(dynamic, 8)
   for (int i = 0; i < N; i++)
     for (int j = 0; j < N; j++) {
-      uint16_t h = d2h(sqrt(sqeuclid_seq(F + (int64_t)i * d, F + (int64_t)j * d, d)));
-      D[(int64_t)i * N + j] = h_mul(h, h);  /* np.power(half,2) = half(float(h)*float(h)) */
+      double sq = sqrt(sqeuclid_seq(F + (int64_t)i * d, F + (int64_t)j * d, d));
+      uint16_t h = d2h(sq);
+      D[(int64_t)i * N + j] = memory_save ? d2h(sq * sq) : h_mul(h, h);  /* np.power(half,2) = half(float(h)*float(h)) */
     }
   free(F);
 }
+void ora_euclid(const float* tgt, int N, int d, uint16_t* D) { ora_euclid2(tgt, N, d, 0, D); }
 
 /* numpy npysort/quicksort.cpp aquicksort_<half> + heapsort.cpp aheapsort_ (published
  * algorithm, restated): introsort on an index array, unstable. */
@@ -470,15 +474,16 @@ void ora_dbscan(const double* M, int N, double eps, int min_samples, int64_t* la
  * used as bench.py's cpu_baseline ("port") and by tests that want every stage boundary.
  * Any output pointer may be NULL.  Returns 0, or 1 if max(source_dist_vec)==0 (NaN path). */
 int ora_re_ranking(const float* src, const float* tgt, int Ns, int N, int d, int k1, int k2, double lambda_value,
-                   int rank_mode, uint16_t* euclid /*[N,N]*/, uint16_t* v_out /*[N]*/, int32_t* rank_out /*[N,k1+1]*/,
+                   int rank_mode, int memory_save, uint16_t* euclid /*[N,N]*/, uint16_t* v_out /*[N]*/,
+                   int32_t* rank_out /*[N,min(N,max(k1+1,k2))]*/,
                    uint16_t* V_out, uint16_t* Vqe_out, uint16_t* J_out, uint16_t* Jp_out, double* final_out) {
-  int K = k1 + 1; if (K > N) K = N;
+  int K = k1 + 1; if (k2 > K) K = k2; if (K > N) K = N;   /* columns of initial_rank that are ever read (:76,:83,:97) */
   size_t nn = (size_t)N * N;
   uint16_t* v_raw = (uint16_t*)malloc((size_t)N * 2); uint16_t* v = (uint16_t*)malloc((size_t)N * 2);
   uint16_t mx = ora_source_vec(tgt, src, N, Ns, d, v_raw, v);
   if (v_out) memcpy(v_out, v, (size_t)N * 2);
   uint16_t* D = euclid ? euclid : (uint16_t*)malloc(nn * 2);
-  ora_euclid(tgt, N, d, D);
+  ora_euclid2(tgt, N, d, memory_save, D);
   uint16_t* Dn = (uint16_t*)malloc(nn * 2); uint16_t* colmax = (uint16_t*)malloc((size_t)N * 2);
   int32_t* rank = rank_out ? rank_out : (int32_t*)malloc((size_t)N * K * 4);
   ora_normalize_rank(D, N, K, rank_mode, Dn, rank, colmax);

@@ -99,12 +99,12 @@ def source_vec(tgt, src):
     return v_raw.view(np.float16), v.view(np.float16), np.uint16(mx).view(np.float16)
 
 
-def euclid(tgt):
-    """rerank.py:33,61-62 -> D half [N,N]."""
+def euclid(tgt, memory_save=False):
+    """rerank.py:33,61-62 (memory_save: the MemorySave=True branch :49-59) -> D half [N,N]."""
     tgt = _c(tgt, np.float32)
     N, d = tgt.shape
     D = np.empty((N, N), np.uint16)
-    lib().ora_euclid(_p(tgt, _f32p), N, d, _p(D, _u16p))
+    lib().ora_euclid2(_p(tgt, _f32p), N, d, 1 if memory_save else 0, _p(D, _u16p))
     return D.view(np.float16)
 
 
@@ -120,8 +120,8 @@ def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.
     src = _c(input_feature_source, np.float32); tgt = _c(input_feature, np.float32)
     N, d = tgt.shape
     if no_rerank:
-        return euclid(tgt), None
-    K = min(k1 + 1, N)
+        return euclid(tgt, MemorySave), None
+    K = min(max(k1 + 1, k2), N)
     E = np.empty((N, N), np.uint16)
     v = np.empty(N, np.uint16)
     rank = np.empty((N, K), np.int32)
@@ -132,7 +132,7 @@ def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.
         J = np.empty((N, N), np.uint16); Jp = np.empty((N, N), np.uint16)
     nan_path = lib().ora_re_ranking(
         _p(src, _f32p), _p(tgt, _f32p), src.shape[0], N, d, int(k1), int(k2), ctypes.c_double(lambda_value),
-        1 if rank_mode == "introsort" else 0, _p(E, _u16p), _p(v, _u16p), _p(rank, _i32p),
+        1 if rank_mode == "introsort" else 0, 1 if MemorySave else 0, _p(E, _u16p), _p(v, _u16p), _p(rank, _i32p),
         _p(V, _u16p), _p(Vq, _u16p), _p(J, _u16p), _p(Jp, _u16p), _p(final, _f64p))
     if stages:
         st = dict(v=v.view(np.float16), rank=rank, V=V.view(np.float16),

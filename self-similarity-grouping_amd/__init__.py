@@ -18,7 +18,7 @@ def __getattr__(name):   # lazy: torch import only when the compute surface is t
     if name in ("DBSCAN", "eps_rule", "as_handle"):
         from . import cluster
         return getattr(cluster, name)
-    if name in ("compute_dist", "generate_selflabel", "select_labeled"):
+    if name in ("compute_dist", "generate_selflabel", "select_labeled", "generate_dataset"):
         from . import selftraining
         return getattr(selftraining, name)
     if name in ("extract_features", "extract_embeddings", "extract_cnn_feature", "fliplr", "pairwise_distance", "pairwise_distance_device"):

@@ -28,7 +28,8 @@ def as_handle(X, device=None):
     """numpy / torch matrix or handle -> DistHandle on the GPU."""
     if isinstance(X, DistHandle):
         return X
-    h = getattr(X, "ssg_handle", None)
+    valid = getattr(X, "valid_handle", None)     # DeviceBackedArray: only the untouched, still read-only original carries one
+    h = valid() if callable(valid) else None
     if isinstance(h, DistHandle):
         return h
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -143,7 +144,7 @@ class DBSCAN:
             cap = ne   # the cursor counted every hit: retry once with the exact size
         edges = edges[:ne]
         if h.group is not None:
-            cnt = gather_rows(cnt, h.group)
+            cnt = gather_rows(cnt, h.group, N)
             edges = gather_varlen(edges, h.group).contiguous()
             ne = int(edges.shape[0])
         ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))

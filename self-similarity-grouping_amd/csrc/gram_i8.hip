@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * PITCH];
   const int tiles_n = (N + GI_T - 1) / GI_T, tiles_m = (M + GI_T - 1) / GI_T;
   int tm, tn;
-  if (symmetric) {
+  if (symmetric & 1) {
     const int T = tiles_n;
     const int t = xcd_remap((int)blockIdx.x, T * (T + 1) / 2);
     int r = (int)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
     tm = tile / tiles_n; tn = tile % tiles_n;
   }
-  const bool mirror = symmetric && tn > tm;
+  const bool mirror = (symmetric & 1) && tn > tm;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
   // staging: the A tile and the B tile together are 128 rows x CPR chunks of 16 bytes = NL chunks per thread
@@ -194,8 +194,10 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
       long long d2i = nA[li] + nj - 2 * dot;           // exact squared distance in units of 2^-48
       if (d2i < 0 || rowA0 + li == gj) d2i = 0;         // cannot be negative; cdist(x, x) diagonal is exactly 0
       const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
-      const hbits hh = d2h(sqrt(s));                    // cdist(...).astype(float16)   rerank.py:61
-      dd = h_mul(hh, hh);                               // np.power(half, 2)            rerank.py:62
+      const double sq = sqrt(s);
+      const hbits hh = d2h(sq);                         // cdist(...).astype(float16)   rerank.py:61
+      // np.power(half, 2) rerank.py:62; MemorySave branch (:49-59): np.power(cdist, 2).astype(float16), one rounding
+      dd = (symmetric & 2) ? d2h(sq * sq) : h_mul(hh, hh);
       D[(int64_t)li * N + gj] = (hbits)dd;
       cmax = cmax > dd ? cmax : dd;
     }
@@ -252,7 +254,7 @@ extern "C" int ssg_gram_i8_encode(const float* x, int n, int d, int ndigits, voi
 
 // Same contract as ssg_sqdist_self_f16 (rows [row0,row0+nrows) x N of the half original distance + row maxima) from the
 // encoded features; does nothing when *flag != 0 (the caller then runs ssg_sqdist_self_f16).
-extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int ndigits, int row0, int nrows, uint16_t* D, uint32_t* rowmax,
+extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, int d, int ndigits, int row0, int nrows, int memory_save, uint16_t* D, uint32_t* rowmax,
                                   const int32_t* flag, hipStream_t stream) {
   if (N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N || d <= 0 || d > 16384 || (ndigits != 3 && ndigits != 4)) {
     ssg_set_error("ssg_sqdist_self_i8: bad shape N=%d d=%d ndigits=%d row0=%d nrows=%d", N, d, ndigits, row0, nrows);
@@ -267,7 +269,7 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
   const int8_t* e = (const int8_t*)E;
   const int64_t rowbytes = (int64_t)nkb * 32 * ndigits;
 #define SSG_GI_LAUNCH(NL_, KB_) hipLaunchKernelGGL((gram_i8_kernel<NL_, KB_>), dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, \
-    (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric, flag)
+    (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric | (memory_save ? 2 : 0), flag)
   static int kb2 = -1;
   if (kb2 < 0) { const char* e_ = getenv("SSG_I8_KB2"); kb2 = e_ ? atoi(e_) : 1; }   // measured: 1 block per stage (3 waves/SIMD) 2.64 ms, 2 blocks (2 waves/SIMD) 2.9 ms at N=16000
   const bool two = kb2 == 2 && (nkb % 2) == 0;     // two k blocks per LDS stage: half the barriers, but 190 VGPRs

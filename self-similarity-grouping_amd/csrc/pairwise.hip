@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
   __shared__ double lds[2 * 2 * BK * LDR];
   const int tiles_n = (N + BN - 1) / BN, tiles_m = (M + BM - 1) / BM;
   int tm, tn;
-  if (MODE == 0 && symmetric) {
+  if (MODE == 0 && (symmetric & 1)) {
     // D is symmetric (same products, same k order): with the whole matrix on one GPU only the
     // T(T+1)/2 tiles on or above the diagonal are launched (row-major over the triangle, so every
     // XCD gets an equal share) and the strictly-upper ones are mirrored on store.
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
     const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
     tm = tile / tiles_n; tn = tile % tiles_n;
   }
-  const bool mirror = MODE == 0 && symmetric && tn > tm;
+  const bool mirror = MODE == 0 && (symmetric & 1) && tn > tm;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // staging map: one row per thread, 8 consecutive k (2 x float4) of the 16-wide k slice
@@ -181,8 +181,10 @@ __global__ __launch_bounds__(256, 2) void gram_kernel(const float* __restrict__ 
           s = s > 0.0 ? s : 0.0;
           if (MODE == 0) {
             if (rowA0 + li == gj) s = 0.0;             // cdist(x, x) diagonal is exactly 0
-            const hbits h = d2h(sqrt(s));               // cdist(...).astype(float16)   rerank.py:61
-            const hbits dd = h_mul(h, h);               // np.power(half, 2)            rerank.py:62
+            const double sq = sqrt(s);
+            const hbits h = d2h(sq);                    // cdist(...).astype(float16)   rerank.py:61
+            // np.power(half, 2) rerank.py:62; MemorySave branch (:49-59): np.power(cdist, 2).astype(float16), one rounding
+            const hbits dd = (symmetric & 2) ? d2h(sq * sq) : h_mul(h, h);
             D[(int64_t)li * N + gj] = dd;
             red = red > dd ? red : (unsigned)dd;
             if (mirror) { D[(int64_t)gj * N + li] = dd; cmax[j] = cmax[j] > dd ? cmax[j] : (unsigned)dd; }
@@ -254,7 +256,7 @@ extern "C" int ssg_row_norms_f64(const float* x, int n, int d, int round_to_half
   return SSG_OK;
 }
 
-extern "C" int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int row0, int nrows, uint16_t* D,
+extern "C" int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int row0, int nrows, int memory_save, uint16_t* D,
                                    uint32_t* rowmax, hipStream_t stream) {
   if (N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N || (d & 3)) {
     ssg_set_error("ssg_sqdist_self_f16: bad shape N=%d d=%d row0=%d nrows=%d (d must be a multiple of 4)", N, d, row0, nrows);
@@ -265,7 +267,7 @@ extern "C" int ssg_sqdist_self_f16(const float* x, const double* norms, int N, i
   const int symmetric = (row0 == 0 && nrows == N) ? 1 : 0;   // whole matrix on this GPU: compute the upper triangle, mirror on store
   const int T = (N + BN - 1) / BN;
   hipLaunchKernelGGL(gram_kernel<0>, dim3(symmetric ? T * (T + 1) / 2 : tiles), dim3(256), 0, stream, x + (int64_t)row0 * d, x, norms + row0, norms, nrows, N, d,
-                     row0, D, rowmax, symmetric);
+                     row0, D, rowmax, symmetric | (memory_save ? 2 : 0));
   SSG_LAUNCH_CHECK("gram_kernel<self>");
   return SSG_OK;
 }

@@ -5,6 +5,9 @@
 // followed by one round-to-nearest-even to half; double -> half is a single direct RNE
 // (npy_double_to_half), never via float.
 #pragma once
+// numpy rounds a*b and +c separately (e.g. rerank.py:122 final_dist, the float64 distance epilogues): no FMA contraction
+// anywhere in this library, whatever flags it is built with.
+#pragma clang fp contract(off)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

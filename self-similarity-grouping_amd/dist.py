@@ -4,8 +4,7 @@ RCCL/xGMI (backend "nccl" on ROCm) -- or gloo in the CPU tests.
 The path shards naturally: image batches split by rank for the embedding,
 row blocks of the N x N work for distance / re-rank / eps / region query.  The exchanges are
 small: one all-gather of the embeddings, all-gathers of the rank lists / sparse V / V_qe /
-edge lists, an all-reduce of the eps histogram.  Only list-style collectives that both RCCL
-and gloo implement are used, so the same code runs in the gloo tests.
+edge lists, an all-reduce of the eps histogram.  Row blocks follow `shard_bounds` (ragged N allowed); the same code runs over gloo in the CPU tests.
 """
 import os
 
@@ -34,16 +33,47 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_rows(t, group):
-    """all-gather equally sized row blocks [r, ...] -> [world*r, ...] (rank order)."""
+def _all_gather_into(out, t, group):
+    """one flat all-gather (RCCL: a single ring/direct transfer into the final buffer; gloo: same call in the CPU tests)"""
+    import torch.distributed as dist
+    try:
+        dist.all_gather_into_tensor(out, t, group=group)
+    except (RuntimeError, NotImplementedError):      # backend without the flat variant: list form + copy
+        ws = dist.get_world_size(group)
+        parts = list(out.view((ws,) + tuple(t.shape)).unbind(0))
+        dist.all_gather(parts, t, group=group)
+
+
+def gather_rows(t, group, n_total=None):
+    """all-gather the row blocks of a row-sharded table [n_r, ...] -> [n_total, ...] in rank order.
+
+    The blocks are the `shard_bounds` blocks of n_total rows (sizes differ by at most one, so N need not divide by
+    the world size: DukeMTMC 16 522, MSMT17 32 621); every rank knows all sizes, so ONE flat all-gather of blocks padded
+    to the largest size suffices.  n_total=None: equally sized blocks."""
     if group is None:
         return t
     import torch.distributed as dist
     ws = dist.get_world_size(group)
     t = t.contiguous()
-    parts = [torch.empty_like(t) for _ in range(ws)]
-    dist.all_gather(parts, t, group=group)
-    return torch.cat(parts, dim=0)
+    if n_total is None:
+        n_total = t.shape[0] * ws
+    base, rem = divmod(int(n_total), ws)
+    rk = dist.get_rank(group)
+    mine = base + (1 if rk < rem else 0)
+    if t.shape[0] != mine:
+        raise ValueError("gather_rows: rank %d holds %d rows, its block of %d rows over %d ranks has %d" % (rk, t.shape[0], n_total, ws, mine))
+    tail = tuple(t.shape[1:])
+    if rem == 0:
+        out = torch.empty((ws * base,) + tail, dtype=t.dtype, device=t.device)
+        _all_gather_into(out, t, group)
+        return out
+    mx = base + 1
+    if mine != mx:
+        t = torch.cat([t, torch.zeros((1,) + tail, dtype=t.dtype, device=t.device)], dim=0)
+    buf = torch.empty((ws * mx,) + tail, dtype=t.dtype, device=t.device)
+    _all_gather_into(buf, t, group)
+    buf = buf.view((ws, mx) + tail)
+    return torch.cat([buf[:rem].reshape((rem * mx,) + tail), buf[rem:, :base].reshape(((ws - rem) * base,) + tail)], dim=0)
 
 
 def gather_varlen(t, group):

@@ -59,11 +59,26 @@ class DistHandle:
 
 class DeviceBackedArray(np.ndarray):
     """numpy view of a materialised distance matrix that remembers its device handle, so
-    `DBSCAN.fit_predict(final_dist)` / `generate_selflabel` can skip the re-upload."""
+    `DBSCAN.fit_predict(final_dist)` / `generate_selflabel` can skip the re-upload.
+
+    The handle is attached to the freshly materialised array ONLY (`attach`): views, copies, ufunc results and astype()
+    never inherit it, and the array is handed out read-only, so every array that still carries a handle provably holds the
+    device matrix's values.  Callers that want to edit the distances copy first (np.array(final)) or flip the flag back
+    (final.setflags(write=True)); `cluster.as_handle` ignores the handle of a writeable array and uploads its contents."""
     ssg_handle = None
 
     def __array_finalize__(self, obj):
-        self.ssg_handle = getattr(obj, "ssg_handle", None) if (obj is not None and getattr(obj, "shape", None) == self.shape) else None
+        self.ssg_handle = None
+
+    @classmethod
+    def attach(cls, arr, handle):
+        out = np.asarray(arr).view(cls)
+        out.ssg_handle = handle
+        out.setflags(write=False)
+        return out
+
+    def valid_handle(self):
+        return self.ssg_handle if (self.ssg_handle is not None and not self.flags.writeable) else None
 
 
 def _as_dev_f32(x, device):
@@ -133,7 +148,7 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
     return rowmin
 
 
-def _original_distance(L, tgt, row0, nrows, max_abs, st):
+def _original_distance(L, tgt, row0, nrows, max_abs, st, memory_save=False):
     """rows [row0,row0+nrows) of the half original distance (rerank.py:33,61-62) + their maxima -> (D, rowmax, flag).
     max_abs = max|tgt| on the host; flag = device flag of the int8 encoder (None on the fp64 path), to be read with the
     caller's next host round trip (it cannot be set after the range check here)."""
@@ -154,12 +169,12 @@ def _original_distance(L, tgt, row0, nrows, max_abs, st):
         inorm = torch.empty(N, dtype=torch.int64, device=dev)
         flag = torch.zeros(1, dtype=torch.int32, device=dev)
         check(L.ssg_gram_i8_encode(ptr(tgt), N, d, nd, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
-        check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, nd, row0, nrows, ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
+        check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, nd, row0, nrows, int(bool(memory_save)), ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
         del enc, inorm
     else:
         norms = torch.empty(N, dtype=torch.float64, device=dev)
         check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
-        check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
+        check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, int(bool(memory_save)), ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
     return D, rowmax, flag
 
 
@@ -196,12 +211,12 @@ def initial_rank(D, rowmax, N, nrows, K, rank_mode=None, force_arena=False):
 
 
 def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, keep_euclid=True, row0=0, nrows=None,
-                      group=None, stages=None, rank_mode=None):
+                      group=None, stages=None, rank_mode=None, memory_save=False):
     """Fused device pipeline K3..K9 for one feature split.
 
     src [Ns,d], tgt [N,d]: float32 CUDA tensors (replicated on every rank of `group`).
-    With a group, each rank computes rows [row0,row0+nrows) and the small tables (rank
-    lists, sparse V / V_qe, v) are all-gathered; N must divide evenly by the world size.
+    With a group, each rank computes rows [row0,row0+nrows) = its `dist.shard_bounds` block (N need not divide by the
+    world size) and the small tables (rank lists, sparse V / V_qe, v) are all-gathered.
     `stages` (dict) receives intermediate tensors for parity tests.
     """
     L = _lib.lib()
@@ -210,6 +225,8 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     nrows = N if nrows is None else nrows
     if N < 2:
         raise ValueError("re_ranking needs at least 2 target samples")
+    if not no_rerank and (k1 < 1 or k2 < 1 or max(k1 + 1, k2) > 64):
+        raise ValueError("re_ranking on the GPU supports 1 <= k1 <= 63 and 1 <= k2 <= 64 (got k1=%r, k2=%r)" % (k1, k2))
     src = _as_dev_f32(src, dev); tgt = _as_dev_f32(tgt, dev)
     d = tgt.shape[1]
     st = stream()
@@ -220,21 +237,21 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     else:
         stats = torch.stack([tgt.abs().max(), src.abs().max(), tgt.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
     # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
-    D, rowmax, flag = _original_distance(L, tgt, row0, nrows, stats[0], st)
+    D, rowmax, flag = _original_distance(L, tgt, row0, nrows, stats[0], st, memory_save)
     if no_rerank:
         if flag is not None and int(flag.item()):
             raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
         return DistHandle(N, 1, D, euclid=D, row0=row0, nrows=nrows, group=group)
 
     # ---- source-domain term (rerank.py:35-40): v half [N]
-    rowmin = _gather_rows(source_vector(src, tgt, row0, nrows, stats=stats), group)
+    rowmin = _gather_rows(source_vector(src, tgt, row0, nrows, stats=stats), group, N)
     v = torch.empty(N, dtype=torch.float16, device=dev)
     vmax = torch.zeros(1, dtype=torch.int32, device=dev)
     check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
 
-    # ---- initial ranking (rerank.py:68-70)
-    K = min(k1 + 1, N)
-    rank = _gather_rows(initial_rank(D, rowmax, N, nrows, K, rank_mode), group)
+    # ---- initial ranking (rerank.py:68-70): the columns that are ever read are [0, max(k1+1, k2)) (:76, :83, :97)
+    K = min(max(k1 + 1, k2), N)
+    rank = _gather_rows(initial_rank(D, rowmax, N, nrows, K, rank_mode), group, N)
 
     # ---- k-reciprocal encoding (rerank.py:74-92)
     capV = int(L.ssg_krecip_row_capacity(k1))
@@ -242,7 +259,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     v_val = torch.empty((nrows, capV), dtype=torch.float16, device=dev)
     v_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
     check(L.ssg_krecip(ptr(D), ptr(rowmax), ptr(rank), N, row0, nrows, K, k1, capV, ptr(v_idx), ptr(v_val), ptr(v_nnz), st), "ssg_krecip")
-    v_idx, v_val, v_nnz = _gather_rows(v_idx, group), _gather_rows(v_val, group), _gather_rows(v_nnz, group)
+    v_idx, v_val, v_nnz = _gather_rows(v_idx, group, N), _gather_rows(v_val, group, N), _gather_rows(v_nnz, group, N)
 
     # ---- local query expansion (rerank.py:94-99)
     if k2 != 1:
@@ -260,7 +277,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
             m = q_nnz.max().clone(); dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
             capQ = max(int(m.item()), 1)
             q_idx, q_val = q_idx[:, :capQ].contiguous(), q_val[:, :capQ].contiguous()
-        q_idx, q_val, q_nnz = _gather_rows(q_idx, group), _gather_rows(q_val, group), _gather_rows(q_nnz, group)
+        q_idx, q_val, q_nnz = _gather_rows(q_idx, group, N), _gather_rows(q_val, group, N), _gather_rows(q_nnz, group, N)
     else:
         capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
 
@@ -294,8 +311,9 @@ def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.
                device=None, rank_mode=None):
     """Drop-in for reid/rerank.py:27 re_ranking (numpy in, numpy out).
 
-    MemorySave / Minibatch are accepted for signature compatibility; row chunking is not
-    needed on a 288 GB device.  Tie order of the initial ranking is the reference's own
+    MemorySave=True selects the numerics of the reference's chunked branch (rerank.py:49-59: the original distance is
+    squared in float64 and rounded to half once); Minibatch only sizes the reference's row chunks and changes no value, so
+    it is accepted and ignored (no chunking is needed on a 288 GB device).  Tie order of the initial ranking is the reference's own
     (np.argsort default = numpy's unstable introsort, replayed on the device); rank_mode='stable'
     selects the canonical (value, index) order instead, see DESIGN.md "ties".
     """
@@ -306,12 +324,12 @@ def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.
     tgt = _as_dev_f32(np.asarray(input_feature), device)
     if not no_rerank:
         print('starting re_ranking...')
-    h = re_ranking_device(src, tgt, k1=k1, k2=k2, lambda_value=lambda_value, no_rerank=no_rerank, rank_mode=rank_mode)
+    h = re_ranking_device(src, tgt, k1=k1, k2=k2, lambda_value=lambda_value, no_rerank=no_rerank, rank_mode=rank_mode,
+                          memory_save=MemorySave)
     euclid = h.euclid.cpu().numpy()
     if no_rerank:
         return euclid, None
-    final = h.final_dist().cpu().numpy().view(DeviceBackedArray)
-    final.ssg_handle = h
+    final = DeviceBackedArray.attach(h.final_dist().cpu().numpy(), h)
     return euclid, final
 
 

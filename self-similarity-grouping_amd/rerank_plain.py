@@ -20,7 +20,7 @@ from ._lib import check, ptr, stream
 from .rerank import DeviceBackedArray, DistHandle, ReRankNaNError, _as_dev_f32, _original_distance, source_vector
 
 
-def re_ranking_plain_device(src, tgt, k=20, lambda_value=0.1, stages=None):
+def re_ranking_plain_device(src, tgt, k=20, lambda_value=0.1, stages=None, memory_save=False):
     L = _lib.lib()
     dev = tgt.device if torch.is_tensor(tgt) and tgt.is_cuda else torch.device("cuda", torch.cuda.current_device())
     src = _as_dev_f32(src, dev); tgt = _as_dev_f32(tgt, dev)
@@ -29,7 +29,7 @@ def re_ranking_plain_device(src, tgt, k=20, lambda_value=0.1, stages=None):
         raise ValueError("re_ranking (plain): need 1 <= k <= min(N, 64), got k=%d N=%d" % (k, N))
     st = stream()
     stats = torch.stack([tgt.abs().max(), src.abs().max(), tgt.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
-    D, rowmax, flag = _original_distance(L, tgt, 0, N, stats[0], st)
+    D, rowmax, flag = _original_distance(L, tgt, 0, N, stats[0], st, memory_save)
     # source-domain term (rerank_plain.py:130-143)
     rowmin = source_vector(src, tgt, 0, N, stats=stats)
     v = torch.empty(N, dtype=torch.float16, device=dev)
@@ -72,7 +72,6 @@ def re_ranking(input_feature_source, input_feature, k=20, lambda_value=0.1, Memo
     print('computing source distance...')
     print('computing original distance...')
     h = re_ranking_plain_device(_as_dev_f32(np.asarray(input_feature_source), device), _as_dev_f32(np.asarray(input_feature), device),
-                                k=k, lambda_value=lambda_value)
-    final = h.final_dist().cpu().numpy().view(DeviceBackedArray)
-    final.ssg_handle = h
+                                k=k, lambda_value=lambda_value, memory_save=MemorySave)
+    final = DeviceBackedArray.attach(h.final_dist().cpu().numpy(), h)
     return final, final

@@ -174,14 +174,29 @@ class ResNet:
         self.device = torch.device("cpu")
         self._sd = synthetic_state_dict(seed, depth, num_features)
         self._folded = None
+        self._weights = "synthetic"      # until load_state_dict puts real backbone weights in
         if checkpoint:
-            self.load_state_dict(torch.load(checkpoint, map_location="cpu")["state_dict"], strict=False)
+            self.load_state_dict(torch.load(checkpoint, map_location="cpu"), strict=False)
+        elif pretrained:
+            # reference: torchvision's ImageNet weights are downloaded here (resnet.py:49); this build has no network and
+            # no torchvision, so the backbone starts from the seeded synthetic initialisation until a checkpoint is loaded
+            import warnings
+            warnings.warn("ssg_amd ResNet(pretrained=True): no ImageNet weights are available offline; the backbone holds seeded "
+                          "synthetic weights until load_state_dict()/checkpoint= supplies real ones", stacklevel=2)
 
     # ---- torch.nn.Module-like surface used by selftraining.py / evaluators.py
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._sd.items())
 
     def load_state_dict(self, state_dict, strict=True):
+        """torch.nn.Module.load_state_dict look-alike.  Accepts what the reference's call sites pass (selftraining.py:129-132,
+        serialization.py:31-40): the checkpoint dict itself ({'state_dict': ...}) and nn.DataParallel's 'module.' key prefix.
+        With strict=False torch leaves unmatched keys at their previous (ImageNet) values; here the previous values are
+        synthetic, so backbone keys that stay unmatched are reported with a warning instead of silently producing garbage."""
+        if isinstance(state_dict, dict) and "state_dict" in state_dict and not any(k in self._sd for k in state_dict):
+            state_dict = state_dict["state_dict"]
+        if state_dict and all(k.startswith("module.") for k in state_dict):
+            state_dict = OrderedDict((k[len("module."):], v) for k, v in state_dict.items())
         missing = [k for k in self._sd if k not in state_dict]
         unexpected = [k for k in state_dict if k not in self._sd]
         if strict and (missing or unexpected):
@@ -192,6 +207,13 @@ class ResNet:
                     raise RuntimeError("size mismatch for %s: %r vs %r" % (k, tuple(v.shape), tuple(self._sd[k].shape)))
                 self._sd[k] = v.detach().to("cpu").clone()
         self._folded = None
+        miss_base = [k for k in missing if k.startswith("base.") and not k.endswith("num_batches_tracked")]
+        if miss_base:
+            import warnings
+            warnings.warn("ssg_amd ResNet.load_state_dict: %d backbone tensors were not in the state dict and keep their synthetic "
+                          "values (first: %s)" % (len(miss_base), miss_base[0]), stacklevel=2)
+        else:
+            self._weights = "loaded"
         return missing, unexpected
 
     def eval(self):

@@ -33,16 +33,15 @@ def compute_dist(source_features, target_features, lambda_value, no_rerank, num_
         row0, nrows = 0, None
         if group is not None:
             import torch.distributed as dist
-            ws, rk = dist.get_world_size(group), dist.get_rank(group)
-            if t.shape[0] % ws:
-                raise ValueError("row-block sharding needs N (%d) divisible by the world size (%d)" % (t.shape[0], ws))
-            nrows = t.shape[0] // ws; row0 = rk * nrows
+            from .dist import shard_bounds
+            row0, row1 = shard_bounds(t.shape[0], dist.get_rank(group), dist.get_world_size(group))   # ragged N allowed
+            nrows = row1 - row0
         h = re_ranking_device(s, t, lambda_value=lambda_value, no_rerank=no_rerank, keep_euclid=no_rerank, row0=row0, nrows=nrows, group=group)
         if materialize:
             if no_rerank:
                 euclidean_dist_list.append(h.euclid.cpu().numpy()); rerank_dist_list.append(None)
             else:
-                f = h.final_dist().cpu().numpy().view(DeviceBackedArray); f.ssg_handle = h
+                f = DeviceBackedArray.attach(h.final_dist().cpu().numpy(), h)
                 euclidean_dist_list.append([]); rerank_dist_list.append(f)
         else:
             euclidean_dist_list.append(h if no_rerank else [])
@@ -74,6 +73,17 @@ def generate_selflabel(e_dist, r_dist, n_iter, args, cluster_list=[]):   # noqa:
 def select_labeled(labels_list):
     """selftraining.py:315-324 join: keep sample i iff no split labelled it -1.
     Returns (kept indices, [per-split label lists])."""
-    lab = np.stack([np.asarray(l) for l in labels_list], axis=1)
+    lab = np.stack([np.asarray(l) for l in labels_list], axis=1) if len(labels_list) else np.zeros((0, 0), np.int64)
     keep = np.nonzero((lab != -1).all(axis=1))[0]
     return keep, lab[keep]
+
+
+def generate_dataset(trainval, labels_list, iter_n=None):
+    """The dataset half of selftraining.py:315-324 generate_dataloader: [(fname, [label of split 0, ...], 0)] for every image of
+    `trainval` ([(fname, pid, cam)], loader order) that no split labelled -1; prints the reference's progress line when
+    iter_n is given.  (The DataLoader / RandomIdentitySampler the reference wraps around it belong to the fine-tune phase.)"""
+    keep, lab = select_labeled(labels_list)
+    new_dataset = [(trainval[int(i)][0], [lab[r, s] for s in range(lab.shape[1])], 0) for r, i in enumerate(keep)]
+    if iter_n is not None:
+        print('Iteration {} have {} training images'.format(iter_n + 1, len(new_dataset)))
+    return new_dataset

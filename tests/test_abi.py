@@ -36,7 +36,7 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.ssg_topk_rank(None, None, 10, 10, 65, None, None) == -1
     assert b"K" in L.ssg_last_error()
-    assert L.ssg_sqdist_self_f16(None, None, 8, 6, 0, 8, None, None, None) == -1     # d % 4 != 0
+    assert L.ssg_sqdist_self_f16(None, None, 8, 6, 0, 8, 0, None, None, None) == -1     # d % 4 != 0
     assert L.ssg_sort_u64(None, 1000, None) == -1
     assert L.ssg_krecip(None, None, None, 100, 0, 100, 21, 20, 10, None, None, None, None) == -1   # cap too small
     assert L.ssg_eps_hist(None, None, 10, 0, 10, 0, 0.1, 0, 51, 12, 1, None, None) == -1
@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu():
     assert L.ssg_h8l8_encode(None, None, 12, 1.0, None) == -1 and L.ssg_h8l8_decode(None, None, 0, 1.0, None) == -1       # n % 8
     assert L.ssg_gram_i8_encode(None, 4, 64, 5, None, None, None, None) == -1                                             # digits must be 3 or 4
     assert L.ssg_gram_i8_encode(None, 4, 20000, 3, None, None, None, None) == -1                                          # d > 16384 (int32 headroom)
-    assert L.ssg_sqdist_self_i8(None, None, 8, 64, 3, 4, 8, None, None, None, None) == -1                                 # row block outside N
+    assert L.ssg_sqdist_self_i8(None, None, 8, 64, 3, 4, 8, 0, None, None, None, None) == -1                                 # row block outside N
     assert L.ssg_gram_i8_encoded_bytes(10, 70, 3) == 10 * 3 * 32 * 3                                                      # 3 k blocks of 32, 3 digits
     assert L.ssg_source_rowmin_filtered(None, None, 8, 100, 100, 64, 1e-3, 0.0, 0.0, None, None, None) == -1              # Ns_pad % 128
     assert L.ssg_rank_metrics(None, 4, 10, 8, None, None, None, None, 0, None, None, None, None) == -1                     # ld < n

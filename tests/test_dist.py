@@ -31,25 +31,38 @@ def _cpu_worker(rank, world, port, q):
     ok = torch.equal(full, torch.arange(22, dtype=torch.int32).view(11, 2))
     blk = torch.full((3, 4), float(rank))
     gr = sd.gather_rows(blk, g)
-    ok = ok and gr.shape == (6, 4) and float(gr[:3].max()) == 0.0 and float(gr[3:].min()) == 1.0
+    ok = ok and gr.shape == (3 * world, 4) and all(float(gr[3 * r:3 * r + 3].min()) == float(gr[3 * r:3 * r + 3].max()) == float(r) for r in range(world))
+    # ragged row blocks (N not divisible by the world size): one flat all-gather of padded blocks, compacted in rank order
+    for n in (11, 16522 % 1000, 7, world, world + 1):
+        lo, hi = sd.shard_bounds(n, rank, world)
+        table = torch.arange(n * 3, dtype=torch.int32).view(n, 3)
+        ok = ok and torch.equal(sd.gather_rows(table[lo:hi].clone(), g, n), table)
+        vec = torch.arange(n, dtype=torch.float16)
+        ok = ok and torch.equal(sd.gather_rows(vec[lo:hi].clone(), g, n), vec)
+    try:
+        sd.gather_rows(torch.zeros((5, 2)), g, 11 if world == 2 and rank == 0 else 12)   # a block of the wrong size is refused
+        ok = False
+    except ValueError:
+        pass
     h = torch.tensor([1, 2, 3], dtype=torch.int64) * (rank + 1)
-    ok = ok and torch.equal(sd.all_reduce_sum(h, g), torch.tensor([3, 6, 9]))
+    ok = ok and torch.equal(sd.all_reduce_sum(h, g), torch.tensor([1, 2, 3]) * (world * (world + 1) // 2))
     empty = sd.gather_varlen(torch.zeros((0, 2), dtype=torch.int32) if rank == 0 else torch.ones((2, 2), dtype=torch.int32), g)
-    ok = ok and empty.shape == (2, 2)
+    ok = ok and empty.shape == (2 * (world - 1), 2)
     sd.barrier(g)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
-def test_dist_plumbing_gloo_world2():
+@pytest.mark.parametrize("world", [2, 3])
+def test_dist_plumbing_gloo(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_cpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_cpu_worker, args=(r, world, port, q)) for r in range(world)]
     [p.start() for p in procs]
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=180) for _ in range(world))
     [p.join(60) for p in procs]
-    assert res == [(0, True), (1, True)]
+    assert res == [(r, True) for r in range(world)]
 
 
 def test_shard_bounds_cover():
@@ -62,49 +75,63 @@ def test_shard_bounds_cover():
 
 def _gpu_worker(rank, world, port, q, N, Ns, d):
     import torch.distributed as dist
+    from types import SimpleNamespace
     import ssg_amd  # noqa: F401
-    from ssg_amd import cluster, rerank
+    from ssg_amd import compute_dist, generate_selflabel
+    from ssg_amd import dist as sd
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     g = dist.group.WORLD
-    tgt = torch.from_numpy(clustered(N, d, 5)).to(dev); src = torch.from_numpy(clustered(Ns, d, 6, intra=0.7)).to(dev)
-    nrows = N // world
+    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(3)]
+    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(3)]
+    lo, hi = sd.shard_bounds(N, rank, world)
     out = {}
-    for mode, kw in (("rerank", dict(lambda_value=0.1)), ("norerank", dict(no_rerank=True))):
-        h = rerank.re_ranking_device(src, tgt, row0=rank * nrows, nrows=nrows, group=g, **kw)
-        eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
-        lab = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h)
-        out[mode] = (float(eps), cnt, top, lab, h.M.cpu().numpy().view(np.uint16))
+    for mode, no_rerank in (("rerank", False), ("norerank", True)):
+        e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2, group=g)
+        args = SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3)
+        labels, clusters = generate_selflabel(e_list, r_list, 0, args, [])
+        hs = e_list if no_rerank else r_list
+        assert all(h.row0 == lo and h.nrows == hi - lo for h in hs)
+        out[mode] = [(float(c.eps), l, h.M.cpu().numpy().view(np.uint16)) for c, l, h in zip(clusters, labels, hs)]
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_sharded_pipeline_matches_unsharded():
-    from ssg_amd import cluster, rerank
-    N, Ns, d = 1536, 640, 96
+@pytest.mark.parametrize("world,N", [(2, 1536), (8, 1531)])
+def test_sharded_pipeline_matches_unsharded(world, N):
+    """compute_dist -> generate_selflabel, 3 feature splits, rows sharded over `world` processes (gloo; they share the
+    test box's single GPU) with ragged row blocks (1531 = 8*191 + 3): eps, labels and every local block of the distance
+    matrix bit-identical to the unsharded run."""
+    from types import SimpleNamespace
+    from ssg_amd import compute_dist, generate_selflabel
+    from ssg_amd.dist import shard_bounds
+    Ns, d = 640, 96
     dev = torch.device("cuda", 0)
-    tgt = torch.from_numpy(clustered(N, d, 5)).to(dev); src = torch.from_numpy(clustered(Ns, d, 6, intra=0.7)).to(dev)
+    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(3)]
+    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(3)]
     ref = {}
-    for mode, kw in (("rerank", dict(lambda_value=0.1)), ("norerank", dict(no_rerank=True))):
-        h = rerank.re_ranking_device(src, tgt, **kw)
-        eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
-        lab = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h)
-        ref[mode] = (float(eps), cnt, top, lab, h.M.cpu().numpy().view(np.uint16))
+    for mode, no_rerank in (("rerank", False), ("norerank", True)):
+        e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2)
+        args = SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3)
+        labels, clusters = generate_selflabel(e_list, r_list, 0, args, [])
+        hs = e_list if no_rerank else r_list
+        ref[mode] = [(float(c.eps), l, h.M.cpu().numpy().view(np.uint16)) for c, l, h in zip(clusters, labels, hs)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    world = 2
     procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, N, Ns, d)) for r in range(world)]
     [p.start() for p in procs]
-    res = dict(q.get(timeout=600) for _ in range(world))
+    res = dict(q.get(timeout=900) for _ in range(world))
     [p.join(120) for p in procs]
     for mode in ("rerank", "norerank"):
-        e0, c0, t0, l0, m0 = ref[mode]
-        for r in range(world):
-            e, c, t, l, m = res[r][mode]
-            assert (e, c, t) == (e0, c0, t0), (mode, r)
-            assert np.array_equal(l, l0), (mode, r)
-            assert np.array_equal(m, m0[r * (N // world):(r + 1) * (N // world)]), (mode, r)
+        for s in range(3):
+            e0, l0, m0 = ref[mode][s]
+            for r in range(world):
+                e, l, m = res[r][mode][s]
+                lo, hi = shard_bounds(N, r, world)
+                assert e == e0, (mode, s, r)
+                assert np.array_equal(l, l0), (mode, s, r)
+                assert np.array_equal(m, m0[lo:hi]), (mode, s, r)

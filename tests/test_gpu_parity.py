@@ -117,7 +117,8 @@ def test_pairwise_vs_oracle(N, Ns, d, dev, ora):
 
 
 # ------------------------------------------------------------------ full re-rank, stage by stage
-RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_n*.npz")) + glob.glob(os.path.join(GOLDEN, "rerank_tiefree_*.npz")))
+RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_n*.npz")) + glob.glob(os.path.join(GOLDEN, "rerank_tiefree_*.npz")) +
+                glob.glob(os.path.join(GOLDEN, "rerank_var_*.npz")))
 
 
 def _check_rerank_golden(g, mode, dev, ora):
@@ -125,13 +126,16 @@ def _check_rerank_golden(g, mode, dev, ora):
     src, tgt = g["src"], g["tgt"]
     k1, k2, lam = int(g["k1"]), int(g["k2"]), float(g["lambda_value"])
     N = tgt.shape[0]
+    msave = bool(g["memory_save"]) if "memory_save" in g.files else False      # MemorySave=True branch, rerank.py:49-59
     st = {}
     h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k1=k1, k2=k2, lambda_value=lam, stages=st,
-                                 rank_mode=mode)
-    oe, of, ost = ora.re_ranking(src, tgt, k1=k1, k2=k2, lambda_value=lam, rank_mode=mode or rerank.default_rank_mode(), stages=True)
+                                 rank_mode=mode, memory_save=msave)
+    oe, of, ost = ora.re_ranking(src, tgt, k1=k1, k2=k2, lambda_value=lam, MemorySave=msave, rank_mode=mode or rerank.default_rank_mode(),
+                                 stages=True)
     assert np.array_equal(bits(st["D"].cpu().numpy()), bits(oe)), "original distance"
     assert np.array_equal(bits(st["v"].cpu().numpy()), bits(ost["v"])), "source vector"
-    assert np.array_equal(st["rank"].cpu().numpy(), g["rank"]), "initial rank (golden)"
+    assert np.array_equal(st["rank"].cpu().numpy()[:, :g["rank"].shape[1]], g["rank"]), "initial rank (golden)"
+    assert np.array_equal(st["rank"].cpu().numpy(), ost["rank"]), "initial rank (oracle, all columns)"
     assert np.array_equal(_sparse_to_dense(st["v_idx"], st["v_val"], st["v_nnz"], N), bits(ost["V"])), "V"
     assert np.array_equal(_sparse_to_dense(st["q_idx"], st["q_val"], st["q_nnz"], N), bits(ost["V_qe"])), "V_qe"
     assert np.array_equal(bits(st["Jp"].cpu().numpy()), bits(ost["jaccard_scaled"])), "scaled jaccard"
@@ -238,6 +242,11 @@ def test_reranking_dropin_signature(golden, dev):
     assert np.array_equal(np.asarray(f), g["final"]) and np.array_equal(bits(e), bits(g["euclid"]))
     lab = DBSCAN(eps=float(g["eps"]), min_samples=4, metric="precomputed", n_jobs=8).fit_predict(f)
     assert np.array_equal(lab, g["labels"])
+    gm = golden("rerank_var_msave_ref.npz")        # MemorySave=True numerics (rerank.py:49-59), Minibatch accepted
+    em, fm = re_ranking(gm["src"], gm["tgt"], k1=20, k2=6, lambda_value=0.1, MemorySave=True, Minibatch=40)
+    assert np.array_equal(np.asarray(fm), gm["final"]) and np.array_equal(bits(em), bits(gm["euclid"]))
+    with pytest.raises(ValueError):
+        re_ranking(g["src"], g["tgt"], k1=64, k2=6)
     gs = golden("rerank_n256_l03_stable.npz")      # opt-in canonical (value, index) order
     _, fs = re_ranking(gs["src"], gs["tgt"], k1=20, k2=6, lambda_value=0.3, rank_mode="stable")
     assert np.array_equal(np.asarray(fs), gs["final"])

@@ -14,17 +14,19 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_n*.npz")) + glob.glob(os.path.join(GOLDEN, "rerank_tiefree_*.npz")))
+RERANK = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "rerank_n*.npz")) + glob.glob(os.path.join(GOLDEN, "rerank_tiefree_*.npz")) +
+                glob.glob(os.path.join(GOLDEN, "rerank_var_*.npz")))
 
 
 @pytest.mark.parametrize("name", RERANK)
 def test_rerank_stages_match_reference(name, golden, ora):
     g = golden(name)
     mode = "stable" if bool(g["stable"]) else "introsort"   # 'ref' fixtures = untouched reference incl. unstable ties
+    msave = bool(g["memory_save"]) if "memory_save" in g.files else False      # MemorySave=True branch, rerank.py:49-59
     e, f, st = ora.re_ranking(g["src"], g["tgt"], k1=int(g["k1"]), k2=int(g["k2"]), lambda_value=float(g["lambda_value"]),
-                              rank_mode=mode, stages=True)
+                              MemorySave=msave, rank_mode=mode, stages=True)
     assert not bool(g["exp_quirk"])
-    assert np.array_equal(st["rank"], g["rank"])
+    assert np.array_equal(st["rank"][:, :g["rank"].shape[1]], g["rank"])
     if "sha_euclid" in g.files:
         assert sha(e) == str(g["sha_euclid"])
         assert sha(st["V"]) == str(g["sha_V"])

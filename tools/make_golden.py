@@ -320,6 +320,36 @@ def tiefree_fixture(mod):
     return True
 
 
+def variant_fixtures(mod):
+    """Untouched reference on the argument combinations outside the script defaults: MemorySave=True (rerank.py:49-59: the
+    original distance is squared in float64 and rounded once; Minibatch chunks the rows) and k2 > k1+1 (the query expansion
+    :97 then reads initial_rank columns beyond k1+1)."""
+    ok = True
+    for name, N, Ns, d, kw in (("msave", 96, 64, 64, dict(k1=20, k2=6, lambda_value=0.1, MemorySave=True, Minibatch=40)),
+                               ("k2wide", 96, 64, 64, dict(k1=4, k2=9, lambda_value=0.3))):
+        tgt = clustered(N, d, 31); src = clustered(Ns, d, 1031, intra=0.6)
+        e, f, cap = run_ref(mod, src, tgt, False, **kw)
+        oe, of, st = ora.re_ranking(src, tgt, rank_mode="introsort", stages=True, **kw)
+        K = cap["rank"].shape[1]
+        chk = dict(euclid=beq(e, oe), rank=beq(cap["rank"], st["rank"][:, :K]), V=beq(cap["V"], st["V"]), V_qe=beq(cap["V_qe"], st["V_qe"]),
+                   jaccard=beq(cap["jaccard"], st["jaccard"]), final=beq(f, of))
+        rho = 2e-2
+        eps, cnt, top = eps_rule_ref(f, rho)
+        labels = DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(f)
+        chk.update(eps=(float(eps), cnt, top) == ora.eps_rule(f, rho), labels=beq(labels, ora.dbscan(f, eps, 4)))
+        if name == "msave":     # the two branches must really differ on this input, or the fixture pins nothing
+            e0, _ = mod.re_ranking(src, tgt, k1=20, k2=6, lambda_value=0.1, no_rerank=True)
+            assert not beq(e, e0), "MemorySave fixture does not distinguish the two rounding orders"
+        print("variant %-7s oracle==reference: %s" % (name, chk))
+        ok = ok and all(chk.values())
+        np.savez_compressed(os.path.join(OUT, "rerank_var_%s_ref.npz" % name), src=src, tgt=tgt, k1=kw["k1"], k2=kw["k2"],
+                            lambda_value=kw["lambda_value"], memory_save=bool(kw.get("MemorySave", False)), rho=rho, stable=False,
+                            rank=cap["rank"].astype(np.int32), eps=np.float64(eps), count=cnt, top_num=top, labels=labels.astype(np.int64),
+                            tie_free=False, exp_quirk=False, v=cap["source_dist_row0"].astype(np.float64), euclid=e, final=f, V=cap["V"],
+                            V_qe=cap["V_qe"], jaccard=cap["jaccard"])
+    return ok
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-plain" in sys.argv:        # regenerate just tests/golden/rerank_plain.npz
@@ -332,11 +362,13 @@ def main():
         sys.exit(0 if ok else 1)
     ora.build(force=True)
     mod = load_ref_rerank()
-    if "--only-tiefree" in sys.argv:      # regenerate just tests/golden/rerank_tiefree_*.npz
+    if "--only-tiefree" in sys.argv:      # regenerate just tests/golden/rerank_tiefree_*.npz and rerank_var_*.npz
         ok = tiefree_fixture(mod)
+        ok = variant_fixtures(mod) and ok
         print("ALL OK" if ok else "ORACLE MISMATCH")
         sys.exit(0 if ok else 1)
     ok = tiefree_fixture(mod)
+    ok = variant_fixtures(mod) and ok
 
     # ---- half exp table of this host's numpy + the exceptions vs correct rounding
     allh, npx, cr, bad = exp_quirk_inputs()
