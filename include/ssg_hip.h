@@ -89,7 +89,7 @@ int ssg_topk_rank(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, i
 /* The same K columns in the order of the UNMODIFIED reference: np.argsort's default kind (rerank.py:70) is numpy's unstable
  * introsort on an index array (npysort aquicksort_<half>: median-of-3 Hoare partition, insertion sort below 17 entries,
  * heapsort past the depth budget), so the column of equal keys depends on the whole partition sequence.  One workgroup per
- * row replays exactly the partitions that reach columns [0,K) (csrc/topk_intro.hip).  2 <= N <= 262144, K <= 64.
+ * row replays exactly the partitions that reach columns [0,K) (csrc/topk_intro.hip).  2 <= N <= 131072, K <= 64.
  * ws: ssg_topk_rank_introsort_ws_bytes(N, nrows) bytes (0 while a row fits in LDS, N <= ~36 k).  A caller that passes
  * ssg_topk_rank_introsort_arena_bytes(N, nrows) bytes anyway selects the global-arena variant for any N (parity tests). */
 size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows);

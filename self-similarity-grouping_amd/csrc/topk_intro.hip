@@ -9,9 +9,12 @@
 // column r depends on the whole sequence of partitions, and the normalised half distances tie in
 // nearly every row (hard part 1).  This kernel reproduces that order exactly:
 //
-//   * one workgroup per row; the row's (key, column) pairs live in LDS as packed 32-bit entries
-//     (14-bit order key of the normalised half | 18-bit column), or in a global arena when the row
-//     does not fit (N > ~36 k);
+//   * one workgroup per row; the row lives in LDS as packed 32-bit entries (15-bit raw half distance |
+//     17-bit column), or in a global arena when it does not fit (N > ~36 k).  The sort key is
+//     key(raw) = half(raw / rowmax), a monotone step function of the raw value, so a comparison with a
+//     pivot key is a comparison of the raw value with the two ends of the pivot's key class
+//     [lo, hi] = {raw : key(raw) == key(pivot)}: only the pivots (and the <= 16-entry tails) are ever
+//     divided, not the N entries;
 //   * only the ranges of the quicksort recursion that intersect output columns [0, K) are walked
 //     (about 2N element visits per row instead of N log N);
 //   * each Hoare partition is executed data-parallel instead of by two sequential scanning
@@ -20,7 +23,7 @@
 //     g(p) = #R-stoppers at positions > p, the scanning pointers perform m = f(p*) swaps, where p* is
 //     the last position with g(p) >= f(p); they pair the k-th L-stopper from the left with the k-th
 //     R-stopper from the right (k <= m), and the pivot lands at p* + 1.  Stopper bitmasks come from
-//     wave ballots, ranks from popcounts and one prefix scan, so a partition costs four barriers.
+//     wave-wide compares, ranks from popcounts and one DPP prefix scan; a partition costs three barriers.
 //     tools/introsort_model.py states the same computation in numpy and is checked against the
 //     sequential restatement (oracle/ssg_oracle.c aquicksort_half) on the CPU;
 //   * ranges of <= 1024 entries are finished by wave 0 alone (no workgroup barriers).
@@ -29,23 +32,35 @@
 namespace ssg {
 namespace intro {
 
-constexpr int NT = 256;            // threads per workgroup
-constexpr int NW = NT / 64;        // waves per workgroup
+#ifdef SSG_INTRO_PROF
+// cycle accounting for tools/micro/intro_prof.hip: thread 0 accumulates s_memtime deltas per phase in registers
+// (compile-time slots) and publishes them once per row
+__device__ unsigned long long g_prof[16];
+struct ProfAcc { unsigned long long a[16]; };
+#define PROF_ARG , ProfAcc& pacc_
+#define PROF_PASS , pacc_
+#define PROF_DECL unsigned long long prof_t_ = clock64()
+#define PROF(slot) do { const unsigned long long n_ = clock64(); pacc_.a[slot] += n_ - prof_t_; prof_t_ = n_; } while (0)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define PROF_DECL do {} while (0)
+#define PROF(slot) do {} while (0)
+#endif
+
 constexpr int SMALL = 15;          // ranges with pr - pl > SMALL are partitioned (numpy 2.2.6)
 constexpr int WAVE_N = 1024;       // ranges up to this many entries are handled by wave 0 alone
 constexpr int STACK = 64;          // pending ranges that intersect [0, K): all disjoint with pl < K <= 64
-constexpr int IDX_BITS = 18;       // column bits of a packed entry (N <= 262144)
+constexpr int IDX_BITS = 17;       // column bits of a packed entry (N <= 131072); the raw half (< 0x8000) sits above
 constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;
-constexpr uint32_t KEY_NAN = 0x3fffu;
+constexpr uint32_t KEY_NAN = 0xffffu;
+constexpr int MAXCH = 64;          // chunks of mask words per partition (one lane each in the chunk scan)
 
 struct Ctl {
-  uint64_t wtot[NW];     // stoppers (L low word, R high word) seen by each wave of the flag pass
-  uint64_t woff[NW];     // exclusive prefix of wtot
-  uint64_t tot;
-  int stack[STACK * 3];  // (pl, pr, depth budget) of pushed ranges that still matter
+  uint32_t ctotL[MAXCH], ctotR[MAXCH];   // stoppers per chunk of 2^cs mask words
+  int stack[STACK * 3];                  // (pl, pr, depth budget) of pushed ranges that still matter
   int sp;
-  int wstar;
-  uint32_t vp;
+  uint32_t xp;                           // raw half of the current pivot
 };
 
 struct LdsArena {
@@ -59,9 +74,13 @@ struct GlobalArena {
   __device__ __forceinline__ void set(int i, uint32_t e) const { p[i] = e; }
 };
 
-__device__ __forceinline__ uint32_t ekey(uint32_t e) { return e >> IDX_BITS; }
-__device__ __forceinline__ uint32_t lo32(uint64_t x) { return (uint32_t)x; }
-__device__ __forceinline__ uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
+__device__ __forceinline__ uint32_t eraw(uint32_t e) { return e >> IDX_BITS; }
+
+// order key of half(raw / rowmax): the half bit pattern (values in [0, 1]); NaN sorts last like numpy's half less-than
+__device__ __forceinline__ uint32_t norm_key(uint32_t raw, float fmx) {
+  const hbits q = f2h(h2f((hbits)raw) / fmx);
+  return h_isnan(q) ? KEY_NAN : (uint32_t)q;
+}
 
 template <bool WAVE>
 __device__ __forceinline__ void gsync() {
@@ -87,112 +106,179 @@ __device__ __forceinline__ int nth_set_bit(uint64_t m, int n) {
 struct Masks {
   uint64_t* L;     // bit b of L[w]: position s0 + 64 w + b holds a key >= pivot
   uint64_t* R;     //                                         ...   a key <= pivot
-  uint64_t* P;     // inclusive prefix of (popc L | popc R << 32) inside the owning wave's chunk of words
+  uint32_t* P;     // inclusive stopper counts from the start of the word's chunk up to and including word w: L | R << 16
 };
 
-// inclusive packed stopper count up to and including word w
-__device__ __forceinline__ uint64_t pincl(const Masks& mk, const Ctl* sh, int w, int wpw) { return mk.P[w] + sh->woff[w / wpw]; }
+// wave64 inclusive prefix sum on the DPP network (row shifts inside the 16-lane rows, then row broadcasts)
+template <int CTRL, int ROWM, int BANKM, bool BC>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t src) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROWM, BANKM, BC);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  uint32_t v = x + dpp_mov<0x111, 0xf, 0xf, true>(x);     // row_shr:1
+  v += dpp_mov<0x112, 0xf, 0xf, true>(x);                 // row_shr:2
+  v += dpp_mov<0x113, 0xf, 0xf, true>(x);                 // row_shr:3
+  v += dpp_mov<0x114, 0xf, 0xe, false>(v);                // row_shr:4, banks 1-3
+  v += dpp_mov<0x118, 0xf, 0xc, false>(v);                // row_shr:8, banks 2-3
+  v += dpp_mov<0x142, 0xa, 0xf, false>(v);                // row_bcast:15 -> rows 1, 3
+  v += dpp_mov<0x143, 0xc, 0xf, false>(v);                // row_bcast:31 -> rows 2, 3
+  return v;
+}
 
-// smallest word whose inclusive count (L: low half, R: high half) reaches r (1-based rank from the left)
+// word holding the r-th (1-based, from the left) stopper: chunk through the per-lane chunk prefix `ex` (lane c = stoppers in
+// chunks < c; nchp = power of two >= number of chunks), then the word inside the chunk through its running counts P
 template <bool RIGHT>
-__device__ __forceinline__ int word_of_rank(const Masks& mk, const Ctl* sh, int W, int wpw, uint32_t r) {
-  int lo = 0, hi = W - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    const uint64_t p = pincl(mk, sh, mid, wpw);
-    const uint32_t c = RIGHT ? hi32(p) : lo32(p);
-    if (c >= r) hi = mid; else lo = mid + 1;
+__device__ __forceinline__ int word_of_rank(const uint32_t* P, uint32_t ex, int W, int cs, int nch, int nchp, uint32_t r, uint32_t& before_chunk) {
+  int lo = 0;                            // last chunk whose exclusive offset is < r (ex[0] = 0 < r); wave-uniform trip count: the
+  for (int step = nchp >> 1; step >= 1; step >>= 1) {      // shuffles need every lane of the wave active
+    const int cand = lo + step;
+    const uint32_t v = (uint32_t)__shfl((int)ex, cand & 63);
+    if (cand < nch && v < r) lo = cand;
   }
-  return lo;
+  const uint32_t off = (uint32_t)__shfl((int)ex, lo);
+  before_chunk = off;
+  int wl = lo << cs, wh = min(W, wl + (1 << cs)) - 1;
+  const uint32_t rr = r - off;
+  while (wl < wh) {
+    const int mid = (wl + wh) >> 1;
+    const uint32_t c = RIGHT ? (P[mid] >> 16) : (P[mid] & 0xffffu);
+    if (c >= rr) wh = mid; else wl = mid + 1;
+  }
+  return wl;
+}
+
+// ends [lo, hi] of the raw values that share the pivot's key (key is monotone in raw): the lanes probe 64 neighbours at a
+// time (one or two raw values share a key in the normal range; arbitrarily many when the key is a half subnormal)
+__device__ __forceinline__ void key_class(uint32_t xp, float fmx, uint32_t& lo, uint32_t& hi) {
+  const uint32_t lane1 = (uint32_t)lane_id() + 1u;
+  const uint32_t kp = norm_key(xp, fmx);
+  lo = xp; hi = xp;
+  for (;;) {
+    const bool same = lo >= lane1 && norm_key(lo - lane1, fmx) == kp;
+    const uint64_t b = __ballot(same);
+    const int n = (b == ~0ull) ? 64 : __builtin_ctzll(~b);
+    lo -= (uint32_t)n;
+    if (n < 64) break;
+  }
+  for (;;) {
+    const bool same = hi + lane1 <= 0x7fffu && norm_key(hi + lane1, fmx) == kp;
+    const uint64_t b = __ballot(same);
+    const int n = (b == ~0ull) ? 64 : __builtin_ctzll(~b);
+    hi += (uint32_t)n;
+    if (n < 64) break;
+  }
 }
 
 // One Hoare partition of A[pl..pr] (pr - pl > SMALL) by the whole workgroup (WAVE = false) or by the calling wave
-// alone (WAVE = true, W <= 16 words).  Returns the final pivot position.
-template <bool WAVE, class Arena>
-__device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& mk, int pl, int pr) {
+// alone (WAVE = true).  Returns the final pivot position.  Three barriers: A | B | C+D+E | (F).
+template <bool WAVE, int NT, class Arena>
+__device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int pl, int pr PROF_ARG) {
+  constexpr int NW = NT / 64;
   const int lane = lane_id();
   const int tid = WAVE ? lane : (int)threadIdx.x;
-  const int nthr = WAVE ? 64 : NT;
-  const int nwav = WAVE ? 1 : NW;
-  const int wav = WAVE ? 0 : (int)(threadIdx.x >> 6);
+  constexpr int nthr = WAVE ? 64 : NT;
+  constexpr int nwav = WAVE ? 1 : NW;
+  const int wav = WAVE ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int s0 = pl + 1, s1 = pr - 2;
-  const int W = (s1 - s0 + 64) >> 6;
-  const int wpw = (W + nwav - 1) / nwav;
+  const int nscan = s1 - s0 + 1;
+  const int W = (nscan + 63) >> 6;
+  // chunks of 2^cs words (cs >= 2: one 4-word group of the flag pass), at most MAXCH of them
+  int cs = 2;
+  while (((W + (1 << cs) - 1) >> cs) > MAXCH) cs++;
+  const int nch = (W + (1 << cs) - 1) >> cs;
+  int nchp = 1;
+  while (nchp < nch) nchp <<= 1;
+  PROF_DECL;
 
-  // ---- A: median of three, pivot parked at pr-1 (quicksort.cpp, head of the partition loop)
+  // ---- A: median of three (on keys), pivot parked at pr-1 (quicksort.cpp, head of the partition loop)
   if (tid == 0) {
     const int pm = pl + ((pr - pl) >> 1);
     uint32_t el = A.get(pl), em = A.get(pm), er = A.get(pr), t;
-    if (ekey(em) < ekey(el)) { t = em; em = el; el = t; }
-    if (ekey(er) < ekey(em)) { t = er; er = em; em = t; }
-    if (ekey(em) < ekey(el)) { t = em; em = el; el = t; }
     const uint32_t e2 = A.get(pr - 1);
+    uint32_t kl = norm_key(eraw(el), fmx), km = norm_key(eraw(em), fmx), kr = norm_key(eraw(er), fmx);
+    if (km < kl) { t = em; em = el; el = t; t = km; km = kl; kl = t; }
+    if (kr < km) { t = er; er = em; em = t; t = kr; kr = km; km = t; }
+    if (km < kl) { t = em; em = el; el = t; }
     A.set(pl, el); A.set(pr, er); A.set(pm, e2); A.set(pr - 1, em);
-    sh->vp = ekey(em);
-    sh->wstar = 0;
+    sh->xp = eraw(em);
   }
   gsync<WAVE>();
-  const uint32_t vp = sh->vp;
+  PROF(WAVE ? 11 : 1);
+  uint32_t tlo, thi;                    // key(raw) >= key(pivot) <=> raw >= tlo;  key(raw) <= key(pivot) <=> raw <= thi
+  key_class(sh->xp, fmx, tlo, thi);
 
-  // ---- B: stopper masks of the scan region + running counts (each wave owns a contiguous chunk of words)
-  {
-    const int w0 = wav * wpw, w1 = min(W, w0 + wpw);
-    uint64_t run = 0;
-    for (int w = w0; w < w1; w++) {
-      const int p = s0 + (w << 6) + lane;
-      const bool valid = p <= s1;
-      const uint32_t k = valid ? ekey(A.get(p)) : 0u;
-      const uint64_t lm = __ballot(valid && k >= vp);
-      const uint64_t rm = __ballot(valid && k <= vp);
-      run += (uint64_t)__popcll(lm) | ((uint64_t)__popcll(rm) << 32);
-      if (lane == 0) { mk.L[w] = lm; mk.R[w] = rm; mk.P[w] = run; }
+  // ---- B: stopper masks of the scan region + running counts inside each chunk; four words (256 positions) per step,
+  //         loads unconditional (clamped address), validity as a wave-uniform mask, one lane stores the group
+  for (int ch = wav; ch < nch; ch += nwav) {
+    uint32_t runL = 0, runR = 0;
+    const int wb = ch << cs, we = min(W, wb + (1 << cs));
+    for (int w = wb; w < we; w += 4) {
+      uint32_t e[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) e[u] = A.get(min(s0 + ((w + u) << 6) + lane, s1));
+      uint64_t lm[4], rm[4];
+      uint32_t cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int rem = nscan - ((w + u) << 6);                         // scan positions left from this word on (uniform)
+        const uint64_t vm = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+        const uint32_t x = eraw(e[u]);
+        lm[u] = __builtin_amdgcn_uicmp(x, tlo, 35) & vm;                // ICMP_UGE
+        rm[u] = __builtin_amdgcn_uicmp(x, thi, 37) & vm;                // ICMP_ULE
+        runL += (uint32_t)__popcll(lm[u]); runR += (uint32_t)__popcll(rm[u]);
+        cc[u] = runL | (runR << 16);
+      }
+      if (lane == 0) {     // the arrays are padded to a multiple of four words
+        uint4* q = reinterpret_cast<uint4*>(mk.L + w);
+        q[0] = make_uint4((uint32_t)lm[0], (uint32_t)(lm[0] >> 32), (uint32_t)lm[1], (uint32_t)(lm[1] >> 32));
+        q[1] = make_uint4((uint32_t)lm[2], (uint32_t)(lm[2] >> 32), (uint32_t)lm[3], (uint32_t)(lm[3] >> 32));
+        q = reinterpret_cast<uint4*>(mk.R + w);
+        q[0] = make_uint4((uint32_t)rm[0], (uint32_t)(rm[0] >> 32), (uint32_t)rm[1], (uint32_t)(rm[1] >> 32));
+        q[1] = make_uint4((uint32_t)rm[2], (uint32_t)(rm[2] >> 32), (uint32_t)rm[3], (uint32_t)(rm[3] >> 32));
+        *reinterpret_cast<uint4*>(mk.P + w) = make_uint4(cc[0], cc[1], cc[2], cc[3]);
+      }
     }
-    if (lane == 0) sh->wtot[wav] = run;
+    if (lane == 0) { sh->ctotL[ch] = runL; sh->ctotR[ch] = runR; }
   }
   gsync<WAVE>();
+  PROF(WAVE ? 12 : 2);
 
-  // ---- C: chunk offsets; count the words at whose end g >= f still holds (monotone) -> crossing word
-  {
-    uint64_t tot = 0;
-    for (int u = 0; u < nwav; u++) tot += sh->wtot[u];
-    if (tid < nwav) {
-      uint64_t off = 0;
-      for (int u = 0; u < tid; u++) off += sh->wtot[u];
-      sh->woff[tid] = off;
-      if (tid == 0) sh->tot = tot;
-    }
-    const uint32_t totR = hi32(tot);
-    int cnt = 0;
-    for (int w = tid; w < W; w += nthr) {
-      const int c = w / wpw;
-      uint64_t off = 0;
-      for (int u = 0; u < c; u++) off += sh->wtot[u];
-      const uint64_t p = mk.P[w] + off;
-      cnt += (totR - hi32(p)) >= lo32(p) ? 1 : 0;
-    }
-    // wave reduction, one LDS atomic per wave
-    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
-    if (lane == 0 && cnt) atomicAdd(&sh->wstar, cnt);
+  // ---- C: chunk prefix in registers (every wave scans the <= 64 chunk totals itself: no barrier, no shared result)
+  const uint32_t cL = lane < nch ? sh->ctotL[lane] : 0u, cR = lane < nch ? sh->ctotR[lane] : 0u;
+  const uint32_t inL = wave_incl_scan(cL), inR = wave_incl_scan(cR);
+  const uint32_t exL = inL - cL, exR = inR - cR;
+  const uint32_t totL = (uint32_t)__builtin_amdgcn_readlane((int)inL, 63), totR = (uint32_t)__builtin_amdgcn_readlane((int)inR, 63);
+  // crossing word = number of words at whose end g >= f still holds (monotone), counted 64 words at a time
+  int wstar = 0;
+  for (int wb = 0; wb < W; wb += 64) {
+    const int w = wb + lane;
+    const bool valid = w < W;
+    const int wc = valid ? w : W - 1;
+    const uint32_t oL = (uint32_t)__shfl((int)exL, wc >> cs), oR = (uint32_t)__shfl((int)exR, wc >> cs);
+    const uint32_t pw = mk.P[wc];
+    const bool g = valid && (totR - ((pw >> 16) + oR)) >= ((pw & 0xffffu) + oL);
+    const int pc = __popcll(__ballot(g));
+    wstar += pc;
+    if (pc != 64) break;                 // monotone: the first false (or the end of the words) ends the count
   }
-  gsync<WAVE>();
+  PROF(WAVE ? 13 : 3);
 
   // ---- D: number of swaps m and the pivot position p* + 1 (every wave computes them redundantly)
-  const uint64_t tot = sh->tot;
-  const uint32_t totL = lo32(tot), totR = hi32(tot);
-  const int wstar = sh->wstar;
   uint32_t m;
   int pstar;
   if (wstar >= W) {
     m = totL; pstar = s1;
   } else {
     const uint64_t lm = mk.L[wstar], rm = mk.R[wstar];
-    const uint64_t p = pincl(mk, sh, wstar, wpw);
-    const uint32_t cumL = lo32(p) - (uint32_t)__popcll(lm);       // L-stoppers in words < wstar
-    const uint32_t cumR = totR - hi32(p);                         // R-stoppers in words > wstar
+    const int ch = wstar >> cs;
+    const uint32_t pw = mk.P[wstar];
+    const uint32_t pL = (pw & 0xffffu) + (uint32_t)__shfl((int)exL, ch), pR = (pw >> 16) + (uint32_t)__shfl((int)exR, ch);
+    const uint32_t cumL = pL - (uint32_t)__popcll(lm);       // L-stoppers in words < wstar
+    const uint32_t cumR = totR - pR;                         // R-stoppers in words > wstar
     const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const uint32_t f = cumL + (uint32_t)__popcll(lm & le);
     const uint32_t g = cumR + (uint32_t)__popcll(rm & ~le);
-    const bool valid = s0 + (wstar << 6) + lane <= s1;
+    const bool valid = (wstar << 6) + lane < nscan;
     const uint64_t bal = __ballot(valid && g >= f);
     if (bal == 0) {
       m = cumL; pstar = s0 + (wstar << 6) - 1;
@@ -204,70 +290,78 @@ __device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& m
     }
   }
   const int pi = pstar + 1;
+  PROF(WAVE ? 14 : 4);
 
   // ---- E: swap the k-th L-stopper from the left with the k-th R-stopper from the right, k <= m
-  if (m) {
+  {
     const uint32_t c = (m + nthr - 1) / nthr;
     const uint32_t k0 = (uint32_t)tid * c + 1u;
     const uint32_t k1 = min(m, k0 + c - 1u);
-    if (k0 <= k1) {
-      int wl = word_of_rank<false>(mk, sh, W, wpw, k0);
-      uint64_t ml = mk.L[wl];
-      {
-        const uint32_t before = lo32(pincl(mk, sh, wl, wpw)) - (uint32_t)__popcll(ml);
-        const int b = nth_set_bit(ml, (int)(k0 - before));
-        ml &= ~((1ull << b) - 1ull);                               // keep bits >= b
-      }
-      const uint32_t t0 = totR - k0 + 1u;                          // the same stopper counted from the left
-      int wr = word_of_rank<true>(mk, sh, W, wpw, t0);
-      uint64_t mr = mk.R[wr];
-      {
-        const uint32_t before = hi32(pincl(mk, sh, wr, wpw)) - (uint32_t)__popcll(mr);
-        const int b = nth_set_bit(mr, (int)(t0 - before));
-        mr &= (b == 63) ? ~0ull : ((2ull << b) - 1ull);            // keep bits <= b
-      }
-      for (uint32_t k = k0; k <= k1; k++) {
-        while (ml == 0) ml = mk.L[++wl];
-        const int bl = __ffsll((long long)ml) - 1;
-        ml &= ml - 1;
-        while (mr == 0) mr = mk.R[--wr];
-        const int br = 63 - __clzll((long long)mr);
-        mr &= ~(1ull << br);
-        const int a = s0 + (wl << 6) + bl, b = s0 + (wr << 6) + br;
-        const uint32_t ea = A.get(a), eb = A.get(b);
-        A.set(a, eb); A.set(b, ea);
+    const bool work = m != 0 && k0 <= k1;
+    // the chunk search shuffles across the wave: every lane takes part (idle lanes look up rank 1 of an existing stopper)
+    if (__ballot(work)) {
+      const uint32_t rl = work ? k0 : 1u, rr = work ? (totR - k0 + 1u) : 1u;      // the R stopper counted from the left
+      uint32_t offl, offr;
+      int wl = word_of_rank<false>(mk.P, exL, W, cs, nch, nchp, rl, offl);
+      int wr = word_of_rank<true>(mk.P, exR, W, cs, nch, nchp, rr, offr);
+      if (work) {
+        uint64_t ml = mk.L[wl], mr = mk.R[wr];
+        {
+          const uint32_t before = offl + (mk.P[wl] & 0xffffu) - (uint32_t)__popcll(ml);
+          const int b = nth_set_bit(ml, (int)(rl - before));
+          ml &= ~((1ull << b) - 1ull);                               // keep bits >= b
+        }
+        {
+          const uint32_t before = offr + (mk.P[wr] >> 16) - (uint32_t)__popcll(mr);
+          const int b = nth_set_bit(mr, (int)(rr - before));
+          mr &= (b == 63) ? ~0ull : ((2ull << b) - 1ull);            // keep bits <= b
+        }
+        for (uint32_t k = k0; k <= k1; k++) {
+          while (ml == 0) ml = mk.L[++wl];
+          const int bl = __ffsll((long long)ml) - 1;
+          ml &= ml - 1;
+          while (mr == 0) mr = mk.R[--wr];
+          const int br = 63 - __clzll((long long)mr);
+          mr &= ~(1ull << br);
+          const int a = s0 + (wl << 6) + bl, b = s0 + (wr << 6) + br;
+          const uint32_t ea = A.get(a), eb = A.get(b);
+          A.set(a, eb); A.set(b, ea);
+        }
       }
     }
   }
   gsync<WAVE>();
+  PROF(WAVE ? 15 : 5);
 
   // ---- F: pivot into place (visible to thread 0 / wave 0, which own every step that follows before the next barrier)
   if (tid == 0) {
     const uint32_t e1 = A.get(pi), e2 = A.get(pr - 1);
     A.set(pi, e2); A.set(pr - 1, e1);
   }
+  PROF(6);
   return pi;
 }
 
 // heapsort.cpp aheapsort_ on A[lo .. lo+n) (one thread; only reached past the depth budget)
 template <class Arena>
-__device__ __forceinline__ void heapsort(const Arena& A, int lo, int n) {
+__device__ __forceinline__ void heapsort(const Arena& A, float fmx, int lo, int n) {
   const int base = lo - 1;   // 1-based heap
+  auto key = [&](int i) { return norm_key(eraw(A.get(base + i)), fmx); };
   int i, j, l;
-  uint32_t tmp;
+  uint32_t tmp, ktmp;
   for (l = n >> 1; l > 0; --l) {
-    tmp = A.get(base + l);
+    tmp = A.get(base + l); ktmp = norm_key(eraw(tmp), fmx);
     for (i = l, j = l << 1; j <= n;) {
-      if (j < n && ekey(A.get(base + j)) < ekey(A.get(base + j + 1))) j += 1;
-      if (ekey(tmp) < ekey(A.get(base + j))) { A.set(base + i, A.get(base + j)); i = j; j += j; } else break;
+      if (j < n && key(j) < key(j + 1)) j += 1;
+      if (ktmp < key(j)) { A.set(base + i, A.get(base + j)); i = j; j += j; } else break;
     }
     A.set(base + i, tmp);
   }
   for (; n > 1;) {
-    tmp = A.get(base + n); A.set(base + n, A.get(base + 1)); n -= 1;
+    tmp = A.get(base + n); ktmp = norm_key(eraw(tmp), fmx); A.set(base + n, A.get(base + 1)); n -= 1;
     for (i = 1, j = 2; j <= n;) {
-      if (j < n && ekey(A.get(base + j)) < ekey(A.get(base + j + 1))) j++;
-      if (ekey(tmp) < ekey(A.get(base + j))) { A.set(base + i, A.get(base + j)); i = j; j += j; } else break;
+      if (j < n && key(j) < key(j + 1)) j++;
+      if (ktmp < key(j)) { A.set(base + i, A.get(base + j)); i = j; j += j; } else break;
     }
     A.set(base + i, tmp);
   }
@@ -275,11 +369,11 @@ __device__ __forceinline__ void heapsort(const Arena& A, int lo, int n) {
 
 // insertion sort of A[pl..pr] (<= 16 entries) == stable rank sort, one wave
 template <class Arena>
-__device__ __forceinline__ void insertion(const Arena& A, int pl, int pr) {
+__device__ __forceinline__ void insertion(const Arena& A, float fmx, int pl, int pr) {
   gsync<true>();
   const int lane = lane_id(), n = pr - pl + 1;
-  const uint32_t e = lane < n ? A.get(pl + lane) : 0xffffffffu;
-  const uint32_t k = ekey(e);
+  const uint32_t e = lane < n ? A.get(pl + lane) : 0u;
+  const uint32_t k = norm_key(eraw(e), fmx);
   int r = 0;
   for (int q = 0; q < n; q++) {
     const uint32_t kq = (uint32_t)__shfl((int)k, q);
@@ -299,8 +393,8 @@ __device__ __forceinline__ Split split_ranges(int pl, int pr, int pi) {
 }
 
 // sorts exactly the ranges of the introsort recursion that intersect [0, K)
-template <class Arena>
-__device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks& mk, int N, int K) {
+template <int NT, class Arena>
+__device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int N, int K PROF_ARG) {
   const int tid = (int)threadIdx.x, lane = lane_id(), wav = tid >> 6;
   int sp = 0;
   int pl = 0, pr = N - 1, cd = 2 * (31 - __clz(N));
@@ -312,14 +406,14 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
       --sp;
       pl = sh->stack[3 * sp]; pr = sh->stack[3 * sp + 1]; cd = sh->stack[3 * sp + 2];
       if (cd < 0) {                       // popped past the depth budget: heapsort the whole range
-        if (tid == 0) heapsort(A, pl, pr - pl + 1);
+        if (tid == 0) heapsort(A, fmx, pl, pr - pl + 1);
         continue;
       }
     }
     have = false;
     bool needed = true;
     while (pr - pl > SMALL && pr - pl + 1 > WAVE_N) {
-      const int pi = partition<false>(A, sh, mk, pl, pr);
+      const int pi = partition<false, NT>(A, sh, mk, fmx, pl, pr PROF_PASS);
       --cd;
       const Split s = split_ranges(pl, pr, pi);
       if (s.ql < K && s.ql <= s.qr) {
@@ -333,7 +427,7 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
       if (wav == 0) {
         int wsp = sp;
         while (pr - pl > SMALL) {
-          const int pi = partition<true>(A, sh, mk, pl, pr);
+          const int pi = partition<true, NT>(A, sh, mk, fmx, pl, pr PROF_PASS);
           --cd;
           const Split s = split_ranges(pl, pr, pi);
           if (s.ql < K && s.ql <= s.qr) {
@@ -343,7 +437,7 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
           if (s.cl < K && s.cl <= s.cr) { pl = s.cl; pr = s.cr; }
           else { needed = false; break; }
         }
-        if (needed && pr > pl) insertion(A, pl, pr);
+        { PROF_DECL; if (needed && pr > pl) insertion(A, fmx, pl, pr); PROF(8); }
         if (lane == 0) sh->sp = wsp;
       }
       __syncthreads();
@@ -353,74 +447,109 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
   __syncthreads();
 }
 
-// order key of half(raw / rowmax): the half bit pattern (values in [0, 1]); NaN sorts last like numpy's half less-than
-__device__ __forceinline__ uint32_t norm_key(hbits raw, float fmx) {
-  const hbits q = f2h(h2f(raw) / fmx);
-  if (h_isnan(q)) return KEY_NAN;
-  return q > 0x3ffeu ? 0x3ffeu : (uint32_t)q;
-}
-
-template <bool LDS>
+// LDS: Ctl | L[wcap] R[wcap] (u64) | P[wcap] (u32) | entries.  Entry of column j lives at word `first + j`, where
+// `first` = misalignment of the row start in D (in halves, 0..7): every 16-byte load of D then maps to two aligned 16-byte
+// stores of entries (conflict-free), whatever the row's alignment.
+template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void topk_introsort_kernel(const hbits* __restrict__ D, const unsigned* __restrict__ rowmax, int N, int nrows,
-                                                            int K, int wcap, uint32_t* __restrict__ arena, int32_t* __restrict__ rank) {
+                                                            int K, int wcap, uint32_t* __restrict__ arena, size_t arena_stride,
+                                                            int32_t* __restrict__ rank) {
   extern __shared__ __align__(16) unsigned char smem[];
   Ctl* sh = reinterpret_cast<Ctl*>(smem);
   Masks mk;
   mk.L = reinterpret_cast<uint64_t*>(smem + ((sizeof(Ctl) + 15) & ~(size_t)15));
   mk.R = mk.L + wcap;
-  mk.P = mk.R + wcap;
-  uint32_t* ent = reinterpret_cast<uint32_t*>(mk.P + wcap);
+  mk.P = reinterpret_cast<uint32_t*>(mk.R + wcap);
+  uint32_t* ent = mk.P + wcap;            // wcap is a multiple of 4: 16-byte aligned
   const int tid = (int)threadIdx.x;
   for (int row = (int)blockIdx.x; row < nrows; row += (int)gridDim.x) {
+#ifdef SSG_INTRO_PROF
+    ProfAcc pacc_;
+#pragma unroll
+    for (int i_ = 0; i_ < 16; i_++) pacc_.a[i_] = 0;
+#endif
+    PROF_DECL;
     const float fmx = h2f((hbits)rowmax[row]);
-    // ---- the row as packed (key, column) entries
+    // ---- the row as packed (raw half, column) entries
     const int64_t total = (int64_t)nrows * N;
     const int64_t base = (int64_t)row * N;
     const int64_t al = base & ~(int64_t)7;
     const int first = (int)(base - al);
     const int nch = (first + N + 7) >> 3;
-    uint32_t* dst = LDS ? ent : arena + (size_t)blockIdx.x * (size_t)N;
-    for (int c = tid; c < nch; c += NT) {
-      const int64_t off = al + (int64_t)c * 8;
-      unsigned w[4] = {0, 0, 0, 0};
-      if (off + 8 <= total) {
-        const uint4 x = *reinterpret_cast<const uint4*>(D + off);
-        w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
-      } else {
+    uint32_t* dst = LDS ? ent : arena + (size_t)blockIdx.x * arena_stride;
+    for (int c0 = 0; c0 < nch; c0 += 2 * NT) {      // two 16-byte loads in flight per thread
+      uint4 x[2];
 #pragma unroll
-        for (int e = 0; e < 8; e++)
-          if (off + e < total) w[e >> 1] |= (unsigned)D[off + e] << ((e & 1) * 16);
+      for (int u = 0; u < 2; u++) {
+        const int c = c0 + u * NT + tid;
+        const int64_t off = al + (int64_t)c * 8;
+        x[u] = make_uint4(0, 0, 0, 0);
+        if (c < nch) {
+          if (off + 8 <= total) x[u] = *reinterpret_cast<const uint4*>(D + off);
+          else {
+            unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+              if (off + e < total) w[e >> 1] |= (unsigned)D[off + e] << ((e & 1) * 16);
+            x[u] = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
       }
-      const int j0 = c * 8 - first;
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int j = j0 + e;
-        if (j >= 0 && j < N) {
-          const hbits r = (hbits)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-          const uint32_t ev = (norm_key(r, fmx) << IDX_BITS) | (uint32_t)j;
-          dst[j] = ev;
+      for (int u = 0; u < 2; u++) {
+        const int c = c0 + u * NT + tid;
+        if (c < nch) {
+          const unsigned w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+          const uint32_t j0 = (uint32_t)(c * 8 - first);    // columns outside [0, N) land in the padding words around the row
+          uint32_t ev[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const uint32_t r = (w[e >> 1] >> ((e & 1) * 16)) & 0x7fffu;   // distances are non-negative: bit 15 is never set
+            ev[e] = (r << IDX_BITS) | ((j0 + (uint32_t)e) & IDX_MASK);
+          }
+          uint4* q = reinterpret_cast<uint4*>(dst + (size_t)c * 8);
+          q[0] = make_uint4(ev[0], ev[1], ev[2], ev[3]);
+          q[1] = make_uint4(ev[4], ev[5], ev[6], ev[7]);
         }
       }
     }
     __syncthreads();
+    PROF(0);
     if (LDS) {
-      LdsArena A{ent};
-      sort_prefix(A, sh, mk, N, K);
+      LdsArena A{ent + first};
+      sort_prefix<NT>(A, sh, mk, fmx, N, K PROF_PASS);
+      PROF(9);
       if (tid < K) rank[(int64_t)row * K + tid] = (int32_t)(A.get(tid) & IDX_MASK);
     } else {
-      GlobalArena A{dst};
-      sort_prefix(A, sh, mk, N, K);
+      GlobalArena A{dst + first};
+      sort_prefix<NT>(A, sh, mk, fmx, N, K PROF_PASS);
       if (tid < K) rank[(int64_t)row * K + tid] = (int32_t)(A.get(tid) & IDX_MASK);
     }
     __syncthreads();
+#ifdef SSG_INTRO_PROF
+    if (tid == 0) {
+#pragma unroll
+      for (int i_ = 0; i_ < 16; i_++) if (pacc_.a[i_]) atomicAdd(&g_prof[i_], pacc_.a[i_]);
+    }
+#endif
   }
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
-__host__ inline int mask_words(int N) { return (N + 63) / 64 + 1; }
-__host__ inline size_t lds_fixed_bytes(int N) { return ((sizeof(Ctl) + 15) & ~(size_t)15) + (size_t)mask_words(N) * 3 * sizeof(uint64_t); }
-__host__ inline bool fits_lds(int N) { return lds_fixed_bytes(N) + (size_t)N * 4 <= LDS_LIMIT; }
+__host__ inline int mask_words(int N) { return (((N + 63) / 64 + 1) + 3) & ~3; }          // padded to the flag pass's 4-word groups
+__host__ inline size_t entry_words(int N) { return (size_t)((N + 7 + 7) / 8) * 8; }         // whole 8-entry groups incl. the alignment shift
+__host__ inline size_t lds_fixed_bytes(int N) { return ((sizeof(Ctl) + 15) & ~(size_t)15) + (size_t)mask_words(N) * (2 * sizeof(uint64_t) + sizeof(uint32_t)); }
+__host__ inline bool fits_lds(int N) { return lds_fixed_bytes(N) + entry_words(N) * 4 <= LDS_LIMIT; }
 __host__ inline int arena_blocks(int nrows) { return nrows < 2048 ? nrows : 2048; }
+
+template <bool LDS, int NT>
+__host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, uint32_t* arena, hipStream_t stream) {
+  const size_t lds = lds_fixed_bytes(N) + (LDS ? entry_words(N) * 4 : 0);
+  SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_introsort_kernel<LDS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((topk_introsort_kernel<LDS, NT>), dim3(LDS ? nrows : arena_blocks(nrows)), dim3(NT), lds, stream, D, rowmax, N, nrows, K,
+                     mask_words(N), arena, entry_words(N), rank);
+  return SSG_OK;
+}
 
 }  // namespace intro
 }  // namespace ssg
@@ -429,7 +558,7 @@ using namespace ssg;
 
 extern "C" size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows) {
   if (N <= 0 || nrows <= 0) return 0;
-  return (size_t)intro::arena_blocks(nrows) * (size_t)N * sizeof(uint32_t);
+  return (size_t)intro::arena_blocks(nrows) * intro::entry_words(N) * sizeof(uint32_t);
 }
 extern "C" size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows) {
   return (N > 0 && intro::fits_lds(N)) ? 0 : ssg_topk_rank_introsort_arena_bytes(N, nrows);
@@ -438,27 +567,28 @@ extern "C" size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows) {
 extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws,
                                        size_t ws_bytes, hipStream_t stream) {
   if (N < 2 || nrows <= 0 || K <= 0 || K > 64 || K > N || N > (1 << intro::IDX_BITS)) {
-    ssg_set_error("ssg_topk_rank_introsort: need 0 < K <= min(64, N), 2 <= N <= 262144 (K=%d N=%d)", K, N);
+    ssg_set_error("ssg_topk_rank_introsort: need 0 < K <= min(64, N), 2 <= N <= 131072 (K=%d N=%d)", K, N);
     return SSG_ERR_INVALID;
   }
-  const int wcap = intro::mask_words(N);
   const bool arena = !intro::fits_lds(N) || (ws != nullptr && ws_bytes > 0 && ws_bytes >= ssg_topk_rank_introsort_arena_bytes(N, nrows));
+  static int nt = -1;
+  if (nt < 0) { const char* e_ = getenv("SSG_INTRO_NT"); nt = e_ ? atoi(e_) : 512; }
+  int rc;
   if (!arena) {
-    const size_t lds = intro::lds_fixed_bytes(N) + (size_t)N * 4;
-    SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&intro::topk_introsort_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(intro::topk_introsort_kernel<true>, dim3(nrows), dim3(intro::NT), lds, stream, D, rowmax, N, nrows, K, wcap,
-                       (uint32_t*)nullptr, rank);
+    rc = nt == 1024 ? intro::launch<true, 1024>(D, rowmax, N, nrows, K, rank, nullptr, stream)
+       : nt == 256 ? intro::launch<true, 256>(D, rowmax, N, nrows, K, rank, nullptr, stream)
+                   : intro::launch<true, 512>(D, rowmax, N, nrows, K, rank, nullptr, stream);
   } else {
     const size_t need = ssg_topk_rank_introsort_arena_bytes(N, nrows);
     if (ws == nullptr || ws_bytes < need) {
       ssg_set_error("ssg_topk_rank_introsort: workspace of %zu bytes needed for N=%d (got %zu)", need, N, ws_bytes);
       return SSG_ERR_INVALID;
     }
-    const size_t lds = intro::lds_fixed_bytes(N);
-    SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&intro::topk_introsort_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(intro::topk_introsort_kernel<false>, dim3(intro::arena_blocks(nrows)), dim3(intro::NT), lds, stream, D, rowmax, N,
-                       nrows, K, wcap, (uint32_t*)ws, rank);
+    rc = nt == 1024 ? intro::launch<false, 1024>(D, rowmax, N, nrows, K, rank, (uint32_t*)ws, stream)
+       : nt == 256 ? intro::launch<false, 256>(D, rowmax, N, nrows, K, rank, (uint32_t*)ws, stream)
+                   : intro::launch<false, 512>(D, rowmax, N, nrows, K, rank, (uint32_t*)ws, stream);
   }
+  if (rc) return rc;
   SSG_LAUNCH_CHECK("topk_introsort_kernel");
   return SSG_OK;
 }

@@ -51,13 +51,5 @@ def bits(a):
     return a.view(np.uint16) if a.dtype == np.float16 else a
 
 
-def clustered(N, d, seed, per_id=16, intra=0.5):
-    """Track-G synthetic embeddings, same generator as tools/make_golden.py."""
-    rng = np.random.default_rng(seed)
-    P = max(1, N // per_id)
-    c = rng.standard_normal((P, d)); c /= np.linalg.norm(c, axis=1, keepdims=True)
-    sigma = np.sqrt(intra / 2.0 / d)
-    ids = np.arange(N) % P
-    x = c[ids] + sigma * rng.standard_normal((N, d))
-    x /= np.linalg.norm(x, axis=1, keepdims=True)
-    return x.astype(np.float32)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from synth import clustered, hard_clustered  # noqa: E402,F401  (Track-G synthetic embeddings; same generator as tools/make_golden.py)
