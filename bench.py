@@ -38,17 +38,6 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec
 FLOP_PER_IMAGE = 10.68e9      # 2 forwards x 2 x 2.669 GMAC
 
 
-def clustered(N, d, seed, per_id=16, intra=0.5, device="cpu"):
-    """Track-G embeddings: N/16 unit-norm identity centres + isotropic noise, renormalised."""
-    g = torch.Generator().manual_seed(seed)
-    P = max(1, N // per_id)
-    c = torch.randn(P, d, generator=g, dtype=torch.float64); c /= c.norm(dim=1, keepdim=True)
-    sigma = (intra / 2.0 / d) ** 0.5
-    x = c[torch.arange(N) % P] + sigma * torch.randn(N, d, generator=g, dtype=torch.float64)
-    x /= x.norm(dim=1, keepdim=True)
-    return x.float().to(device)
-
-
 class KernelTimer:
     """HIP-event timing of individual C-ABI launches on the stream they are launched on."""
 
@@ -58,8 +47,8 @@ class KernelTimer:
 
     def __getattr__(self, k):
         fn = getattr(self.L, k)
-        if not self.on or not self.sample or not k.startswith("ssg_") or k in ("ssg_last_error", "ssg_krecip_row_capacity", "ssg_double_to_half_bits",
-                                                            "ssg_eps_mean_workspace_bytes", "ssg_dbscan_cc_workspace_bytes", "ssg_version"):
+        if not self.on or not self.sample or not k.startswith("ssg_") or k.endswith("_bytes") or k in (
+                "ssg_last_error", "ssg_krecip_row_capacity", "ssg_double_to_half_bits", "ssg_version"):
             return fn
 
         def timed(*a):
@@ -74,18 +63,20 @@ class KernelTimer:
         return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.ev.items()}
 
 
-def cpu_baseline(args):
-    """Oracle ("port" of the reference algorithm, oracle/ssg_oracle.c + oracle/embed_oracle.py) on this box's host
-    cores, bounded sample.  The thread count is probed (8-image / N=1000 warm-ups): on the GPU boxes the full
-    `sched_getaffinity` count oversubscribes badly (torch conv: 0.4 img/s with 256 threads, 21 img/s with 32)."""
+def cpu_baseline(args, src, tgt, gpu_labels, gpu_eps):
+    """Oracle ("port" of the reference algorithm, oracle/ssg_oracle.c + oracle/embed_oracle.py) on this box's host cores.
+    The grouping leg is MEASURED at the bench size on the bench's own embeddings (and its labels are compared with the
+    GPU's); the embedding leg on a bounded sample of images.  The thread counts are probed (8-image / N=1000 warm-ups):
+    on the GPU boxes the full `sched_getaffinity` count oversubscribes badly (torch conv: 0.4 img/s with 256 threads,
+    21 img/s with 32)."""
     from oracle import ssg_oracle as ora, embed_oracle
     import ssg_amd
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cand = sorted({c for c in (8, 16, 32, 64) if c <= avail} | ({avail} if avail <= 64 else set()))
+    cand = sorted({c for c in (8, 16, 32, 64, 128) if c <= avail} | ({avail} if avail <= 128 else set()))
     sd = ssg_amd.synthetic_state_dict(seed=1)
     imgs = torch.randn(args.cpu_images, 3, 256, 128, generator=torch.Generator().manual_seed(1))
     best_t, best_r = cand[0], 0.0
-    for c in cand:                                   # embed probe: 8 images after a 2-image warm-up
+    for c in [c for c in cand if c <= 64]:           # embed probe: 8 images after a 2-image warm-up
         torch.set_num_threads(c)
         embed_oracle.embed_with_flip(sd, imgs[:2], 1)
         t0 = time.time(); embed_oracle.embed_with_flip(sd, imgs[:8], 1); r = 8 / (time.time() - t0)
@@ -93,31 +84,37 @@ def cpu_baseline(args):
             best_t, best_r = c, r
     torch.set_num_threads(best_t)
     t0 = time.time(); embed_oracle.embed_with_flip(sd, imgs, 1); t_embed = time.time() - t0
-    n = args.cpu_n
-    tgt = clustered(n, 2048, 1).numpy(); src = clustered(n, 2048, 2, intra=0.7).numpy()
     best_o, best_s = cand[0], float("inf")
     for c in cand:                                   # grouping probe: N = 1000
         ora.set_num_threads(c)
-        t0 = time.time(); ora.re_ranking(src[:1000], tgt[:1000], k1=20, k2=6, lambda_value=0.3); dt = time.time() - t0
+        t0 = time.time(); ora.re_ranking(src[:1000], tgt[:1000], k1=20, k2=6, lambda_value=args.lambda_value); dt = time.time() - t0
         if dt < best_s:
             best_o, best_s = c, dt
     ora.set_num_threads(best_o)
+    n = min(args.cpu_n, tgt.shape[0]) if args.cpu_n > 0 else tgt.shape[0]
+    ns = src.shape[0] if n == tgt.shape[0] else min(n, src.shape[0])
     t0 = time.time()
-    _, final = ora.re_ranking(src, tgt, k1=20, k2=6, lambda_value=0.3)
+    _, final = ora.re_ranking(src[:ns], tgt[:n], k1=20, k2=6, lambda_value=args.lambda_value)
     t_rr = time.time() - t0
     t0 = time.time()
-    eps, _, _ = ora.eps_rule(final, 1.6e-3); ora.dbscan(final, eps, 4)
+    eps, _, _ = ora.eps_rule(final, args.rho); lab = ora.dbscan(final, eps, 4)
     t_cl = time.time() - t0
+    del final
     img_s = args.cpu_images / t_embed
-    # extrapolation of the grouping leg to the bench size with the N*(N+Ns)*d cost model
-    scale = (args.N * (args.N + args.Ns)) / float(n * (n + n))
+    full = n == args.N and ns == args.Ns
+    scale = 1.0 if full else (args.N * (args.N + args.Ns)) / float(n * (n + ns))      # N*(N+Ns)*d cost model only when a smaller N was asked for
     est_iter = (args.N + args.Ns) / img_s + (t_rr + t_cl) * scale
-    return {"value": round((args.N + args.Ns) / est_iter, 3), "unit": "images/s", "cores": max(best_t, best_o), "kind": "port",
-            "sample": "embed: %d images 256x128 incl. flip, torch fp32 on %d threads (best of %r; %.2f img/s measured); grouping: oracle "
-                      "re_ranking+eps+DBSCAN at N=Ns=%d d=2048 on %d OpenMP threads (best of %r; %.2f s measured), extrapolated to N=%d,Ns=%d by "
-                      "N*(N+Ns); %d cores visible" % (args.cpu_images, best_t, cand, img_s, n, best_o, cand, t_rr + t_cl, args.N, args.Ns, avail),
-            "embed_images_per_s": round(img_s, 3), "rerank_dbscan_s_measured": round(t_rr + t_cl, 3), "rerank_dbscan_N": n,
-            "threads_embed": best_t, "threads_grouping": best_o, "cores_visible": avail}
+    out = {"value": round((args.N + args.Ns) / est_iter, 3), "unit": "images/s", "cores": max(best_t, best_o), "kind": "port",
+           "sample": "embed: %d images 256x128 incl. flip, torch fp32 on %d threads (best of %r; %.2f img/s measured); grouping: oracle "
+                     "re_ranking+eps+DBSCAN MEASURED at N=%d Ns=%d d=2048 on %d OpenMP threads (best of %r): %.2f s%s; %d cores visible"
+                     % (args.cpu_images, best_t, [c for c in cand if c <= 64], img_s, n, ns, best_o, cand, t_rr + t_cl,
+                        "" if full else " (extrapolated to N=%d,Ns=%d by N*(N+Ns))" % (args.N, args.Ns), avail),
+           "embed_images_per_s": round(img_s, 3), "rerank_s_measured": round(t_rr, 3), "eps_dbscan_s_measured": round(t_cl, 3),
+           "rerank_dbscan_s_measured": round(t_rr + t_cl, 3), "rerank_dbscan_N": n, "rerank_dbscan_Ns": ns, "grouping_extrapolated": not full,
+           "threads_embed": best_t, "threads_grouping": best_o, "cores_visible": avail}
+    if full:
+        out["labels_equal_gpu"] = bool(np.array_equal(lab, gpu_labels)) and float(eps) == float(gpu_eps)
+    return out
 
 
 def main():
@@ -131,8 +128,12 @@ def main():
     ap.add_argument("--lambda_value", type=float, default=0.3)
     ap.add_argument("--rho", type=float, default=1.6e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=64)
-    ap.add_argument("--cpu-n", type=int, default=3000)
+    ap.add_argument("--cpu-images", type=int, default=256)
+    ap.add_argument("--cpu-n", type=int, default=0, help="grouping size of the CPU baseline (0 = the bench size, measured)")
+    ap.add_argument("--track-g", choices=("hard", "separable"), default="hard",
+                    help="embeddings of the timed grouping leg: 'hard' (tools/synth.hard_clustered: noise, border points, unequal identity "
+                         "sizes) or 'separable' (SURVEY 8d: 16 per identity, trivially separable); the other one is timed once, untimed-region")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (f32 embed, stable rank mode, other track)")
     args = ap.parse_args()
 
     import ssg_amd
@@ -147,15 +148,19 @@ def main():
     _lib._lib = timer
 
     # ---- inputs resident in HBM before the timed region
-    model = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1).cuda(local).eval()
+    model = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1, pretrained=False).cuda(local).eval()
     precision = model.precision
     t_lo, t_hi = sdist.shard_bounds(args.N, rank, world)
     s_lo, s_hi = sdist.shard_bounds(args.Ns, rank, world)
     g = torch.Generator(device=dev).manual_seed(1 + rank)
     tgt_imgs = torch.randn(t_hi - t_lo, 3, 256, 128, generator=g, device=dev)
     src_imgs = torch.randn(s_hi - s_lo, 3, 256, 128, generator=g, device=dev)
-    tgt_emb = clustered(args.N, 2048, 1, device=dev)
-    src_emb = clustered(args.Ns, 2048, 2, intra=0.7, device=dev)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import synth
+    gens = {"hard": synth.hard_clustered, "separable": synth.clustered}
+    emb_np = {k: (g(args.Ns, 2048, 2, intra=0.7), g(args.N, 2048, 1)) for k, g in gens.items() if k == args.track_g or not args.no_extras}
+    src_emb = torch.from_numpy(emb_np[args.track_g][0]).to(dev)
+    tgt_emb = torch.from_numpy(emb_np[args.track_g][1]).to(dev)
     row0, row1 = sdist.shard_bounds(args.N, rank, world)      # ragged row blocks (N need not divide by the number of GPUs)
     nrows = row1 - row0
 
@@ -212,6 +217,46 @@ def main():
     t_cluster = sum(e[2].elapsed_time(e[3]) for e in legs) / args.steps
     tot = timer.totals()
 
+    # ---- untimed extras (rank 0, single GPU): what the headline configuration costs relative to its alternatives
+    extras = {}
+    if world == 1 and not args.no_extras:
+        def timed_ms(fn, reps=2):
+            fn(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3 / reps
+        # (a) initial ranking: the reference's introsort tie order (default) vs the canonical stable order
+        D, rowmax, _ = rerank._original_distance(_lib.lib(), tgt_emb, 0, args.N, float(tgt_emb.abs().max()), _lib.stream())
+        t_intro = timed_ms(lambda: rerank.initial_rank(D, rowmax, args.N, args.N, 21, "introsort"))
+        t_stable = timed_ms(lambda: rerank.initial_rank(D, rowmax, args.N, args.N, 21, "stable"))
+        del D, rowmax
+        t_rr_stable = timed_ms(lambda: rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False,
+                                                                 rank_mode="stable"))
+        extras["rank_mode"] = {"default": "introsort (np.argsort default kind replayed on the device: bit parity with the unmodified reference)",
+                               "introsort_kernel_ms": round(t_intro, 3), "stable_kernel_ms": round(t_stable, 3),
+                               "rerank_ms_with_stable_order": round(t_rr_stable, 3)}
+        # (b) the embedding without the split-half trick: every product on the fp32 matrix cores
+        m32 = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1, pretrained=False, precision="f32").cuda(local).eval()
+        n32 = min(4 * args.batch, tgt_imgs.shape[0])
+        t32 = timed_ms(lambda: [m32.embed_with_flip(tgt_imgs[i:i + args.batch]) for i in range(0, n32, args.batch)], reps=1)
+        extras["embed_precision_f32"] = {"images_per_s": round(n32 / (t32 * 1e-3), 1), "images": n32,
+                                         "what": "same embedding with precision='f32' (v_mfma_f32_32x32x2 for every product), timed on %d images" % n32}
+        del m32
+        # (c) the grouping leg on the other synthetic track
+        other = "separable" if args.track_g == "hard" else "hard"
+        so, to = (torch.from_numpy(a).to(dev) for a in emb_np[other])
+        def grouping_other():
+            ho = rerank.re_ranking_device(so, to, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False)
+            e_, _, _ = cluster.eps_rule(ho, args.rho)
+            return e_, cluster.DBSCAN(eps=e_, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(ho)
+        t_other = timed_ms(grouping_other, reps=2)
+        e_o, l_o = grouping_other()
+        extras["grouping_other_track"] = {"track": other, "rerank_dbscan_ms": round(t_other, 3), "clusters": int(l_o.max() + 1),
+                                          "noise": int((l_o < 0).sum()), "eps": e_o}
+        del so, to
+
     if rank != 0:
         return
     n_img = args.N + args.Ns
@@ -249,7 +294,10 @@ def main():
         roof["vs_fp32_mfma_peak"] = round(conv_tf / PEAK_FP32_MFMA_TF, 3)
     nn2 = 2.0 * nrows * args.N   # bytes of one half row block
     hbm = []
-    for k, byt, what in (("ssg_topk_rank", nn2, "reads D (2*N^2 B)"), ("ssg_jaccard_rows", nn2, "writes J' (2*N^2 B)"),
+    for k, byt, what in (("ssg_topk_rank", nn2, "reads D (2*N^2 B); canonical (value, column) order, opt-in rank_mode='stable'"),
+                         ("ssg_topk_rank_introsort", nn2, "reads D (2*N^2 B); replays numpy's unstable introsort argsort per row (reference tie order, "
+                          "default): VALU/latency-bound emulation of a sequential algorithm, listed against the same bytes"),
+                         ("ssg_jaccard_rows", nn2, "writes J' (2*N^2 B)"),
                          ("ssg_eps_hist", nn2 / 2, "reads upper triangle of J' (N^2 B) per level"),
                          ("ssg_eps_compact", nn2 / 2, "reads upper triangle of J' (N^2 B)"),
                          ("ssg_region_query", nn2, "reads J' (2*N^2 B)")):
@@ -283,7 +331,7 @@ def main():
         hbm.append({"kernel": "ssg_source_rowmin_filtered", "bound": "mfma", "what": "source term by filter-and-refine: split-half fp16-MFMA bound pass (2*N*Ns*d flop, 3 products each) + fp64 "
                     "re-evaluation of candidate granules; time covers both; peak = fp16 MFMA / 3", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
                     "peak": round(PEAK_FP16_MFMA_TF / 3.0, 1), "unit": "TFLOP/s", "frac": round(tf / (PEAK_FP16_MFMA_TF / 3.0), 4)})
-    hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
+    hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
                                     "ssg_eps_compact", "ssg_sort_u64", "ssg_eps_mean", "ssg_region_query", "ssg_dbscan_cc") if k in tot) / args.steps
     k5_12 = 8.0 * nrows * args.N / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else float("nan")
     out = {
@@ -293,7 +341,9 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": ("f32 (embed: split-half operands hi+lo on fp16 MFMA, fp32 accumulate, 6e-8 max error vs the fp32 reference features)" if split else
                                                      "f32 (embed, fp32 MFMA)") + " / exact int64 via int8 MFMA digits + f64 + f16 (distance, re-rank: half semantics, bit-exact)",
         "data": "synthetic: N(0,1) 256x128 images + seeded Kaiming ResNet-50 weights for the embed leg; clustered unit-norm 2048-d embeddings "
-                "(16 per identity) for the grouping leg (random-init backbone features are degenerate: reid/rerank.py:40 NaN path)",
+                "for the grouping leg (track '%s', tools/synth.py: %s) -- random-init backbone features are degenerate: reid/rerank.py:40 NaN path"
+                % (args.track_g, "identity sizes 1..24, unequal spreads, 30%% confusable centres -> noise, border points, merged clusters"
+                   if args.track_g == "hard" else "16 per identity, trivially separable (SURVEY.md 8d)"),
         "config": {"workload": "BASELINE configs[1]+[2]: N=%d target + Ns=%d source images -> ResNet-50 2048-d embed (orig+flip) -> "
                                "k-reciprocal re-rank (k1=20,k2=6,lambda=%.1f) -> eps rule (rho=%.1e) -> DBSCAN(min_samples=4), 1 feature split"
                                % (args.N, args.Ns, args.lambda_value, args.rho),
@@ -301,13 +351,19 @@ def main():
         "embed_images_per_s": round(n_img / (t_embed * 1e-3), 1), "embed_ms": round(t_embed, 2),
         "rerank_dbscan_s_per_iter": round((t_rerank + t_cluster) * 1e-3, 5), "rerank_ms": round(t_rerank, 3), "eps_dbscan_ms": round(t_cluster, 3),
         "labels": {"clusters": int(labels.max() + 1), "noise": int((labels < 0).sum()), "eps": eps},
+        "rank_mode": rerank.default_rank_mode(),
         "roofline": roof, "roofline_kernels": hbm,
         "roofline_k5_k12": {"bound": "hbm", "achieved": round(k5_12, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k5_12 / PEAK_HBM_GBS, 4),
-                            "algorithmic": "8*N^2 bytes per split over all K5..K12 kernel time (SURVEY.md 8d)", "kernel_ms": round(hbm_ms, 3)},
+                            "algorithmic": "8*N^2 bytes per split over all K5..K12 kernel time (SURVEY.md 8d); K5 = the introsort replay "
+                                           "unless rank_mode is 'stable'", "kernel_ms": round(hbm_ms, 3)},
     }
+    out.update(extras)
+    if "rank_mode" in extras and "ssg_topk_rank_introsort" in tot:
+        alt_ms = hbm_ms - tot["ssg_topk_rank_introsort"][1] / args.steps + extras["rank_mode"]["stable_kernel_ms"]
+        out["roofline_k5_k12"]["frac_with_stable_order"] = round(8.0 * nrows * args.N / (alt_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
     if not args.no_cpu_baseline and world == 1:
         _lib._lib = timer.L
-        out["cpu_baseline"] = cpu_baseline(args)
+        out["cpu_baseline"] = cpu_baseline(args, emb_np[args.track_g][0], emb_np[args.track_g][1], labels, eps)
     print(json.dumps(out))
 
 
