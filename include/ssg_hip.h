@@ -236,6 +236,19 @@ int ssg_rerank_init_jaccard(const float* D, const float* rowmax, const int32_t* 
                             int nq, float lambda_value, int32_t* colcnt, int64_t* colptr, int32_t* inv_row, float* inv_val, float* out,
                             ssg_stream_t stream);
 
+/* ---- input transform of the extraction loaders (selftraining.py:43-47 applied by reid/utils/data/preprocessor.py:22-30):
+ * Resize((H,W)) [= PIL.Image.resize((W,H), BILINEAR) on 8-bit RGB] + ToTensor + Normalize for a batch of equally sized decoded
+ * images.  src [B,h,w,3] uint8, tmp [B,h,W,3] uint8 scratch, out [B,3,H,W] float32.  (xmin, xcnt, xk[W,xksize]) and
+ * (ymin, ycnt, yk[H,yksize]) are Pillow's per-output-pixel windows of 22-bit fixed-point triangle coefficients
+ * (libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc; ssg_amd/preprocessor.py computes them), device arrays;
+ * mean3_host / std3_host are HOST pointers to 3 floats.  Bit-exact with Pillow 12.2. */
+int ssg_preprocess_u8(const uint8_t* src, int B, int h, int w, int H, int W, const int32_t* xmin, const int32_t* xcnt, const int32_t* xk,
+                      int xksize, const int32_t* ymin, const int32_t* ycnt, const int32_t* yk, int yksize, const float* mean3_host,
+                      const float* std3_host, uint8_t* tmp, float* out, ssg_stream_t stream);
+/* x = sqrt(max(x, lo)) in place: with ssg_pairwise_sqdist_f32 the pairwise block of the fine-tune phase's TripletLoss
+ * (reid/loss/triplet.py:28-31: dist = (|x|^2 + |x|^2' - 2 x x').clamp(min=1e-12).sqrt()) */
+int ssg_clamp_sqrt_f32(float* x, int64_t n, float lo, ssg_stream_t stream);
+
 /* ---- device self-tests used by the parity suite ----------------------------------------- */
 int ssg_selftest_half_table(int which, uint16_t* out65536, ssg_stream_t stream);
 int ssg_selftest_half_binop(int which, const uint16_t* a, const uint16_t* b, int n, uint16_t* out, ssg_stream_t stream);

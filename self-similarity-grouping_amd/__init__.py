@@ -30,6 +30,12 @@ def __getattr__(name):   # lazy: torch import only when the compute surface is t
     if name in ("cmc", "mean_ap", "evaluate_all", "Evaluator"):
         from . import ranking
         return getattr(ranking, name)
+    if name in ("Preprocessor", "GpuBatchLoader", "preprocess_batch"):
+        from . import preprocessor
+        return getattr(preprocessor, name)
+    if name == "triplet_pairwise_dist":
+        from . import triplet
+        return triplet.pairwise_dist
     if name in ("create", "ResNet", "synthetic_state_dict"):
         from . import resnet
         return getattr(resnet, name)

@@ -102,3 +102,74 @@ def test_extract_cnn_feature_and_fliplr(golden):
         assert cat.shape == (4, len(out) * 2048)
         with pytest.raises(NotImplementedError):
             evaluators.extract_cnn_feature(m, imgs, False, modules=["layer4"])
+
+
+# ------------------------------------------------------------------ 8f-4: input transform + TripletLoss pairwise block
+def test_preprocess_oracle_matches_pil_golden(golden):
+    """oracle/preprocess_oracle.py (restatement of Pillow's bilinear resampling + ToTensor + Normalize) against PIL's own
+    outputs stored in tests/golden/preprocess.npz; the host-side coefficient tables of the product are the same integers."""
+    from oracle import preprocess_oracle as po
+    from ssg_amd import preprocessor
+    g = golden("preprocess.npz")
+    for name in ("market", "duke", "up", "same", "split384"):
+        H, W = (int(v) for v in g["size_" + name])
+        for img, res in zip(g["in_" + name], g["resized_" + name]):
+            assert np.array_equal(po.resize_bilinear_u8(img, H, W), res)
+        x = po.to_tensor_normalize(g["resized_" + name][0])
+        assert x.dtype == np.float32 and x.shape == (3, H, W)
+        assert np.array_equal(x[1, 5, 7], (np.float32(g["resized_" + name][0][5, 7, 1]) / np.float32(255) - np.float32(0.456)) / np.float32(0.224))
+        for n_in, n_out in ((g["in_" + name].shape[2], W), (g["in_" + name].shape[1], H)):
+            a = po.bilinear_coeffs(n_in, n_out); b = preprocessor.bilinear_coeffs(n_in, n_out)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.gpu
+def test_gpu_preprocess_bit_exact_with_pil(golden, tmp_path):
+    """ssg_preprocess_u8 == Resize((H,W)) + ToTensor + Normalize of the reference loaders (selftraining.py:43-47), bit for bit,
+    on PIL's own outputs; then the loader surface on real files (decode on the CPU like preprocessor.py:28, transform on the GPU)."""
+    from PIL import Image
+    from oracle import preprocess_oracle as po
+    from ssg_amd import preprocessor
+    g = golden("preprocess.npz")
+    expect = {}
+    for name in ("market", "duke", "up", "same", "split384"):
+        H, W = (int(v) for v in g["size_" + name])
+        expect[name] = np.stack([po.to_tensor_normalize(r) for r in g["resized_" + name]])     # ToTensor + Normalize of PIL's own resize
+        got = preprocessor.preprocess_batch(g["in_" + name], H, W).cpu().numpy()
+        assert got.shape == expect[name].shape and got.dtype == np.float32
+        assert np.array_equal(got, expect[name]), name
+    # files of two different sizes through the DataLoader replacement, batch of 4, dataset order kept
+    ds = []
+    for i, name in enumerate(["market", "duke", "market", "duke", "market"]):
+        fn = "img%d.png" % i
+        Image.fromarray(g["in_" + name][i % g["in_" + name].shape[0]]).save(str(tmp_path / fn))
+        ds.append((fn, i + 10, i % 3))
+    loader = preprocessor.GpuBatchLoader(ds, root=str(tmp_path), height=256, width=128, batch_size=4)
+    batches = list(loader)
+    assert len(loader) == 2 and [len(b[1]) for b in batches] == [4, 1]
+    imgs = torch.cat([b[0] for b in batches]).cpu().numpy()
+    assert [f for b in batches for f in b[1]] == [d[0] for d in ds] and [p for b in batches for p in b[2]] == [d[1] for d in ds]
+    for i, name in enumerate(["market", "duke", "market", "duke", "market"]):
+        assert np.array_equal(imgs[i], expect[name][i % g["in_" + name].shape[0]]), i
+    item = preprocessor.Preprocessor(ds, root=str(tmp_path))[1]
+    assert item[0].dtype == np.uint8 and item[0].shape == (210, 77, 3) and item[1:] == ("img1.png", 11, 1)
+
+
+@pytest.mark.gpu
+def test_triplet_pairwise_block_vs_torch():
+    """reid/loss/triplet.py:28-31 (pairwise distance of a training batch) on the fp32-MFMA Gram kernel; float32 tolerance
+    2e-5 relative to the largest distance (GEMM accumulation order), the clamp floor reproduced exactly on the diagonal."""
+    from ssg_amd import triplet
+    g = torch.Generator().manual_seed(5)
+    for n, d in ((128, 2048), (96, 512), (50, 100)):
+        x = torch.randn(n, d, generator=g)
+        x[3] = x[1]
+        dist = torch.pow(x, 2).sum(dim=1, keepdim=True).expand(n, n)
+        dist = dist + dist.t()
+        dist = dist.addmm(x, x.t(), beta=1, alpha=-2)
+        ref = dist.clamp(min=1e-12).sqrt()
+        got = triplet.pairwise_dist(x).cpu()
+        assert got.shape == (n, n)
+        off = ~torch.eye(n, dtype=torch.bool); off[1, 3] = off[3, 1] = False
+        assert (got[off] - ref[off]).abs().max() < 2e-5 * ref.max()
+        assert float(got.min()) >= 1e-6 - 1e-12          # sqrt(1e-12): the clamp floor, never NaN

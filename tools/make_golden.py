@@ -350,10 +350,43 @@ def variant_fixtures(mod):
     return ok
 
 
+def preprocess_fixture():
+    """tests/golden/preprocess.npz: decoded-image inputs and what the reference's extraction transform makes of them
+    (selftraining.py:43-47 via reid/utils/data/preprocessor.py:22-30).  The resize is run with PIL itself (what
+    torchvision's Resize calls for a PIL image); torchvision is absent here, so ToTensor / Normalize are their published
+    float32 formulas.  Also pins oracle/preprocess_oracle.py against PIL on many random shapes."""
+    from PIL import Image
+    from oracle import preprocess_oracle as po
+    rng = np.random.default_rng(77)
+    ok = True
+    for t in range(200):
+        h = int(rng.integers(4, 320)); w = int(rng.integers(4, 220))
+        H, W = [(256, 128), (384, 128), (64, 32), (h, w), (300, 310), (h, 128), (256, w)][t % 7]
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((W, H), Image.BILINEAR))
+        ok = ok and np.array_equal(ref, po.resize_bilinear_u8(img, H, W))
+    print("preprocess oracle == PIL.Image.resize(BILINEAR) on 200 random shapes:", ok)
+    rec = {}
+    for name, (h, w), (H, W), B in (("market", (128, 64), (256, 128), 3), ("duke", (210, 77), (256, 128), 2), ("up", (40, 30), (256, 128), 1),
+                                    ("same", (256, 128), (256, 128), 1), ("split384", (173, 91), (384, 128), 1)):
+        imgs = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        imgs[0] = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) % 256)], axis=-1).astype(np.uint8)   # smooth ramps
+        res = np.stack([np.asarray(Image.fromarray(im).resize((W, H), Image.BILINEAR)) for im in imgs])
+        rec["in_" + name] = imgs; rec["resized_" + name] = res      # PIL's output; ToTensor/Normalize are applied by the tests (published formulas)
+        rec["size_" + name] = np.asarray([H, W])
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), **rec)
+    return ok
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if "--only-plain" in sys.argv:        # regenerate just tests/golden/rerank_plain.npz
         ok = plain_fixture()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
+    if "--only-preproc" in sys.argv:      # regenerate just tests/golden/preprocess.npz
+        ok = preprocess_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
         sys.exit(0 if ok else 1)
     if "--only-eval" in sys.argv:         # regenerate just tests/golden/eval_cases.npz
@@ -369,6 +402,7 @@ def main():
         sys.exit(0 if ok else 1)
     ok = tiefree_fixture(mod)
     ok = variant_fixtures(mod) and ok
+    ok = preprocess_fixture() and ok
 
     # ---- half exp table of this host's numpy + the exceptions vs correct rounding
     allh, npx, cr, bad = exp_quirk_inputs()
