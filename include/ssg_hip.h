@@ -174,10 +174,16 @@ int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w,
  * are h8l8 (values must stay below 65504).  flags = 0 is exactly ssg_conv2d_nhwc_f32. */
 #define SSG_CONV_IN_SPLIT 1
 #define SSG_CONV_OUT_SPLIT 2
+/* ch_scale (nullable): per-output-channel factor applied to the accumulator (after acc_scale) before the bias -- the split path
+ * pre-multiplies every weight ROW by its own power of two, so folded checkpoints whose per-channel BN scales span orders of
+ * magnitude keep all their bits.  overflow (nullable): *overflow is set to 1 when a value that does not fit the split-half
+ * output format (|v| >= 65520 or NaN) is written; the caller zeroes it, reads it after the forward and falls back to fp32. */
 int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bias, const void* res, void* out, int B, int H, int W, int Cin,
-                      int Cout, int KH, int KW, int stride, int pad, int relu, int flags, float acc_scale, ssg_stream_t stream);
+                      int Cout, int KH, int KW, int stride, int pad, int relu, int flags, float acc_scale, const float* ch_scale,
+                      int32_t* overflow, ssg_stream_t stream);
 int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const void* w, const float* bias, void* out, int B, int H, int W, int Cin,
-                            int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, ssg_stream_t stream);
+                            int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, const float* ch_scale,
+                            int32_t* overflow, ssg_stream_t stream);
 /* stem input for the split path: [B,3,H,W] NCHW fp32 -> [B,H,W] pixels of 16 bytes [4 x half hi][4 x half lo] ("h4l4",
  * 4th channel 0); ssg_conv2d_nhwc_x with Cin = 4 and SSG_CONV_IN_SPLIT takes these, with w in the same per-tap layout */
 int ssg_nchw_to_nhwc4_h4l4(const float* in, void* out, int B, int H, int W, int flip, ssg_stream_t stream);

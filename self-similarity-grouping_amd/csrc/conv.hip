@@ -50,6 +50,11 @@ __device__ __forceinline__ void split_encode4(const float4 v, uint2& hi, uint2& 
   hi = make_uint2(pack_h2(h0, h1), pack_h2(h2, h3));
   lo = make_uint2(pack_h2((_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1)), pack_h2((_Float16)(v.z - (float)h2), (_Float16)(v.w - (float)h3)));
 }
+// any of the four hi halves infinite or NaN (the value did not fit the split-half format)
+__device__ __forceinline__ bool split_hi_nonfinite(const uint2 hi) {
+  const unsigned a = hi.x & 0x7fff7fffu, b = hi.y & 0x7fff7fffu;
+  return (a & 0xffffu) >= 0x7c00u || (a >> 16) >= 0x7c00u || (b & 0xffffu) >= 0x7c00u || (b >> 16) >= 0x7c00u;
+}
 __device__ __forceinline__ float4 split_decode4(const uint2 hi, const uint2 lo) {
   return make_float4(unpack_lo(hi.x) + unpack_lo(lo.x), unpack_hi(hi.x) + unpack_hi(lo.x), unpack_lo(hi.y) + unpack_lo(lo.y), unpack_hi(hi.y) + unpack_hi(lo.y));
 }
@@ -70,6 +75,11 @@ struct ConvParams {
   // split-half format (see "split-half activations" below): which tensors are encoded, and the factor
   // that undoes the operand scaling (weights / features are pre-scaled by a power of two)
   int out_split, res_split; float acc_scale;
+  // per-output-channel factor applied to the accumulator before the bias (nullptr = none): the split-half path pre-scales
+  // every weight ROW by its own power of two (folded checkpoints have per-channel BN scales spanning orders of magnitude)
+  const float* cscale = nullptr;
+  // set to 1 when a value that does not fit the split-half output format (|v| >= 65520 or NaN) is encoded (nullptr = no check)
+  int* overflow = nullptr;
 };
 
 constexpr int CLD32 = 36;   // LDS row pitch in floats for BK=32 (BK=16 uses 20): pitch/4 odd -> conflict-free b128
@@ -404,6 +414,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
     const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
     const int col = tn * BN + wn * WN + chunk * 4;
     const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
+    const float4 cs = p.cscale ? *reinterpret_cast<const float4*>(p.cscale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
 #pragma unroll
     for (int i = 0; i < MT; i++) {
       const int mbase = tm * BM + wm * WM + i * 32;
@@ -425,7 +436,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
       for (int it = 0; it < ITS; it++) {
         const int m = mbase + it * RPI + prow;
         float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + chunk * 4);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        v.x = v.x * cs.x + bias.x; v.y = v.y * cs.y + bias.y; v.z = v.z * cs.z + bias.z; v.w = v.w * cs.w + bias.w;
         if (resp) {
           float4 r4 = rr[it];
           if (p.res_split) {
@@ -441,6 +452,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
         if (p.out_split) {
           uint2 hp, lp;
           split_encode4(v, hp, lp);
+          if (p.overflow && split_hi_nonfinite(hp)) *p.overflow = 1;
           const uint2 send = odd ? hp : lp;
           const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 1, 64), (unsigned)__shfl_xor((int)send.y, 1, 64));
           const uint4 st = odd ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
@@ -480,7 +492,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
       for (int q = 0; q < 4; q++) {
         const int col = tn * BN + wn * WN + j * 32 + 8 * q + 4 * h;
         const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
-        float4 v = make_float4(acc[i][j][4 * q] + bias.x, acc[i][j][4 * q + 1] + bias.y, acc[i][j][4 * q + 2] + bias.z, acc[i][j][4 * q + 3] + bias.w);
+        const float4 cs = p.cscale ? *reinterpret_cast<const float4*>(p.cscale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 v = make_float4(acc[i][j][4 * q] * cs.x + bias.x, acc[i][j][4 * q + 1] * cs.y + bias.y, acc[i][j][4 * q + 2] * cs.z + bias.z,
+                               acc[i][j][4 * q + 3] * cs.w + bias.w);
         if (p.epi == 2) {       // cosine form 2 - 2<x,y> (reid/rerank.py:182)
           v = make_float4(2.f - 2.f * acc[i][j][4 * q], 2.f - 2.f * acc[i][j][4 * q + 1], 2.f - 2.f * acc[i][j][4 * q + 2], 2.f - 2.f * acc[i][j][4 * q + 3]);
         } else if (p.epi == 1) {
@@ -499,6 +513,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
           // four: half-wave 0 ends up storing the 16 hi bytes, half-wave 1 the 16 lo bytes.
           uint2 hp, lp;
           split_encode4(v, hp, lp);
+          if (p.overflow && split_hi_nonfinite(hp)) *p.overflow = 1;
           const uint2 send = h ? hp : lp;
           const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 32, 64), (unsigned)__shfl_xor((int)send.y, 32, 64));
           const uint4 st = h ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
@@ -683,6 +698,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
     for (int j = 0; j < NT; j++) {
       const int col = tn * BN + wn * WN + j * 32 + chunk * 4;
       const float4 bias = *reinterpret_cast<const float4*>(p.bias + col);
+      const float4 cs = p.cscale ? *reinterpret_cast<const float4*>(p.cscale + col) : make_float4(1.f, 1.f, 1.f, 1.f);
       float4 rr[ITS];
       if (resp) {
 #pragma unroll
@@ -699,7 +715,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
       for (int it = 0; it < ITS; it++) {
         const int m = mbase + it * RPI + prow;
         float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + chunk * 4);
-        v.x += bias.x; v.y += bias.y; v.z += bias.z; v.w += bias.w;
+        v.x = v.x * cs.x + bias.x; v.y = v.y * cs.y + bias.y; v.z = v.z * cs.z + bias.z; v.w = v.w * cs.w + bias.w;
         if (resp) {
           float4 r4 = rr[it];
           if (p.res_split) {
@@ -714,6 +730,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
         if (p.out_split) {
           uint2 hp, lp;
           split_encode4(v, hp, lp);
+          if (p.overflow && split_hi_nonfinite(hp)) *p.overflow = 1;
           const uint2 send = odd ? hp : lp;
           const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 1, 64), (unsigned)__shfl_xor((int)send.y, 1, 64));
           const uint4 stv = odd ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
@@ -958,8 +975,10 @@ static bool conv_prefers_bn64(const ConvParams& p, bool split) {
 // 1/acc_scale, a power of two), the GEMM runs on the fp16 matrix cores (3 products per term, fp32 accumulate);
 // SSG_CONV_OUT_SPLIT (2) = out (and res) are written / read in h8l8.  flags = 0 is the plain fp32 path.
 extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bias, const void* res, void* out, int B, int H, int W,
-                                 int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int flags, float acc_scale, hipStream_t stream) {
+                                 int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int flags, float acc_scale, const float* ch_scale,
+                                 int32_t* overflow, hipStream_t stream) {
   ConvParams p;
+  p.cscale = ch_scale; p.overflow = overflow;
   p.in = (const float*)in; p.w = (const float*)w; p.bias = bias; p.res = (const float*)res; p.out = (float*)out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.relu = relu;
   p.OH = (H + 2 * pad - KH) / stride + 1; p.OW = (W + 2 * pad - KW) / stride + 1;
@@ -988,7 +1007,7 @@ extern "C" int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bia
 
 extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float* bias, const float* res, float* out, int B, int H, int W,
                                    int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, hipStream_t stream) {
-  return ssg_conv2d_nhwc_x(in, w, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, 0, 1.f, stream);
+  return ssg_conv2d_nhwc_x(in, w, bias, res, out, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, 0, 1.f, nullptr, nullptr, stream);
 }
 
 // Fused bottleneck tail with a downsample branch (reid/models/base.py:75-90 when
@@ -996,8 +1015,10 @@ extern "C" int ssg_conv2d_nhwc_f32(const float* in, const float* w, const float*
 // as ONE implicit GEMM over the concatenated K = Cin + Cin2: w [Cout][Cin + Cin2], bias = b3 + b_ds.
 // in [B,H,W,Cin] (1x1, stride 1); in2 [B,H2,W2,Cin2] sampled at (oh*stride2, ow*stride2).
 extern "C" int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const void* w, const float* bias, void* out, int B, int H, int W,
-                                       int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, hipStream_t stream) {
+                                       int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, const float* ch_scale,
+                                       int32_t* overflow, hipStream_t stream) {
   ConvParams p;
+  p.cscale = ch_scale; p.overflow = overflow;
   p.in = (const float*)in; p.w = (const float*)w; p.bias = bias; p.res = nullptr; p.out = (float*)out;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = relu;
   p.OH = H; p.OW = W;
@@ -1019,7 +1040,7 @@ extern "C" int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const vo
 
 extern "C" int ssg_conv1x1_dual_nhwc_f32(const float* in, const float* in2, const float* w, const float* bias, float* out, int B, int H, int W,
                                          int Cin, int H2, int W2, int Cin2, int stride2, int Cout, int relu, hipStream_t stream) {
-  return ssg_conv1x1_dual_nhwc_x(in, in2, w, bias, out, B, H, W, Cin, H2, W2, Cin2, stride2, Cout, relu, 0, 1.f, stream);
+  return ssg_conv1x1_dual_nhwc_x(in, in2, w, bias, out, B, H, W, Cin, H2, W2, Cin2, stride2, Cout, relu, 0, 1.f, nullptr, nullptr, stream);
 }
 
 namespace ssg {

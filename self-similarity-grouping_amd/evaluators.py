@@ -66,11 +66,10 @@ def extract_features(model, data_loader, print_freq=20, for_eval=True, metric=No
     feats, fnames, pids = extract_embeddings(m, data_loader, for_eval=for_eval, print_freq=print_freq)
     features, labels = OrderedDict(), OrderedDict()
     cpu = feats.cpu()
-    if getattr(m, "precision", "f32") == "split" and not bool(torch.isfinite(cpu).all()):
-        # the split-half activations are half pairs: |activation| >= 65504 overflows to inf (never silently wrong)
+    if not bool(torch.isfinite(cpu).all()):
+        # (the split-half path detects half-range overflow itself and recomputes such batches in fp32: resnet.ResNet._overflowed)
         from ._lib import SSGError
-        raise SSGError("non-finite embeddings: an activation left the half range of the split-half path; "
-                       "build the model with precision='f32' (SSG_EMBED_PRECISION=f32) for these weights")
+        raise SSGError("non-finite embeddings (NaN/inf in the input images or the weights?)")
     if cpu.dim() == 3:       # split model, for_eval=False: list of S+1 vectors per image (evaluators.py:37-39)
         for idx, (fname, pid) in enumerate(zip(fnames, pids)):
             features[fname] = [cpu[s, idx] for s in range(cpu.shape[0])]

@@ -84,7 +84,7 @@ def synthetic_state_dict(seed=1, depth=50, num_features=2048, randomize_bn=True)
 
 
 class _FoldedConv:
-    __slots__ = ("w", "bias", "cin", "cout", "k", "stride", "pad", "split", "acc_scale")
+    __slots__ = ("w", "bias", "cin", "cout", "k", "stride", "pad", "split", "acc_scale", "cscale")
 
 
 _IN_SPLIT, _OUT_SPLIT = 1, 2      # include/ssg_hip.h SSG_CONV_IN_SPLIT / SSG_CONV_OUT_SPLIT
@@ -115,6 +115,16 @@ def _weight_scale(w):
     return 256.0 if mx == 0 else float(min(256.0, 2.0 ** math.floor(math.log2(16384.0 / mx))))
 
 
+def _row_scales(w):
+    """per-output-channel powers of two s_c with max|w_c| * s_c in (8192, 16384]: every weight row uses the full half range
+    (hi AND lo parts normal) whatever the folded BatchNorm scale of its channel is -- real checkpoints have per-channel
+    scales spanning more than 10^3, which one per-layer scale pushes into the half subnormals.  Exponent clamped to +-40."""
+    mx = w.abs().amax(dim=1).double()
+    e = torch.floor(torch.log2(16384.0 / mx.clamp_min(1e-300))).clamp(-40, 40)
+    e = torch.where(mx > 0, e, torch.zeros_like(e))
+    return torch.pow(2.0, e).float()
+
+
 def pack_weight_khwc(w):
     """[Cout, KH, KW, Cin] (Cin % 32 == 0) -> [Cout, K] in the kernels' reduction order
     k = ((c // 32) * KH*KW + r*KW + s) * 32 + c % 32  (include/ssg_hip.h, ssg_conv2d_nhwc_f32)."""
@@ -142,11 +152,12 @@ def _fold(sd, conv_name, bn_name, stride, pad, device, split=False):
         w = pack_weight_khwc(w)
     f = _FoldedConv()
     w = w.float().contiguous()
-    f.split, f.acc_scale = bool(split), 1.0
+    f.split, f.acc_scale, f.cscale = bool(split), 1.0, None
     if split:
-        sc = _weight_scale(w)
-        w = _h4l4(w * sc) if cin == 4 else _h8l8(w * sc)
-        f.acc_scale = 1.0 / sc
+        sc = _row_scales(w)                          # exact: powers of two
+        w = w * sc.view(-1, 1)
+        w = _h4l4(w) if cin == 4 else _h8l8(w)
+        f.cscale = (1.0 / sc).contiguous().to(device)
     f.w = w.to(device); f.bias = bias.float().contiguous().to(device)
     f.cin, f.cout, f.k, f.stride, f.pad = cin, cout, k, stride, pad
     return f
@@ -256,8 +267,8 @@ class ResNet:
                 ds = _fold(sd, p + ".downsample.0", p + ".downsample.1", blk["stride"], 0, dev)
                 wcat = torch.cat([c3.w, ds.w], dim=1)
                 if sp:
-                    sc = _weight_scale(wcat)
-                    ds.w = _h8l8((wcat * sc).cpu()).to(dev); ds.acc_scale = 1.0 / sc; ds.split = True
+                    sc = _row_scales(wcat.cpu())
+                    ds.w = _h8l8((wcat.cpu() * sc.view(-1, 1))).to(dev); ds.acc_scale = 1.0; ds.cscale = (1.0 / sc).contiguous().to(dev); ds.split = True
                 else:
                     ds.w = wcat.contiguous()
                 ds.bias = (c3.bias + ds.bias).contiguous()
@@ -273,24 +284,24 @@ class ResNet:
 
     # ---- forward
     @staticmethod
-    def _conv(L, x, f, res=None, relu=True, out_split=False):
+    def _conv(L, x, f, res=None, relu=True, out_split=False, ovf=None):
         B, H, W, _ = x.shape
         OH = (H + 2 * f.pad - f.k) // f.stride + 1; OW = (W + 2 * f.pad - f.k) // f.stride + 1
         out = torch.empty((B, OH, OW, f.cout), dtype=torch.float32, device=x.device)
         flags = (_IN_SPLIT if f.split else 0) | (_OUT_SPLIT if out_split else 0)
         check(L.ssg_conv2d_nhwc_x(ptr(x), ptr(f.w), ptr(f.bias), ptr(res), ptr(out), B, H, W, f.cin, f.cout, f.k, f.k, f.stride, f.pad,
-                                  1 if relu else 0, flags, f.acc_scale, stream()), "ssg_conv2d_nhwc_x")
+                                  1 if relu else 0, flags, f.acc_scale, ptr(getattr(f, "cscale", None)), ptr(ovf), stream()), "ssg_conv2d_nhwc_x")
         return out
 
     @staticmethod
-    def _conv_dual(L, o, x, c3, ds, out_split=False):
+    def _conv_dual(L, o, x, c3, ds, out_split=False, ovf=None):
         """relu(conv3(o) + downsample(x)) as one GEMM (ssg_conv1x1_dual_nhwc_x)."""
         B, H, W, _ = o.shape
         _, H2, W2, _ = x.shape
         out = torch.empty((B, H, W, c3.cout), dtype=torch.float32, device=o.device)
         flags = (_IN_SPLIT if ds.split else 0) | (_OUT_SPLIT if out_split else 0)
         check(L.ssg_conv1x1_dual_nhwc_x(ptr(o), ptr(x), ptr(ds.w), ptr(ds.bias), ptr(out), B, H, W, c3.cin, H2, W2, ds.cin, ds.stride, c3.cout, 1,
-                                        flags, ds.acc_scale, stream()), "ssg_conv1x1_dual_nhwc_x")
+                                        flags, ds.acc_scale, ptr(getattr(ds, "cscale", None)), ptr(ovf), stream()), "ssg_conv1x1_dual_nhwc_x")
         return out
 
     def _fmap(self, x, flip=False):
@@ -308,7 +319,8 @@ class ResNet:
             check(L.ssg_nchw_to_nhwc4_h4l4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4_h4l4")
         else:
             check(L.ssg_nchw_to_nhwc4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4")
-        y = self._conv(L, x4, net["stem"], out_split=sp)
+        ovf = self._overflow_flag() if sp else None
+        y = self._conv(L, x4, net["stem"], out_split=sp, ovf=ovf)
         _, H2, W2, _ = y.shape
         p = torch.empty((B, (H2 + 1) // 2, (W2 + 1) // 2, 64), dtype=torch.float32, device=self.device)
         if sp:
@@ -317,19 +329,49 @@ class ResNet:
             check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
         y = p
         for blk in net["blocks"]:
-            o = self._conv(L, y, blk["c1"], out_split=sp)
-            o = self._conv(L, o, blk["c2"], out_split=sp)
+            o = self._conv(L, y, blk["c1"], out_split=sp, ovf=ovf)
+            o = self._conv(L, o, blk["c2"], out_split=sp, ovf=ovf)
             if blk["ds"] is not None:
-                y = self._conv_dual(L, o, y, blk["c3"], blk["ds"], out_split=sp)
+                y = self._conv_dual(L, o, y, blk["c3"], blk["ds"], out_split=sp, ovf=ovf)
             else:
-                y = self._conv(L, o, blk["c3"], res=y, relu=True, out_split=sp)
+                y = self._conv(L, o, blk["c3"], res=y, relu=True, out_split=sp, ovf=ovf)
         return y, sp
+
+    # ---- split-half range guard: activations are half pairs, |v| >= 65520 cannot be stored.  Every convolution raises a
+    # device flag when it has to encode such a value; the public entry points read it once per call and recompute the batch
+    # on the fp32 matrix cores (same weights) instead of returning inf / NaN / silently clipped features.
+    def _overflow_flag(self):
+        if getattr(self, "_ovf", None) is None or self._ovf.device != self.device:
+            self._ovf = torch.zeros(1, dtype=torch.int32, device=self.device)
+        return self._ovf
+
+    def _overflowed(self):
+        """read and clear the flag (one host round trip)"""
+        if self.precision != "split" or getattr(self, "_ovf", None) is None:
+            return False
+        hit = bool(int(self._ovf.item()))
+        if hit:
+            self._ovf.zero_()
+        return hit
+
+    def _f32_twin(self):
+        if getattr(self, "_twin", None) is None:
+            import warnings
+            warnings.warn("ssg_amd ResNet: an activation left the half range of the split-half path (|v| >= 65520); this batch and any "
+                          "later one that overflows is recomputed with precision='f32'", stacklevel=3)
+            t = ResNet.__new__(ResNet)
+            t.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_folded", "_ovf", "_twin")})
+            t.precision, t._folded, t._ovf, t._twin = "f32", None, None, None
+            self._twin = t
+        return self._twin
 
     def feature_map(self, x, flip=False):
         """images [B,3,H,W] float32 (NCHW, any device) -> layer4 map [B,H/32,W/32,2048] NHWC fp32
         (resnet.py:87-92: every base module up to, not including, avgpool)."""
         y, sp = self._fmap(x, flip)
         if sp:
+            if self._overflowed():
+                return self._f32_twin().feature_map(x, flip)
             out = torch.empty_like(y)
             check(_lib.lib().ssg_h8l8_decode(ptr(y), ptr(out), y.numel(), 1.0, stream()), "ssg_h8l8_decode")
             return out
@@ -366,6 +408,8 @@ class ResNet:
 
     def __call__(self, x, for_eval=False):
         sets = self.pooled(*self._fmap(x))
+        if self._overflowed():
+            return self._f32_twin()(x, for_eval)
         x2 = self._x2(sets[0])
         if self.num_split > 1:
             x1 = [sets[s] for s in range(sets.shape[0])]
@@ -383,6 +427,8 @@ class ResNet:
         x = x.to(self.device, torch.float32)          # one H2D copy for both orientations
         a = self.pooled(*self._fmap(x, flip=False))
         b = self.pooled(*self._fmap(x, flip=True))
+        if self._overflowed():
+            return self._f32_twin().embed_with_flip(x, for_eval)
         nsets, B, C = a.shape
         if for_eval or nsets == 1:
             a = a.permute(1, 0, 2).reshape(B, nsets * C).contiguous(); b = b.permute(1, 0, 2).reshape(B, nsets * C).contiguous()

@@ -43,9 +43,9 @@ def test_argument_validation_without_gpu():
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     # entry points added with the split-half embedding, the int8 Gram, the evaluation step and the kNN-set variant
-    assert L.ssg_conv2d_nhwc_x(None, None, None, None, None, 2, 8, 8, 48, 64, 1, 1, 1, 0, 1, 3, 1.0, None) == -1          # Cin % 32
+    assert L.ssg_conv2d_nhwc_x(None, None, None, None, None, 2, 8, 8, 48, 64, 1, 1, 1, 0, 1, 3, 1.0, None, None, None) == -1          # Cin % 32
     assert b"unsupported shape" in L.ssg_last_error()
-    assert L.ssg_conv1x1_dual_nhwc_x(None, None, None, None, None, 2, 8, 8, 64, 4, 4, 64, 2, 96, 1, 3, 1.0, None) == -1   # Cout % 64, grid
+    assert L.ssg_conv1x1_dual_nhwc_x(None, None, None, None, None, 2, 8, 8, 64, 4, 4, 64, 2, 96, 1, 3, 1.0, None, None, None) == -1   # Cout % 64, grid
     assert L.ssg_h8l8_encode(None, None, 12, 1.0, None) == -1 and L.ssg_h8l8_decode(None, None, 0, 1.0, None) == -1       # n % 8
     assert L.ssg_gram_i8_encode(None, 4, 64, 5, None, None, None, None) == -1                                             # digits must be 3 or 4
     assert L.ssg_gram_i8_encode(None, 4, 20000, 3, None, None, None, None) == -1                                          # d > 16384 (int32 headroom)

@@ -440,11 +440,11 @@ def test_conv_split_half_vs_fp64(cfg, L, dev):
     if use_res:
         rs = torch.empty_like(res_d); check(L.ssg_h8l8_encode(ptr(res_d), ptr(rs), res_d.numel(), 1.0, stream()), "enc")
     outs = torch.empty(B, OH, OW, Cout, device=dev)
-    check(L.ssg_conv2d_nhwc_x(ptr(xs), ptr(ws), ptr(bias_d), ptr(rs), ptr(outs), B, H, W, Cin, Cout, k, k, stride, pad, int(relu), 3, 1.0 / sc, stream()), "convx")
+    check(L.ssg_conv2d_nhwc_x(ptr(xs), ptr(ws), ptr(bias_d), ptr(rs), ptr(outs), B, H, W, Cin, Cout, k, k, stride, pad, int(relu), 3, 1.0 / sc, None, None, stream()), "convx")
     dec = torch.empty_like(outs); check(L.ssg_h8l8_decode(ptr(outs), ptr(dec), outs.numel(), 1.0, stream()), "dec")
     # fp32 output of the same split GEMM (flags = IN only)
     outp = torch.empty(B, OH, OW, Cout, device=dev)
-    check(L.ssg_conv2d_nhwc_x(ptr(xs), ptr(ws), ptr(bias_d), ptr(res_d), ptr(outp), B, H, W, Cin, Cout, k, k, stride, pad, int(relu), 1, 1.0 / sc, stream()), "convx")
+    check(L.ssg_conv2d_nhwc_x(ptr(xs), ptr(ws), ptr(bias_d), ptr(res_d), ptr(outp), B, H, W, Cin, Cout, k, k, stride, pad, int(relu), 1, 1.0 / sc, None, None, stream()), "convx")
     scale = max(1.0, ref.abs().max().item())
     e32 = (out32.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
     esp = (dec.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item()
@@ -732,3 +732,71 @@ def test_rerank_plain_ties_and_chunks_vs_oracle(dev, ora):
         h = rerank_plain.re_ranking_plain_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k=k, lambda_value=lam)
         ref, _ = ora.re_ranking_plain(src, tgt, k=k, lambda_value=lam)
         assert np.array_equal(h.final_dist().cpu().numpy(), ref), (k, lam)
+
+
+# ------------------------------------------------------------------ split-half embedding on checkpoint-like weights
+def _checkpoint_like_state_dict(seed):
+    """Kaiming convolutions + BatchNorm statistics with the spread of a trained, folded checkpoint: per-channel scales
+    gamma / sqrt(var + eps) log-normal over ~3 decades (rms 1 per layer so the network neither explodes nor dies),
+    running_var log-uniform in [1e-3, 1e2], non-zero running_mean / beta."""
+    import ssg_amd
+    sd = ssg_amd.synthetic_state_dict(seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    for k in list(sd):
+        if k.endswith("running_var") and k.startswith("base."):
+            p = k[: -len("running_var")]
+            n = sd[k].numel()
+            var = torch.exp(torch.empty(n).uniform_(float(np.log(1e-3)), float(np.log(1e2)), generator=g))
+            s = torch.exp(2.3 * torch.randn(n, generator=g))
+            s = s / s.pow(2).mean().sqrt()
+            sd[p + "running_var"] = var
+            sd[p + "weight"] = s * torch.sqrt(var + 1e-5)
+            sd[p + "running_mean"] = 0.1 * torch.randn(n, generator=g)
+            sd[p + "bias"] = 0.05 * torch.randn(n, generator=g)
+    return sd
+
+
+def test_split_half_on_checkpoint_like_weights(dev):
+    """Per-output-channel weight scales: the split-half embedding stays fp32-class when the folded per-channel BN scales of
+    a layer span more than 10^3 (one per-layer power of two would push the small rows into the half subnormals)."""
+    import warnings
+    import ssg_amd
+    from oracle import embed_oracle
+    sd = _checkpoint_like_state_dict(7)
+    scales = (sd["base.layer2.0.bn2.weight"] / torch.sqrt(sd["base.layer2.0.bn2.running_var"] + 1e-5)).abs()
+    assert float(scales.max() / scales.min()) > 1e3
+    imgs = torch.randn(3, 3, 256, 128, generator=torch.Generator().manual_seed(11))
+    ref = torch.stack(embed_oracle.embed_with_flip(sd, imgs, 2))     # torch fp32 on the CPU, [3, B, 2048]
+    errs = {}
+    for precision in ("split", "f32"):
+        m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, pretrained=False, precision=precision).cuda().eval()
+        m.load_state_dict(sd, strict=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                      # no overflow fallback may be needed here
+            got = m.embed_with_flip(imgs).cpu()
+        assert got.shape == ref.shape and bool(torch.isfinite(got).all())
+        errs[precision] = float((got - ref).abs().max())
+    print("checkpoint-like weights: max |err| vs torch fp32 CPU: split %.3g, f32 %.3g" % (errs["split"], errs["f32"]))
+    assert errs["f32"] < 1e-5 and errs["split"] < 1e-5 and errs["split"] < 3.0 * errs["f32"] + 2e-7
+
+
+def test_split_half_overflow_falls_back_to_f32(dev):
+    """Activations beyond the half range (|v| >= 65520): every entry point notices (device flag raised by the encoding
+    epilogue), warns once and returns the fp32-path result instead of inf / NaN / clipped features."""
+    import ssg_amd
+    sd = ssg_amd.synthetic_state_dict(seed=1)
+    imgs = 3.0e4 * torch.randn(2, 3, 256, 128, generator=torch.Generator().manual_seed(3))      # stem outputs ~ 1e5
+    ms = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, pretrained=False, seed=1, precision="split").cuda().eval()
+    m32 = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, pretrained=False, seed=1, precision="f32").cuda().eval()
+    with pytest.warns(UserWarning, match="half range"):
+        got = ms.embed_with_flip(imgs)
+    want = m32.embed_with_flip(imgs)
+    assert bool(torch.isfinite(got).all()) and torch.equal(got, want)
+    x1, _ = ms(imgs, False); y1, _ = m32(imgs, False)
+    assert torch.equal(x1, y1)
+    assert torch.equal(ms.feature_map(imgs), m32.feature_map(imgs))
+    # in-range batches keep using the split path afterwards (flag cleared)
+    small = torch.randn(2, 3, 256, 128, generator=torch.Generator().manual_seed(4))
+    a = ms.embed_with_flip(small); b = m32.embed_with_flip(small)
+    assert not torch.equal(a, b) and float((a - b).abs().max()) < 5e-6
+    del sd

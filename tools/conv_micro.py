@@ -23,7 +23,7 @@ def run(B, H, W, Cin, Cout, k, stride, pad, res, reps=20):
         w = _h8l8(w.cpu() * 256.0).to(dev); sc = 1.0 / 256.0; flags = 3
         if res:
             rs = torch.empty_like(r); check(L.ssg_h8l8_encode(ptr(r), ptr(rs), r.numel(), 1.0, stream()), "enc"); r = rs
-    f = lambda: check(L.ssg_conv2d_nhwc_x(ptr(x), ptr(w), ptr(b), ptr(r), ptr(out), B, H, W, Cin, Cout, k, k, stride, pad, 1, flags, sc, stream()), "conv")
+    f = lambda: check(L.ssg_conv2d_nhwc_x(ptr(x), ptr(w), ptr(b), ptr(r), ptr(out), B, H, W, Cin, Cout, k, k, stride, pad, 1, flags, sc, None, None, stream()), "conv")
     f(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
