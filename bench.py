@@ -181,7 +181,7 @@ def main():
         f_tgt = sdist.gather_varlen(embed(tgt_imgs), group)
         ev[1].record()
         assert f_tgt.shape == (args.N, 2048) and f_src.shape == (args.Ns, 2048)
-        h = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False,
+        h = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
                                      row0=row0, nrows=nrows, group=group)
         ev[2].record()
         eps, cnt, top = cluster.eps_rule(h, args.rho)

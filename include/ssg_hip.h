@@ -151,6 +151,10 @@ size_t ssg_dbscan_cc_workspace_bytes(int N);
 /* cnt is the FULL [N] table, edges the concatenated edge list: labels[N] int64, -1 = noise */
 int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,
                   int64_t* labels, ssg_stream_t stream);
+/* the same with the edge count left on the device (the region query's cursor; min(*nedges_dev, cap_edges) edges are read): no host
+ * round trip between region query and labels */
+int ssg_dbscan_cc_dev(const int32_t* cnt, const int32_t* edges, const uint64_t* nedges_dev, uint64_t cap_edges, int N, int min_samples,
+                      void* ws, size_t ws_bytes, int64_t* labels, ssg_stream_t stream);
 
 /* ---- K1/K2 ResNet-50 embedding forward (reid/models/resnet.py:86-111, reid/evaluators.py:18-60) */
 /* Conv2d with eval-BatchNorm folded into (w, bias) + optional residual add + optional ReLU, NHWC

@@ -59,6 +59,7 @@ def eps_rule(X, rho):
     L = _lib.lib()
     h = as_handle(X)
     dev, st = h.device, stream()
+    h.validate()
     args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
     prefix, below, count, top = 0, 0, None, None
     key_max = None
@@ -133,26 +134,40 @@ class DBSCAN:
         eps = float(self.eps)
         cnt = torch.empty(h.nrows, dtype=torch.int32, device=dev)
         cap = max(64 * h.nrows, 1 << 16)
+        ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        labels = torch.empty(N, dtype=torch.int64, device=dev)
+        if hasattr(h, "validate"):
+            h.validate()
         while True:
             edges = torch.empty((cap, 2), dtype=torch.int32, device=dev)
             cursor = torch.zeros(1, dtype=torch.int64, device=dev)
             check(L.ssg_region_query(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, eps, ptr(cnt), ptr(edges), cap,
                                      ptr(cursor), st), "ssg_region_query")
+            if h.group is None:
+                # one GPU: components and labels follow on the stream, the edge count stays on the device; ONE read-back at
+                # the end brings labels, neighbour counts and the count (which tells whether the edge list was big enough)
+                check(L.ssg_dbscan_cc_dev(ptr(cnt), ptr(edges), ptr(cursor), cap, N, int(self.min_samples), ptr(ws), ws_bytes, ptr(labels), st),
+                      "ssg_dbscan_cc_dev")
+                host = torch.cat([cursor, labels, cnt.to(torch.int64)]).cpu().numpy()
+                ne = int(host[0])
+                if ne <= cap:
+                    self.labels_ = host[1:1 + N].copy()
+                    self.core_sample_indices_ = np.nonzero(host[1 + N:] >= int(self.min_samples))[0]
+                    break
+                cap = ne       # the cursor counted every hit: retry once with the exact size
+                continue
             ne = int(cursor.item())
             if ne <= cap:
+                edges = edges[:ne]
+                cnt_all = gather_rows(cnt, h.group, N)
+                edges = gather_varlen(edges, h.group).contiguous()
+                ne = int(edges.shape[0])
+                check(L.ssg_dbscan_cc(ptr(cnt_all), ptr(edges), ne, N, int(self.min_samples), ptr(ws), ws_bytes, ptr(labels), st), "ssg_dbscan_cc")
+                self.labels_ = labels.cpu().numpy()
+                self.core_sample_indices_ = torch.nonzero(cnt_all >= int(self.min_samples)).flatten().cpu().numpy()
                 break
-            cap = ne   # the cursor counted every hit: retry once with the exact size
-        edges = edges[:ne]
-        if h.group is not None:
-            cnt = gather_rows(cnt, h.group, N)
-            edges = gather_varlen(edges, h.group).contiguous()
-            ne = int(edges.shape[0])
-        ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        labels = torch.empty(N, dtype=torch.int64, device=dev)
-        check(L.ssg_dbscan_cc(ptr(cnt), ptr(edges), ne, N, int(self.min_samples), ptr(ws), ws_bytes, ptr(labels), st), "ssg_dbscan_cc")
-        self.labels_ = labels.cpu().numpy()
-        self.core_sample_indices_ = torch.nonzero(cnt >= int(self.min_samples)).flatten().cpu().numpy()
+            cap = ne
         self.n_features_in_ = N
         return self
 

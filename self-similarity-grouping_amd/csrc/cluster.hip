@@ -83,6 +83,48 @@ __device__ __forceinline__ void load_vals(const MatView& mv, const RowStream& rs
   }
 }
 
+// The same in two steps for the half modes, so that a streaming loop can keep several chunks' loads in flight before it
+// decodes the first one (one 1 KiB load per wave at a time leaves the pass latency-bound at ~2.3 TB/s).
+struct RawChunk { uint4 m, v; };
+template <int MODE>
+__device__ __forceinline__ RawChunk load_raw(const MatView& mv, const RowStream& rs, int c, int lane) {
+  static_assert(MODE == 0 || MODE == 1, "half matrices only");
+  RawChunk r; r.m = make_uint4(0, 0, 0, 0); r.v = make_uint4(0, 0, 0, 0);
+  const int64_t off = rs.al + (int64_t)c * 512 + lane * 8;
+  const hbits* M = reinterpret_cast<const hbits*>(mv.M);
+  if (c < rs.nchunks) {
+    if (off + 8 <= rs.total) r.m = *reinterpret_cast<const uint4*>(M + off);
+    else if (off < rs.total) {
+      unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int e = 0; e < 8; e++) if (off + e < rs.total) w[e >> 1] |= (unsigned)M[off + e] << ((e & 1) * 16);
+      r.m = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    if (MODE == 0) {
+      const int j0 = rs.col0(c, lane);
+      if (j0 >= 0 && j0 + 8 <= mv.N && (j0 & 7) == 0) r.v = *reinterpret_cast<const uint4*>(mv.v + j0);
+      else {
+        unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; e++) { const int k = j0 + e; if (k >= 0 && k < mv.N) w[e >> 1] |= (unsigned)mv.v[k] << ((e & 1) * 16); }
+        r.v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+  }
+  return r;
+}
+template <int MODE>
+__device__ __forceinline__ void decode_raw(const MatView& mv, const RawChunk& r, hbits vi, double d[8]) {
+  const unsigned w[4] = {r.m.x, r.m.y, r.m.z, r.m.w}, vw[4] = {r.v.x, r.v.y, r.v.z, r.v.w};
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const hbits raw = (hbits)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    if (MODE == 0) d[e] = final_dist_value(raw, vi, (hbits)((vw[e >> 1] >> ((e & 1) * 16)) & 0xffffu), mv.lambda_value);
+    else d[e] = (double)h2f(raw);
+  }
+}
+constexpr int PIPE = 4;     // chunks (4 KiB of the matrix per wave) in flight in the streaming passes
+
 // ------------------------------------------------------------------ K10 histogram level
 // hist[bin] += #{ (i<k), d != 0, (key >> (shift+width)) == prefix }, bin = (key>>shift) & mask.
 // hist[4096] += number of non-zero strict-upper entries (only when count_nonzero != 0).
@@ -103,34 +145,46 @@ __global__ __launch_bounds__(256) void eps_hist_kernel(MatView mv, unsigned long
     RowStream rs(il, mv.N, mv.nrows);
     // strict upper triangle: columns k > gi only -> skip leading chunks
     int c0 = (rs.first + gi + 1) / 512;
-    for (int c = c0; c < rs.nchunks; c++) {
-      double dv[8];
-      load_vals<MODE>(mv, rs, c, lane, gi, dv);
-      const int j0 = rs.col0(c, lane);
-      int pbin = -1; unsigned pcnt = 0;
+    const hbits vi = MODE == 0 ? mv.v[gi] : (hbits)0;
+    for (int cb = c0; cb < rs.nchunks; cb += PIPE) {
+      RawChunk raw[PIPE];
+      if (MODE != 2) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int k = j0 + e;
-        if (k > gi && k < mv.N) {
-          const double d = dv[e];
-          if (d != 0.0) {
-            nz++;
-            const unsigned long long key = (unsigned long long)__double_as_longlong(d);
-            if (anyprefix || (key >> (shift + width)) == prefix) {
-              const int bin = (int)((key >> shift) & mask);
-              if (bin == pbin) pcnt++;
-              else { if (pcnt) atomicAdd(&lh[pbin], pcnt); pbin = bin; pcnt = 1; }
+        for (int u = 0; u < PIPE; u++) raw[u] = load_raw<MODE == 2 ? 1 : MODE>(mv, rs, cb + u, lane);
+      }
+#pragma unroll
+      for (int u = 0; u < PIPE; u++) {
+        const int c = cb + u;
+        if (c >= rs.nchunks) break;
+        double dv[8];
+        if (MODE == 2) load_vals<MODE>(mv, rs, c, lane, gi, dv);
+        else decode_raw<MODE == 2 ? 1 : MODE>(mv, raw[u], vi, dv);
+        const int j0 = rs.col0(c, lane);
+        int pbin = -1; unsigned pcnt = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int k = j0 + e;
+          if (k > gi && k < mv.N) {
+            const double d = dv[e];
+            if (d != 0.0) {
+              nz++;
+              const unsigned long long key = (unsigned long long)__double_as_longlong(d);
+              if (anyprefix || (key >> (shift + width)) == prefix) {
+                const int bin = (int)((key >> shift) & mask);
+                if (bin == pbin) pcnt++;
+                else { if (pcnt) atomicAdd(&lh[pbin], pcnt); pbin = bin; pcnt = 1; }
+              }
             }
           }
         }
+        // the bulk of a row falls into one bin: one add per wave instead of 64
+        const int fb = __shfl(pbin, 0, 64);
+        if (__all(pbin == fb)) {
+          unsigned tot = pcnt;
+          for (int sh = 1; sh < 64; sh <<= 1) tot += (unsigned)__shfl_xor((int)tot, sh, 64);
+          if (lane == 0 && fb >= 0 && tot) atomicAdd(&lh[fb], tot);
+        } else if (pcnt) atomicAdd(&lh[pbin], pcnt);
       }
-      // the bulk of a row falls into one bin: one add per wave instead of 64
-      const int fb = __shfl(pbin, 0, 64);
-      if (__all(pbin == fb)) {
-        unsigned tot = pcnt;
-        for (int sh = 1; sh < 64; sh <<= 1) tot += (unsigned)__shfl_xor((int)tot, sh, 64);
-        if (lane == 0 && fb >= 0 && tot) atomicAdd(&lh[fb], tot);
-      } else if (pcnt) atomicAdd(&lh[pbin], pcnt);
     }
   }
   for (int sh = 1; sh < 64; sh <<= 1) nz += (unsigned long long)__shfl_xor((long long)nz, sh, 64);
@@ -170,30 +224,42 @@ __global__ __launch_bounds__(256) void eps_compact_kernel(MatView mv, unsigned l
     const int gi = mv.row0 + il;
     RowStream rs(il, mv.N, mv.nrows);
     int c0 = (rs.first + gi + 1) / 512;
-    for (int c = c0; c < rs.nchunks; c++) {
-      double dv[8];
-      load_vals<MODE>(mv, rs, c, lane, gi, dv);
-      const int j0 = rs.col0(c, lane);
-      unsigned long long keys[8]; int n = 0;
+    const hbits vi = MODE == 0 ? mv.v[gi] : (hbits)0;
+    for (int cb = c0; cb < rs.nchunks; cb += PIPE) {
+      RawChunk raw[PIPE];
+      if (MODE != 2) {
 #pragma unroll
-      for (int e = 0; e < 8; e++) {
-        const int k = j0 + e;
-        keys[e] = ~0ULL;
-        if (k > gi && k < mv.N) {
-          const double d = dv[e];
-          const unsigned long long key = (unsigned long long)__double_as_longlong(d);
-          if (d != 0.0 && key <= key_max) { keys[e] = key; n++; }
-        }
+        for (int u = 0; u < PIPE; u++) raw[u] = load_raw<MODE == 2 ? 1 : MODE>(mv, rs, cb + u, lane);
       }
-      if (!__any(n > 0)) continue;
-      int incl = n;
-      for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
-      const int tot = __shfl(incl, 63, 64);
-      int w = st.n + incl - n;
 #pragma unroll
-      for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) st.buf[w++] = keys[e];
-      st.n += tot;
-      if (st.n > STAGE_CAP - 512) st.flush(buf, cap, cursor, lane);
+      for (int u = 0; u < PIPE; u++) {
+        const int c = cb + u;
+        if (c >= rs.nchunks) break;
+        double dv[8];
+        if (MODE == 2) load_vals<MODE>(mv, rs, c, lane, gi, dv);
+        else decode_raw<MODE == 2 ? 1 : MODE>(mv, raw[u], vi, dv);
+        const int j0 = rs.col0(c, lane);
+        unsigned long long keys[8]; int n = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          const int k = j0 + e;
+          keys[e] = ~0ULL;
+          if (k > gi && k < mv.N) {
+            const double d = dv[e];
+            const unsigned long long key = (unsigned long long)__double_as_longlong(d);
+            if (d != 0.0 && key <= key_max) { keys[e] = key; n++; }
+          }
+        }
+        if (!__any(n > 0)) continue;
+        int incl = n;
+        for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
+        const int tot = __shfl(incl, 63, 64);
+        int w = st.n + incl - n;
+#pragma unroll
+        for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) st.buf[w++] = keys[e];
+        st.n += tot;
+        if (st.n > STAGE_CAP - 512) st.flush(buf, cap, cursor, lane);
+      }
     }
   }
   st.flush(buf, cap, cursor, lane);
@@ -357,22 +423,33 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
       const _Float16 vi16 = __builtin_bit_cast(_Float16, mv.v[gi]);
       const h2 vi2 = {vi16, vi16};
       const int nfull = mv.N / 512;
-      for (int c = 0; c < nfull; c++) {
-        const int j0 = c * 512 + lane * 8;
-        const uint4 xj = *reinterpret_cast<const uint4*>(M + j0);
-        const uint4 xv = *reinterpret_cast<const uint4*>(mv.v + j0);
-        const unsigned wj[4] = {xj.x, xj.y, xj.z, xj.w}, wv[4] = {xv.x, xv.y, xv.z, xv.w};
-        unsigned flags = 0;   // bit e set: element e may be <= eps
+      for (int cb = 0; cb < nfull; cb += PIPE) {
+        uint4 xjs[PIPE], xvs[PIPE];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const h2 s2 = __builtin_bit_cast(h2, wv[q]) + vi2;
-          const h2 d2 = s2 * lam2 + __builtin_bit_cast(h2, wj[q]);
-          const unsigned sg = __builtin_bit_cast(unsigned, (h2)(d2 - thr2));     // sign bit set <=> d16 < thr (NaNs never hit)
-          flags |= ((sg >> 15) & 1u) << (2 * q) | ((sg >> 31) & 1u) << (2 * q + 1);
+        for (int u = 0; u < PIPE; u++) {
+          const int j0 = min(cb + u, nfull - 1) * 512 + lane * 8;       // clamped: the loads of a short tail are repeated, never out of range
+          xjs[u] = *reinterpret_cast<const uint4*>(M + j0);
+          xvs[u] = *reinterpret_cast<const uint4*>(mv.v + j0);
         }
-        if (!__any(flags != 0)) continue;                         // the common case: one branch per KiB
-        const unsigned hitmask = rq_decide(mv, flags, xj, xv, gi, eps);
-        if (__any(hitmask != 0)) rowcnt += rq_append(st, hitmask, j0, gi, eout, cap, cursor);
+#pragma unroll
+        for (int u = 0; u < PIPE; u++) {
+          const int c = cb + u;
+          if (c >= nfull) break;
+          const int j0 = c * 512 + lane * 8;
+          const uint4 xj = xjs[u], xv = xvs[u];
+          const unsigned wj[4] = {xj.x, xj.y, xj.z, xj.w}, wv[4] = {xv.x, xv.y, xv.z, xv.w};
+          unsigned flags = 0;   // bit e set: element e may be <= eps
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const h2 s2 = __builtin_bit_cast(h2, wv[q]) + vi2;
+            const h2 d2 = s2 * lam2 + __builtin_bit_cast(h2, wj[q]);
+            const unsigned sg = __builtin_bit_cast(unsigned, (h2)(d2 - thr2));     // sign bit set <=> d16 < thr (NaNs never hit)
+            flags |= ((sg >> 15) & 1u) << (2 * q) | ((sg >> 31) & 1u) << (2 * q + 1);
+          }
+          if (!__any(flags != 0)) continue;                         // the common case: one branch per KiB
+          const unsigned hitmask = rq_decide(mv, flags, xj, xv, gi, eps);
+          if (__any(hitmask != 0)) rowcnt += rq_append(st, hitmask, j0, gi, eout, cap, cursor);
+        }
       }
       if (nfull * 512 < mv.N) {
         const unsigned hitmask = rq_generic_chunk<MODE>(mv, rs, nfull, lane, gi, eps);
@@ -412,8 +489,10 @@ __global__ void cc_init_kernel(const int32_t* __restrict__ cnt, int N, int min_s
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < N) { parent[i] = i; lab[i] = 0x7fffffff; (void)cnt; (void)min_samples; }
 }
-__global__ void cc_union_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const int32_t* __restrict__ cnt, int min_samples,
+__global__ void cc_union_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const unsigned long long* __restrict__ ne_dev,
+                                const int32_t* __restrict__ cnt, int min_samples,
                                 int* __restrict__ parent) {
+  if (ne_dev) { const unsigned long long d = *ne_dev; ne = d < ne ? d : ne; }     // device-side count (region query cursor), capped by the capacity
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (unsigned long long)gridDim.x * blockDim.x) {
     const int i = edges[2 * e], k = edges[2 * e + 1];
     if (i != k && cnt[i] >= min_samples && cnt[k] >= min_samples) uf_union(parent, i, k);
@@ -432,8 +511,10 @@ __global__ void cc_label_core_kernel(const int32_t* __restrict__ cnt, int N, int
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < N && cnt[i] >= min_samples) lab[i] = (int)rootid[parent[i]];
 }
-__global__ void cc_border_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const int32_t* __restrict__ cnt, int min_samples,
+__global__ void cc_border_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const unsigned long long* __restrict__ ne_dev,
+                                 const int32_t* __restrict__ cnt, int min_samples,
                                  const int* __restrict__ parent, const int64_t* __restrict__ rootid, int* __restrict__ lab) {
+  if (ne_dev) { const unsigned long long d = *ne_dev; ne = d < ne ? d : ne; }
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (unsigned long long)gridDim.x * blockDim.x) {
     const int i = edges[2 * e], k = edges[2 * e + 1];
     if (cnt[i] >= min_samples && cnt[k] < min_samples) atomicMin(&lab[k], (int)rootid[parent[i]]);
@@ -583,20 +664,32 @@ extern "C" int ssg_region_query(const void* M, const uint16_t* v, int N, int row
 // workspace: parent[N] int32 | lab[N] int32 | rootflag[N] int32 | rootid[N+1] int64
 extern "C" size_t ssg_dbscan_cc_workspace_bytes(int N) { return (size_t)N * 12 + ((size_t)N + 1) * 8 + 64; }
 
-extern "C" int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,
-                             int64_t* labels, hipStream_t stream) {
+static int dbscan_cc_impl(const int32_t* cnt, const int32_t* edges, uint64_t nedges, const unsigned long long* ne_dev, int N, int min_samples, void* ws,
+                          size_t ws_bytes, int64_t* labels, hipStream_t stream) {
   if (N <= 0 || ws_bytes < ssg_dbscan_cc_workspace_bytes(N)) { ssg_set_error("ssg_dbscan_cc: workspace too small"); return SSG_ERR_INVALID; }
   int* parent = (int*)ws; int* lab = parent + N; int32_t* rootflag = lab + N;
   int64_t* rootid = (int64_t*)(((uintptr_t)(rootflag + N) + 15) & ~(uintptr_t)15);
   const int nb = (N + 255) / 256;
   const int eb = nedges ? (int)((nedges + 255) / 256 < 8192 ? (nedges + 255) / 256 : 8192) : 1;
   hipLaunchKernelGGL(cc_init_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, lab);
-  if (nedges) hipLaunchKernelGGL(cc_union_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, cnt, min_samples, parent);
+  if (nedges) hipLaunchKernelGGL(cc_union_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent);
   hipLaunchKernelGGL(cc_flatten_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootflag);
   hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, stream, rootflag, N, rootid);
   hipLaunchKernelGGL(cc_label_core_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootid, lab);
-  if (nedges) hipLaunchKernelGGL(cc_border_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, cnt, min_samples, parent, rootid, lab);
+  if (nedges) hipLaunchKernelGGL(cc_border_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent, rootid, lab);
   hipLaunchKernelGGL(cc_finalize_kernel, dim3(nb), dim3(256), 0, stream, lab, N, labels);
   SSG_LAUNCH_CHECK("dbscan_cc");
   return SSG_OK;
+}
+
+extern "C" int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,
+                             int64_t* labels, hipStream_t stream) {
+  return dbscan_cc_impl(cnt, edges, nedges, nullptr, N, min_samples, ws, ws_bytes, labels, stream);
+}
+// the same with the edge count left on the device: edges holds min(*nedges_dev, cap_edges) entries (the region query's cursor
+// and capacity), so region query -> components -> labels runs without a host round trip in between
+extern "C" int ssg_dbscan_cc_dev(const int32_t* cnt, const int32_t* edges, const uint64_t* nedges_dev, uint64_t cap_edges, int N, int min_samples,
+                                 void* ws, size_t ws_bytes, int64_t* labels, hipStream_t stream) {
+  if (!nedges_dev) { ssg_set_error("ssg_dbscan_cc_dev: null edge counter"); return SSG_ERR_INVALID; }
+  return dbscan_cc_impl(cnt, edges, cap_edges, (const unsigned long long*)nedges_dev, N, min_samples, ws, ws_bytes, labels, stream);
 }

@@ -44,9 +44,25 @@ class DistHandle:
     def device(self):
         return self.M.device
 
+    _pending = None
+
+    def validate(self):
+        """Raise what the pipeline could only detect on the device (read once, with the caller's host round trip)."""
+        if self._pending is None:
+            return self
+        vmax_h, flag_h = self._pending.tolist()
+        self._pending = None
+        if flag_h:
+            raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
+        if int(vmax_h) & 0x7FFF == 0:
+            raise ReRankNaNError("max(source_dist_vec) == 0: every target->source 1-exp(-d^2) rounds to 0 in float16; the reference "
+                                 "(reid/rerank.py:40) would return an all-NaN final_dist")
+        return self
+
     def final_dist(self):
         """float64 [nrows, N] device tensor (API materialisation, 8 bytes/entry)."""
         L = _lib.lib()
+        self.validate()
         if self.mode == 2:
             return self.M
         if self.mode == 1:
@@ -211,7 +227,7 @@ def initial_rank(D, rowmax, N, nrows, K, rank_mode=None, force_arena=False):
 
 
 def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, keep_euclid=True, row0=0, nrows=None,
-                      group=None, stages=None, rank_mode=None, memory_save=False):
+                      group=None, stages=None, rank_mode=None, memory_save=False, validate=True):
     """Fused device pipeline K3..K9 for one feature split.
 
     src [Ns,d], tgt [N,d]: float32 CUDA tensors (replicated on every rank of `group`).
@@ -282,7 +298,9 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
         capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
 
     # ---- inverted index + Jaccard rows (rerank.py:101-122)
-    total = int(q_nnz.sum().item())
+    # the inverted lists hold at most one entry per stored V_qe entry: sized by that bound instead of reading sum(q_nnz) back
+    # (one host round trip less; the bound is N * capQ entries of 6 bytes)
+    total = int(N) * int(capQ)
     colcnt = torch.empty(N, dtype=torch.int32, device=dev)
     colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
     inv_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
@@ -295,16 +313,16 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
                              om, ptr(Jp), st), "ssg_jaccard_rows")
 
-    vmax_h, flag_h = torch.cat([vmax, flag if flag is not None else torch.zeros_like(vmax)]).tolist()
-    if flag_h:
-        raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
-    if int(vmax_h) & 0x7FFF == 0:
-        raise ReRankNaNError("max(source_dist_vec) == 0: every target->source 1-exp(-d^2) rounds to 0 in float16; the reference "
-                             "(reid/rerank.py:40) would return an all-NaN final_dist")
     if stages is not None:
         stages.update(D=D, rowmax=rowmax, v=v, rank=rank, v_idx=v_idx, v_val=v_val, v_nnz=v_nnz, q_idx=q_idx, q_val=q_val, q_nnz=q_nnz,
                       colptr=colptr, inv_row=inv_row, inv_val=inv_val, Jp=Jp)
-    return DistHandle(N, 0, Jp, v=v, lambda_value=lambda_value, euclid=D if keep_euclid else None, row0=row0, nrows=nrows, group=group)
+    h = DistHandle(N, 0, Jp, v=v, lambda_value=lambda_value, euclid=D if keep_euclid else None, row0=row0, nrows=nrows, group=group)
+    # the two device-side status words (zero source vector -> the reference's NaN path; int8 digit overflow) are read with the
+    # consumer's first host round trip (`validate`: eps_rule / DBSCAN / final_dist), not with one of their own
+    h._pending = torch.cat([vmax, flag if flag is not None else torch.zeros_like(vmax)])
+    if validate:
+        h.validate()
+    return h
 
 
 def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.2, MemorySave=False, Minibatch=2000, no_rerank=False,

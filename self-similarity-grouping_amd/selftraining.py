@@ -36,7 +36,8 @@ def compute_dist(source_features, target_features, lambda_value, no_rerank, num_
             from .dist import shard_bounds
             row0, row1 = shard_bounds(t.shape[0], dist.get_rank(group), dist.get_world_size(group))   # ragged N allowed
             nrows = row1 - row0
-        h = re_ranking_device(s, t, lambda_value=lambda_value, no_rerank=no_rerank, keep_euclid=no_rerank, row0=row0, nrows=nrows, group=group)
+        h = re_ranking_device(s, t, lambda_value=lambda_value, no_rerank=no_rerank, keep_euclid=no_rerank, row0=row0, nrows=nrows, group=group,
+                              validate=materialize)     # fused path: the status words are read by generate_selflabel's first round trip
         if materialize:
             if no_rerank:
                 euclidean_dist_list.append(h.euclid.cpu().numpy()); rerank_dist_list.append(None)

@@ -50,7 +50,7 @@ def main():
     for rep in range(a.reps):
         times.clear()
         torch.cuda.synchronize(); t0 = time.time()
-        h = rerank.re_ranking_device(src, tgt, lambda_value=0.1)
+        h = rerank.re_ranking_device(src, tgt, lambda_value=0.1, validate=False)
         torch.cuda.synchronize(); t1 = time.time()
         eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
         torch.cuda.synchronize(); t2 = time.time()
