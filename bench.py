@@ -298,8 +298,9 @@ def main():
                          ("ssg_topk_rank_introsort", nn2, "reads D (2*N^2 B); replays numpy's unstable introsort argsort per row (reference tie order, "
                           "default): VALU/latency-bound emulation of a sequential algorithm, listed against the same bytes"),
                          ("ssg_jaccard_rows", nn2, "writes J' (2*N^2 B)"),
-                         ("ssg_eps_hist", nn2 / 2, "reads upper triangle of J' (N^2 B) per level"),
-                         ("ssg_eps_compact", nn2 / 2, "reads upper triangle of J' (N^2 B)"),
+                         ("ssg_eps_hist", nn2 / 2, "radix-select fallback of the eps rule: reads upper triangle of J' (N^2 B) per level"),
+                         ("ssg_eps_compact", nn2 / 2, "radix-select fallback: reads upper triangle of J' (N^2 B)"),
+                         ("ssg_eps_compact_below", nn2 / 2, "eps rule, the one full pass of the sampled-threshold path: reads upper triangle of J' (N^2 B)"),
                          ("ssg_region_query", nn2, "reads J' (2*N^2 B)")):
         if k in tot:
             n, ms = tot[k]
@@ -332,7 +333,9 @@ def main():
                     "re-evaluation of candidate granules; time covers both; peak = fp16 MFMA / 3", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
                     "peak": round(PEAK_FP16_MFMA_TF / 3.0, 1), "unit": "TFLOP/s", "frac": round(tf / (PEAK_FP16_MFMA_TF / 3.0), 4)})
     hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
-                                    "ssg_eps_compact", "ssg_sort_u64", "ssg_eps_mean", "ssg_region_query", "ssg_dbscan_cc") if k in tot) / args.steps
+                                    "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_compact_below", "ssg_fill_u64",
+                                    "ssg_sort_u64", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_dbscan_cc", "ssg_dbscan_cc_dev")
+                 if k in tot) / args.steps
     k5_12 = 8.0 * nrows * args.N / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else float("nan")
     out = {
         "metric": "images/s embed + s/iter for NxN rerank+DBSCAN, N=16k, 1/2/4/8 GPU",

@@ -136,12 +136,27 @@ int ssg_eps_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, i
 /* buf[cursor++] = key for every strict-upper non-zero key <= key_max (writes beyond cap dropped) */
 int ssg_eps_compact(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, uint64_t key_max,
                     uint64_t* buf, uint64_t cap, uint64_t* cursor, ssg_stream_t stream);
+/* Fast path of the epsilon rule: (1) float32-surrogate histogram (4096 bins over the float bit pattern, hist[4096] = sample size;
+ * hist = 4097 uint64 zeroed by the caller) of every row_stride-th local row's strict-upper non-zero elements; (2) threshold =
+ * upper edge of the bin after the one where the cumulative count reaches quantile * sample size -> thr3 = {float bits, sample
+ * size, bin}; (3) ONE pass over the block: exact float64 keys of the strict-upper non-zero elements whose surrogate is below the
+ * threshold -> buf (cursor2[0] counts them, writes beyond cap dropped), cursor2[1] += exact zeros.  The caller sorts, and accepts
+ * the result only if the top-th smallest key is below the threshold by more than the surrogate error (else: the radix select). */
+int ssg_eps_sample_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, int row_stride,
+                        uint64_t* hist, ssg_stream_t stream);
+int ssg_eps_select_threshold(const uint64_t* hist, double quantile, uint64_t* thr3, ssg_stream_t stream);
+int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
+                          const uint64_t* thr3, uint64_t* buf, uint64_t cap, uint64_t* cursor2, ssg_stream_t stream);
 int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t value, ssg_stream_t stream);
 int ssg_sort_u64(uint64_t* buf, uint64_t n_pow2, ssg_stream_t stream); /* ascending, n = 2^k >= 2048 */
 size_t ssg_eps_mean_workspace_bytes(int64_t top);
 /* out2[0] = mean of the first `top` sorted keys with numpy's pairwise summation (mode 0: f64;
  * mode 1: float32 sum of half values -> half, out2[1] = its bits) */
 int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, ssg_stream_t stream);
+/* the same in two steps: _prepare uploads the recursion tables of numpy's pairwise tree for `top` summands (blocks until the copy is
+ * done: call it while the stream is idle), _run launches the summation asynchronously.  ssg_eps_mean = prepare + run. */
+int ssg_eps_mean_prepare(int64_t top, void* ws, size_t ws_bytes, ssg_stream_t stream);
+int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, ssg_stream_t stream);
 
 /* ---- K11/K12 DBSCAN (selftraining.py:295,306; sklearn 1.7.2 DBSCAN precomputed) ---------- */
 /* cnt[il] = |{k: d(i,k) <= eps}|; edges[2e],[2e+1] = (i,k) for every hit (cursor counts all) */

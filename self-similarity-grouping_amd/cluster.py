@@ -48,6 +48,73 @@ def as_handle(X, device=None):
     raise TypeError("unsupported distance matrix type %r" % type(X))
 
 
+def _eps_finish(L, h, buf, got, n_pow2, top, st):
+    """sort the collected keys, numpy pairwise mean of the first `top` -> (eps, key[top-1] as float64)"""
+    dev = h.device
+    ws_bytes = int(L.ssg_eps_mean_workspace_bytes(top))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    out = torch.zeros(2, dtype=torch.float64, device=dev)
+    # the summation tables depend on `top` only: uploaded now, while the stream is idle (the caller has just read `top`
+    # back), so that sort -> leaves -> tree run back to back without a host wait in between
+    check(L.ssg_eps_mean_prepare(top, ptr(ws), ws_bytes, st), "ssg_eps_mean_prepare")
+    check(L.ssg_fill_u64(ptr(buf), got, n_pow2, 0xFFFFFFFFFFFFFFFF, st), "ssg_fill_u64")
+    check(L.ssg_sort_u64(ptr(buf), n_pow2, st), "ssg_sort_u64")
+    check(L.ssg_eps_mean_run(ptr(buf), top, 1 if h.mode == 1 else 0, ptr(ws), ws_bytes, ptr(out), st), "ssg_eps_mean_run")
+    res = torch.cat([out, buf[top - 1:top].view(torch.float64)]).cpu().numpy()      # one read-back: eps (+ half bits) and the top-th key
+    eps = np.uint16(int(res[1])).view(np.float16) if h.mode == 1 else float(res[0])
+    return eps, float(res[2])
+
+
+def _eps_rule_sampled(L, h, rho, st):
+    """Fast path (csrc/cluster.hip "K10, fast path"): sampled float32 threshold, ONE full pass, exactness verified a posteriori.
+    Returns (eps, count, top) or None when the verification fails (the caller then runs the radix select)."""
+    dev = h.device
+    args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
+    # strict upper triangle of this row block
+    N = h.N
+    upper_total = N * (N - 1) // 2
+    expected_top = max(int(rho * upper_total), 1)
+    stride = max(1, h.nrows // 192)
+    hist = torch.zeros(4097, dtype=torch.int64, device=dev)
+    check(L.ssg_eps_sample_hist(*args, stride, ptr(hist), st), "ssg_eps_sample_hist")
+    hist = _all_reduce(hist, h.group)                       # sharded rows: every rank selects from the same global sample
+    thr3 = torch.zeros(3, dtype=torch.int64, device=dev)
+    check(L.ssg_eps_select_threshold(ptr(hist), 1.3 * float(rho), ptr(thr3), st), "ssg_eps_select_threshold")
+    cap = max(6 * expected_top * h.nrows // N + (1 << 16), 1 << 16)
+    n_cap = max(2048, 1 << (cap - 1).bit_length())
+    buf = torch.empty(n_cap, dtype=torch.int64, device=dev)
+    cursor = torch.zeros(2, dtype=torch.int64, device=dev)
+    check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
+    got, zeros, thr_bits = torch.cat([cursor, thr3[:1]]).tolist()       # host round trip 1
+    thr = float(np.uint32(thr_bits & 0xFFFFFFFF).view(np.float32))
+    overflow = int(got > n_cap)
+    if h.group is not None:             # the accept / fall-back decision must be the same on every rank
+        tot = _all_reduce(torch.tensor([zeros, got, overflow], dtype=torch.int64, device=dev), h.group).tolist()
+        zeros_all, got_all, overflow = int(tot[0]), int(tot[1]), int(tot[2])
+    else:
+        zeros_all, got_all = int(zeros), int(got)
+    count = upper_total - zeros_all
+    top = int(np.round(rho * count))                  # np.round: half to even (selftraining.py:292)
+    if top <= 0:
+        return (np.float16(np.nan) if h.mode == 1 else float("nan")), count, top
+    if overflow or got_all < top or not np.isfinite(thr):
+        return None
+    if h.group is not None:
+        allk = gather_varlen(buf[:got], h.group)
+        got = int(allk.shape[0])
+        n_pow2 = max(2048, 1 << (got - 1).bit_length())
+        buf = torch.empty(n_pow2, dtype=torch.int64, device=dev)
+        buf[:got] = allk
+    else:
+        n_pow2 = max(2048, 1 << (max(got, 1) - 1).bit_length())
+    eps, key_top = _eps_finish(L, h, buf, got, n_pow2, top, st)          # host round trip 2
+    # every element that was NOT collected has surrogate >= thr, hence exact value >= thr - err: the `top` smallest are all
+    # among the collected keys iff the top-th of them is below that
+    if not (key_top < thr - 1e-6 * (1.0 + abs(thr))):
+        return None
+    return eps, count, top
+
+
 def eps_rule(X, rho):
     """selftraining.py:289-293 on device.
 
@@ -56,10 +123,15 @@ def eps_rule(X, rho):
     half matrix (mode 1) -> np.float16 like `tri_mat[:top].mean()` on a float16 array.
     Returns (eps, count, top_num).
     """
+    import os
     L = _lib.lib()
     h = as_handle(X)
     dev, st = h.device, stream()
     h.validate()
+    if os.environ.get("SSG_EPS_PATH", "sampled") == "sampled" and float(rho) > 0 and h.N >= 64:
+        r = _eps_rule_sampled(L, h, float(rho), st)
+        if r is not None:
+            return r
     args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
     prefix, below, count, top = 0, 0, None, None
     key_max = None
@@ -94,16 +166,8 @@ def eps_rule(X, rho):
         buf[:got] = allk
     if got != ncand:
         raise _lib.SSGError("eps_rule: compaction found %d keys, histogram promised %d" % (got, ncand))
-    check(L.ssg_fill_u64(ptr(buf), got, n_pow2, 0xFFFFFFFFFFFFFFFF, st), "ssg_fill_u64")
-    check(L.ssg_sort_u64(ptr(buf), n_pow2, st), "ssg_sort_u64")
-    ws_bytes = int(L.ssg_eps_mean_workspace_bytes(top))
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    out = torch.zeros(2, dtype=torch.float64, device=dev)
-    check(L.ssg_eps_mean(ptr(buf), top, 1 if h.mode == 1 else 0, ptr(ws), ws_bytes, ptr(out), st), "ssg_eps_mean")
-    out = out.cpu().numpy()
-    if h.mode == 1:
-        return np.uint16(int(out[1])).view(np.float16), count, top
-    return float(out[0]), count, top
+    eps, _ = _eps_finish(L, h, buf, got, n_pow2, top, st)
+    return eps, count, top
 
 
 class DBSCAN:

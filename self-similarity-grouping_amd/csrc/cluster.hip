@@ -265,6 +265,253 @@ __global__ __launch_bounds__(256) void eps_compact_kernel(MatView mv, unsigned l
   st.flush(buf, cap, cursor, lane);
 }
 
+// ------------------------------------------------------------------ K10, fast path: sampled threshold + ONE full pass
+// The radix select above costs two or three N^2 passes that each rebuild the float64 value of every element.  The fast path
+// estimates the rho-quantile from a strided sample of rows (a few MB), turns it into a float32 threshold with a safety margin,
+// and makes ONE pass over the strict upper triangle that (a) counts the exact zeros and (b) collects the exact float64 keys of
+// the elements whose float32 SURROGATE value is below the threshold.  The host then sorts the collected keys and checks that
+// the top-th smallest exact key lies below the threshold by more than the surrogate's error bound: in that case no
+// uncollected element can be among the `top` smallest and the result is exactly the reference's; otherwise (a sample that
+// underestimated the quantile) it falls back to the radix select.  Correctness never depends on the sample, only speed does.
+//
+// surrogate: float32 evaluation of the element (mode 0: jp + half(v_i+v_k)*lambda with float32 ops; modes 1/2: the value
+// rounded to float32): |surrogate - exact| <= 4e-7 * (1 + |exact|) for the values that occur (final_dist < 4).
+__device__ __forceinline__ int sur_bin(float x) {
+  // 4096 bins over the float32 bit pattern: 16 binades [2^-14, 4) x 256 mantissa steps (0.4 % per bin); monotone in x >= 0
+  const int b = (int)(__float_as_uint(x) >> 15) - 0x7100;
+  return b < 0 ? 0 : (b > 4095 ? 4095 : b);
+}
+__device__ __forceinline__ float sur_bin_upper(int b) { return __uint_as_float((unsigned)(b + 1 + 0x7100) << 15); }   // exclusive upper edge of bin b
+
+// raw half chunk -> 8 surrogate values (+ exact-zero mask for mode 0/1)
+template <int MODE>
+__device__ __forceinline__ void surrogate8(const MatView& mv, const RawChunk& r, hbits vi, float lam32, float sv[8], unsigned& zeromask) {
+  const unsigned w[4] = {r.m.x, r.m.y, r.m.z, r.m.w}, vw[4] = {r.v.x, r.v.y, r.v.z, r.v.w};
+  zeromask = 0;
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    const hbits raw = (hbits)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+    if (MODE == 0) {
+      const hbits s = h_add((hbits)((vw[e >> 1] >> ((e & 1) * 16)) & 0xffffu), vi);
+      const float p = h2f(s) * lam32;
+      sv[e] = h2f(raw) + p;
+      // exact value 0 <=> J' == +-0 and half(v_i+v_k)*lambda == 0 (all terms are finite and the sum of two non-zero terms of
+      // opposite sign is decided exactly below, on the rare candidates only)
+      if ((raw & 0x7fffu) == 0 && ((s & 0x7fffu) == 0 || mv.lambda_value == 0.0)) zeromask |= 1u << e;
+    } else {
+      sv[e] = h2f(raw);
+      if ((raw & 0x7fffu) == 0) zeromask |= 1u << e;
+    }
+  }
+}
+
+// sample histogram: local rows 0, stride, 2*stride, ...; strict upper triangle, exact zeros dropped; hist[4096] = sample size
+template <int MODE>
+__global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int stride, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int lh[4097];
+  for (int b = (int)threadIdx.x; b < 4097; b += 256) lh[b] = 0;
+  __syncthreads();
+  const int lane = lane_id();
+  const float lam32 = (float)mv.lambda_value;
+  const int nsamp = (mv.nrows + stride - 1) / stride;
+  for (int sidx = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); sidx < nsamp; sidx += (int)gridDim.x * 4) {
+    const int il = sidx * stride, gi = mv.row0 + il;
+    RowStream rs(il, mv.N, mv.nrows);
+    const hbits vi = MODE == 0 ? mv.v[gi] : (hbits)0;
+    unsigned cnt = 0;
+    for (int c = (rs.first + gi + 1) / 512; c < rs.nchunks; c++) {
+      float sv[8]; unsigned zm = 0;
+      const int j0 = rs.col0(c, lane);
+      if (MODE == 2) {
+        double dv[8];
+        load_vals<MODE>(mv, rs, c, lane, gi, dv);
+#pragma unroll
+        for (int e = 0; e < 8; e++) { sv[e] = (float)dv[e]; if (dv[e] == 0.0) zm |= 1u << e; }
+      } else {
+        const RawChunk raw = load_raw<MODE == 2 ? 1 : MODE>(mv, rs, c, lane);
+        surrogate8<MODE == 2 ? 1 : MODE>(mv, raw, vi, lam32, sv, zm);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int k = j0 + e;
+        if (k > gi && k < mv.N && !((zm >> e) & 1u)) { atomicAdd(&lh[sur_bin(sv[e])], 1u); cnt++; }
+      }
+    }
+    for (int sh = 1; sh < 64; sh <<= 1) cnt += (unsigned)__shfl_xor((int)cnt, sh, 64);
+    if (lane == 0 && cnt) atomicAdd(&lh[4096], cnt);
+  }
+  __syncthreads();
+  for (int b = (int)threadIdx.x; b < 4097; b += 256) if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+}
+
+// one workgroup: first bin whose cumulative sample count reaches ceil(q * sample size); threshold = upper edge of the NEXT
+// bin (one guard bin = 0.4 % in value).  out3 = {threshold as float bits, sample size, bin}; degenerate sample -> +inf threshold
+__global__ __launch_bounds__(1024) void eps_select_kernel(const unsigned long long* __restrict__ hist, double q, unsigned long long* __restrict__ out3) {
+  __shared__ unsigned long long part[1024];
+  const int t = (int)threadIdx.x;
+  unsigned long long c[4], s = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) { c[u] = hist[4 * t + u]; s += c[u]; }
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {             // Hillis-Steele inclusive scan
+    const unsigned long long add = t >= o ? part[t - o] : 0ull;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const unsigned long long total = hist[4096];
+  unsigned long long target = (unsigned long long)ceil(q * (double)total);
+  if (target < 64) target = 64;
+  unsigned long long run = part[t] - s;              // exclusive prefix of this thread's four bins
+  __shared__ int bsel;
+  if (t == 0) bsel = 4096;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const unsigned long long before = run;
+    run += c[u];
+    if (before < target && run >= target) bsel = 4 * t + u;   // unique
+  }
+  __syncthreads();
+  if (t == 0) {
+    const int b = bsel;
+    float thr = b >= 4094 ? __uint_as_float(0x7f800000u) : sur_bin_upper(b + 1);
+    if (total == 0) thr = __uint_as_float(0x7f800000u);
+    out3[0] = (unsigned long long)__float_as_uint(thr); out3[1] = total; out3[2] = (unsigned long long)b;
+  }
+}
+
+// the one full pass: exact float64 keys of the strict-upper non-zero elements whose surrogate is < *thr -> buf (cursor[0]);
+// cursor[1] += number of exact zeros in the strict upper triangle
+template <int MODE>
+__global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const unsigned long long* __restrict__ thr3, unsigned long long* __restrict__ buf,
+                                                              unsigned long long cap, unsigned long long* __restrict__ cursor) {
+  __shared__ unsigned long long sbuf[4][STAGE_CAP];
+  const int lane = lane_id();
+  WaveStage<unsigned long long> st{sbuf[threadIdx.x >> 6], 0};
+  const float thr = __uint_as_float((unsigned)thr3[0]);
+  const float lam32 = (float)mv.lambda_value;
+  unsigned long long zeros = 0;
+  // generic chunk: per-element bounds, exact zero detection (row edges, unaligned rows, modes 1 / 2)
+  auto generic_chunk = [&](const RowStream& rs, int c, int gi, hbits vi, const RawChunk* rawp) {
+    const int j0 = rs.col0(c, lane);
+    float sv[8]; unsigned zm = 0;
+    double dv[8];
+    RawChunk raw;
+    if (MODE == 2) {
+      load_vals<MODE>(mv, rs, c, lane, gi, dv);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { sv[e] = (float)dv[e]; if (dv[e] == 0.0) zm |= 1u << e; }
+    } else {
+      raw = rawp ? *rawp : load_raw<MODE == 2 ? 1 : MODE>(mv, rs, c, lane);
+      surrogate8<MODE == 2 ? 1 : MODE>(mv, raw, vi, lam32, sv, zm);
+    }
+    unsigned cand = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int k = j0 + e;
+      if (k > gi && k < mv.N) {
+        if ((zm >> e) & 1u) zeros++;
+        else if (sv[e] < thr) cand |= 1u << e;
+      }
+    }
+    if (!__any(cand != 0)) return;
+    if (MODE != 2) decode_raw<MODE == 2 ? 1 : MODE>(mv, raw, vi, dv);   // exact float64 values of this chunk (rare path)
+    unsigned long long keys[8]; int n = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      keys[e] = ~0ULL;
+      if ((cand >> e) & 1u) {
+        if (dv[e] != 0.0) { keys[e] = (unsigned long long)__double_as_longlong(dv[e]); n++; }
+        else zeros++;
+      }
+    }
+    int incl = n;
+    for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
+    const int tot = __shfl(incl, 63, 64);
+    int w = st.n + incl - n;
+#pragma unroll
+    for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) st.buf[w++] = keys[e];
+    st.n += tot;
+    if (st.n > STAGE_CAP - 512) st.flush(buf, cap, cursor, lane);
+  };
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const bool fast_ok = MODE == 0 && (mv.N & 7) == 0 && thr > 0.f;
+  // rows of the strict upper triangle get shorter linearly: a wave takes rows in complementary pairs (p, nrows-1-p), so every
+  // wave streams the same number of elements (a handful of whole rows per wave would leave a 1.5-2x imbalance)
+  const int npairs = (mv.nrows + 1) / 2;
+  for (int pidx = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); pidx < npairs; pidx += (int)gridDim.x * 4)
+  for (int hh = 0; hh < 2; hh++) {
+    const int il = hh ? mv.nrows - 1 - pidx : pidx;
+    if (hh && il == pidx) continue;                // odd row count: the middle row is its own partner
+    const int gi = mv.row0 + il;
+    RowStream rs(il, mv.N, mv.nrows);
+    const int c0 = (rs.first + gi + 1) / 512;
+    const hbits vi = MODE == 0 ? mv.v[gi] : (hbits)0;
+    if (fast_ok) {
+      // N % 8 == 0: rows are 16-byte aligned.  The chunk holding the diagonal and a partial last chunk take the generic path;
+      // every chunk in between lies entirely in the strict upper triangle: no bounds, packed half adds, and no zero test --
+      // an exact zero has surrogate 0 (or J' alone when lambda == 0) < thr, so it is a candidate and is classified exactly below
+      const hbits* M = reinterpret_cast<const hbits*>(mv.M) + (int64_t)il * mv.N;
+      const _Float16 vi16 = __builtin_bit_cast(_Float16, vi);
+      const h2 vi2 = {vi16, vi16};
+      const int nfull = mv.N / 512;
+      if (c0 < rs.nchunks) generic_chunk(rs, c0, gi, vi, nullptr);
+      for (int cb = c0 + 1; cb < nfull; cb += PIPE) {
+        uint4 xjs[PIPE], xvs[PIPE];
+#pragma unroll
+        for (int u = 0; u < PIPE; u++) {
+          const int j0 = min(cb + u, nfull - 1) * 512 + lane * 8;
+          xjs[u] = *reinterpret_cast<const uint4*>(M + j0);
+          xvs[u] = *reinterpret_cast<const uint4*>(mv.v + j0);
+        }
+#pragma unroll
+        for (int u = 0; u < PIPE; u++) {
+          const int c = cb + u;
+          if (c >= nfull) break;
+          const unsigned wj[4] = {xjs[u].x, xjs[u].y, xjs[u].z, xjs[u].w}, wv[4] = {xvs[u].x, xvs[u].y, xvs[u].z, xvs[u].w};
+          unsigned cand = 0;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const h2 s2 = __builtin_bit_cast(h2, wv[q]) + vi2;                 // half(v_k + v_i), two columns per instruction
+            const h2 j2 = __builtin_bit_cast(h2, wj[q]);
+            const float a = (float)j2.x + (float)s2.x * lam32, b = (float)j2.y + (float)s2.y * lam32;
+            cand |= (a < thr ? 1u : 0u) << (2 * q) | (b < thr ? 1u : 0u) << (2 * q + 1);
+          }
+          if (!__any(cand != 0)) continue;
+          RawChunk raw; raw.m = xjs[u]; raw.v = xvs[u];
+          double dv[8];
+          decode_raw<0>(mv, raw, vi, dv);
+          unsigned long long keys[8]; int n = 0;
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            keys[e] = ~0ULL;
+            if ((cand >> e) & 1u) {
+              if (dv[e] != 0.0) { keys[e] = (unsigned long long)__double_as_longlong(dv[e]); n++; }
+              else zeros++;
+            }
+          }
+          int incl = n;
+          for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
+          const int tot = __shfl(incl, 63, 64);
+          int w = st.n + incl - n;
+#pragma unroll
+          for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) st.buf[w++] = keys[e];
+          st.n += tot;
+          if (st.n > STAGE_CAP - 512) st.flush(buf, cap, cursor, lane);
+        }
+      }
+      if (nfull * 512 < mv.N && nfull > c0) generic_chunk(rs, nfull, gi, vi, nullptr);
+      continue;
+    }
+    for (int c = c0; c < rs.nchunks; c++) generic_chunk(rs, c, gi, vi, nullptr);
+  }
+  st.flush(buf, cap, cursor, lane);
+  for (int sh = 1; sh < 64; sh <<= 1) zeros += (unsigned long long)__shfl_xor((long long)zeros, sh, 64);
+  if (lane == 0 && zeros) atomicAdd(&cursor[1], zeros);
+}
+
 __global__ void fill_u64_kernel(unsigned long long* p, unsigned long long n0, unsigned long long n1, unsigned long long v) {
   for (unsigned long long i = n0 + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n1; i += (unsigned long long)gridDim.x * blockDim.x) p[i] = v;
 }
@@ -321,14 +568,40 @@ __device__ T pw_leaf(const unsigned long long* keys, long long off, int n) {
   for (; i < n; i++) res += val(i);
   return res;
 }
+// leaves of the pairwise tree, 8 lanes per leaf (one lane per accumulator of numpy's unrolled loop), 8 leaves per wave:
+//   r[j] = a[j]; for i = 8, 16, ...: r[j] += a[i + j];  res = ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7));  res += a[tail...]
+template <typename T>
+__global__ __launch_bounds__(256) void eps_leaf_kernel(const unsigned long long* __restrict__ keys, int nleaves, const long long* __restrict__ leaf_off,
+                                                       const int* __restrict__ leaf_n, T* __restrict__ val) {
+  const int gl = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3);      // leaf
+  const int j = (int)(threadIdx.x & 7);
+  const bool live = gl < nleaves;
+  const long long off = live ? leaf_off[gl] : 0;
+  const int n = live ? leaf_n[gl] : 0;
+  auto a = [&](int i) -> T { return (T)__longlong_as_double((long long)keys[off + i]); };
+  T res;
+  if (n < 8) {
+    res = (T)0;
+    if (j == 0) for (int i = 0; i < n; i++) res += a(i);
+  } else {
+    const int nb = n - (n % 8);
+    T r = a(j);
+    for (int i = 8; i < nb; i += 8) r += a(i + j);
+    // combine in numpy's order: lanes 2q, 2q+1 -> pairs, then pairs of pairs, then the two halves (xor shuffles inside the 8 lanes)
+    T p = r + (T)__shfl_xor(r, 1, 64);         // lane even: r_j + r_{j+1} (addition is commutative, the operand order does not matter)
+    T q = p + (T)__shfl_xor(p, 2, 64);         // lanes 0-3: (r0+r1)+(r2+r3); lanes 4-7: (r4+r5)+(r6+r7)
+    res = q + (T)__shfl_xor(q, 4, 64);
+    if (j == 0) for (int i = nb; i < n; i++) res += a(i);
+  }
+  if (live && j == 0) val[gl] = res;
+}
 // out[0] = eps as double; out[1] = half bits of eps (mode 1) as a double-held integer
 template <typename T>
 __global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long* __restrict__ keys, long long top, int nleaves, int nlevels,
                                                         const long long* __restrict__ leaf_off, const int* __restrict__ leaf_n,
                                                         const int* __restrict__ node_l, const int* __restrict__ node_r,
                                                         const int* __restrict__ level_ptr, T* __restrict__ val, double* __restrict__ out) {
-  for (int l = (int)threadIdx.x; l < nleaves; l += (int)blockDim.x) val[l] = pw_leaf<T>(keys, leaf_off[l], leaf_n[l]);
-  __syncthreads();
+  (void)keys; (void)leaf_off; (void)leaf_n;        // the leaves were summed by eps_leaf_kernel
   for (int h = 0; h < nlevels; h++) {
     for (int x = level_ptr[h] + (int)threadIdx.x; x < level_ptr[h + 1]; x += (int)blockDim.x) val[nleaves + x] = val[node_l[x]] + val[node_r[x]];
     __syncthreads();
@@ -545,7 +818,11 @@ static int check_view(const char* fn, const void* M, const uint16_t* v, int N, i
 // Persistent grid: ~5 workgroups per CU.  Every wave walks many rows and publishes its staged results with one
 // cursor atomic per ~500 entries; one wave per row meant N cursor / histogram atomics on a single word
 // (one word saturates at ~90 atomics/us: 16 000 rows = 0.18 ms of pure serialisation).
-static int stream_grid(int nrows) { int b = (nrows + 3) / 4; return b < 1280 ? b : 1280; }
+static int stream_grid(int nrows) {
+  static int cap = -1;
+  if (cap < 0) { const char* e = getenv("SSG_STREAM_GRID"); cap = e ? atoi(e) : 1280; }     // tuning knob
+  int b = (nrows + 3) / 4; return b < cap ? b : cap;
+}
 
 extern "C" int ssg_eps_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
                             uint64_t prefix, int shift, int width, int count_nonzero, uint64_t* hist, hipStream_t stream) {
@@ -567,6 +844,37 @@ extern "C" int ssg_eps_compact(const void* M, const uint16_t* v, int N, int row0
   if (mode == 0) SSG_COMPACT(0); else if (mode == 1) SSG_COMPACT(1); else SSG_COMPACT(2);
 #undef SSG_COMPACT
   SSG_LAUNCH_CHECK("eps_compact_kernel");
+  return SSG_OK;
+}
+
+
+// ---- K10 fast path (see eps_sample_hist_kernel): hist = 4097 uint64 zeroed by the caller; thr3 = 3 uint64 out
+extern "C" int ssg_eps_sample_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, int row_stride,
+                                   uint64_t* hist, hipStream_t stream) {
+  int rc = check_view("ssg_eps_sample_hist", M, v, N, row0, nrows, mode); if (rc) return rc;
+  if (row_stride < 1) { ssg_set_error("ssg_eps_sample_hist: row_stride must be >= 1"); return SSG_ERR_INVALID; }
+  const int nsamp = (nrows + row_stride - 1) / row_stride;
+#define SSG_SH(MD) hipLaunchKernelGGL(eps_sample_hist_kernel<MD>, dim3(stream_grid(nsamp)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
+                     row_stride, (unsigned long long*)hist)
+  if (mode == 0) SSG_SH(0); else if (mode == 1) SSG_SH(1); else SSG_SH(2);
+#undef SSG_SH
+  SSG_LAUNCH_CHECK("eps_sample_hist_kernel");
+  return SSG_OK;
+}
+extern "C" int ssg_eps_select_threshold(const uint64_t* hist, double quantile, uint64_t* thr3, hipStream_t stream) {
+  if (!(quantile > 0.0)) { ssg_set_error("ssg_eps_select_threshold: quantile must be positive"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(eps_select_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)hist, quantile, (unsigned long long*)thr3);
+  SSG_LAUNCH_CHECK("eps_select_kernel");
+  return SSG_OK;
+}
+extern "C" int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
+                                     const uint64_t* thr3, uint64_t* buf, uint64_t cap, uint64_t* cursor2, hipStream_t stream) {
+  int rc = check_view("ssg_eps_compact_below", M, v, N, row0, nrows, mode); if (rc) return rc;
+#define SSG_CT(MD) hipLaunchKernelGGL(eps_compact_thr_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
+                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor2)
+  if (mode == 0) SSG_CT(0); else if (mode == 1) SSG_CT(1); else SSG_CT(2);
+#undef SSG_CT
+  SSG_LAUNCH_CHECK("eps_compact_thr_kernel");
   return SSG_OK;
 }
 
@@ -609,11 +917,19 @@ struct PwTree {
 };
 }  // namespace
 
-extern "C" int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
-  if (top <= 0 || ws_bytes < ssg_eps_mean_workspace_bytes(top)) { ssg_set_error("ssg_eps_mean: top=%lld ws too small", (long long)top); return SSG_ERR_INVALID; }
+namespace {
+struct PwLayout { int L, I, hroot; size_t o_off, o_n, o_l, o_r, o_lp, o_val, need; std::vector<char> host; };
+// numpy's pairwise-summation tree for `top` summands (depends on top only) and its packed device layout
+static void pw_layout(int64_t top, PwLayout& out, bool with_tables) {
   PwTree t; std::vector<int> il, ir, ih; int hroot = 0;
   t.build(0, top, il, ir, ih, hroot);
   const int L = (int)t.leaf_off.size(), I = (int)il.size();
+  out.L = L; out.I = I; out.hroot = hroot;
+  // pack tables: leaf_off[L] i64 | leaf_n[L] | node_l[I] | node_r[I] | level_ptr[hroot+1] | val[(L+I)] (8 B each)
+  out.o_off = 0; out.o_n = out.o_off + (size_t)L * 8; out.o_l = out.o_n + (size_t)L * 4; out.o_r = out.o_l + (size_t)I * 4; out.o_lp = out.o_r + (size_t)I * 4;
+  out.o_val = out.o_lp + (size_t)(hroot + 1) * 4; out.o_val = (out.o_val + 15) & ~(size_t)15;
+  out.need = out.o_val + (size_t)(L + I) * 8;
+  if (!with_tables) return;
   // order internal nodes by height (stable), remap child references
   std::vector<int> order(I), pos(I);
   for (int i = 0; i < I; i++) order[i] = i;
@@ -625,29 +941,50 @@ extern "C" int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, 
   // level_ptr[h] currently counts nodes of height h (h>=1) at index h; turn into prefix offsets over levels 1..hroot
   std::vector<int> lp(hroot + 1, 0);
   for (int h = 1; h <= hroot; h++) lp[h] = lp[h - 1] + t.level_ptr[h];
-  // pack tables: leaf_off[L] i64 | leaf_n[L] | node_l[I] | node_r[I] | level_ptr[hroot+1] | val[(L+I)] (8 B each)
-  const size_t o_off = 0, o_n = o_off + (size_t)L * 8, o_l = o_n + (size_t)L * 4, o_r = o_l + (size_t)I * 4, o_lp = o_r + (size_t)I * 4;
-  size_t o_val = o_lp + (size_t)(hroot + 1) * 4; o_val = (o_val + 15) & ~(size_t)15;
-  const size_t need = o_val + (size_t)(L + I) * 8;
-  if (need > ws_bytes) { ssg_set_error("ssg_eps_mean: workspace %zu < %zu", ws_bytes, need); return SSG_ERR_INVALID; }
-  std::vector<char> host(o_val);
-  memcpy(host.data() + o_off, t.leaf_off.data(), (size_t)L * 8);
-  memcpy(host.data() + o_n, t.leaf_n.data(), (size_t)L * 4);
-  if (I) { memcpy(host.data() + o_l, t.node_l.data(), (size_t)I * 4); memcpy(host.data() + o_r, t.node_r.data(), (size_t)I * 4); }
-  memcpy(host.data() + o_lp, lp.data(), (size_t)(hroot + 1) * 4);
-  SSG_HIP(hipMemcpyAsync(ws, host.data(), o_val, hipMemcpyHostToDevice, stream));
-  SSG_HIP(hipStreamSynchronize(stream));   // `host` is a local buffer
-  char* w = (char*)ws;
-  if (mode == 0)
-    hipLaunchKernelGGL(eps_mean_kernel<double>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
-                       (const long long*)(w + o_off), (const int*)(w + o_n), (const int*)(w + o_l), (const int*)(w + o_r), (const int*)(w + o_lp),
-                       (double*)(w + o_val), out2);
-  else
-    hipLaunchKernelGGL(eps_mean_kernel<float>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
-                       (const long long*)(w + o_off), (const int*)(w + o_n), (const int*)(w + o_l), (const int*)(w + o_r), (const int*)(w + o_lp),
-                       (float*)(w + o_val), out2);
-  SSG_LAUNCH_CHECK("eps_mean_kernel");
+  out.host.assign(out.o_val, 0);
+  memcpy(out.host.data() + out.o_off, t.leaf_off.data(), (size_t)L * 8);
+  memcpy(out.host.data() + out.o_n, t.leaf_n.data(), (size_t)L * 4);
+  if (I) { memcpy(out.host.data() + out.o_l, t.node_l.data(), (size_t)I * 4); memcpy(out.host.data() + out.o_r, t.node_r.data(), (size_t)I * 4); }
+  memcpy(out.host.data() + out.o_lp, lp.data(), (size_t)(hroot + 1) * 4);
+}
+}  // namespace
+
+// Step 1 of ssg_eps_mean: upload the recursion tables for `top` into ws.  Blocks until the copy is done (the tables live in a
+// local host buffer) -- call it while the stream is idle (right after `top` became known), not behind the sort.
+extern "C" int ssg_eps_mean_prepare(int64_t top, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (top <= 0 || ws_bytes < ssg_eps_mean_workspace_bytes(top)) { ssg_set_error("ssg_eps_mean: top=%lld ws too small", (long long)top); return SSG_ERR_INVALID; }
+  PwLayout lay; pw_layout(top, lay, true);
+  if (lay.need > ws_bytes) { ssg_set_error("ssg_eps_mean: workspace %zu < %zu", ws_bytes, lay.need); return SSG_ERR_INVALID; }
+  SSG_HIP(hipMemcpyAsync(ws, lay.host.data(), lay.o_val, hipMemcpyHostToDevice, stream));
+  SSG_HIP(hipStreamSynchronize(stream));   // `lay.host` is a local buffer
   return SSG_OK;
+}
+// Step 2: the summation itself (asynchronous): leaves in parallel (8 lanes per leaf), then one workgroup walks the tree levels
+extern "C" int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
+  if (top <= 0 || ws_bytes < ssg_eps_mean_workspace_bytes(top)) { ssg_set_error("ssg_eps_mean: top=%lld ws too small", (long long)top); return SSG_ERR_INVALID; }
+  PwLayout lay; pw_layout(top, lay, false);
+  char* w = (char*)ws;
+  const int L = lay.L, hroot = lay.hroot;
+  const int lb = (L * 8 + 255) / 256;
+  if (mode == 0) {
+    hipLaunchKernelGGL(eps_leaf_kernel<double>, dim3(lb), dim3(256), 0, stream, (const unsigned long long*)sorted_keys, L, (const long long*)(w + lay.o_off),
+                       (const int*)(w + lay.o_n), (double*)(w + lay.o_val));
+    hipLaunchKernelGGL(eps_mean_kernel<double>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
+                       (const long long*)(w + lay.o_off), (const int*)(w + lay.o_n), (const int*)(w + lay.o_l), (const int*)(w + lay.o_r),
+                       (const int*)(w + lay.o_lp), (double*)(w + lay.o_val), out2);
+  } else {
+    hipLaunchKernelGGL(eps_leaf_kernel<float>, dim3(lb), dim3(256), 0, stream, (const unsigned long long*)sorted_keys, L, (const long long*)(w + lay.o_off),
+                       (const int*)(w + lay.o_n), (float*)(w + lay.o_val));
+    hipLaunchKernelGGL(eps_mean_kernel<float>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
+                       (const long long*)(w + lay.o_off), (const int*)(w + lay.o_n), (const int*)(w + lay.o_l), (const int*)(w + lay.o_r),
+                       (const int*)(w + lay.o_lp), (float*)(w + lay.o_val), out2);
+  }
+  SSG_LAUNCH_CHECK("eps_mean kernels");
+  return SSG_OK;
+}
+extern "C" int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
+  const int rc = ssg_eps_mean_prepare(top, ws, ws_bytes, stream);
+  return rc ? rc : ssg_eps_mean_run(sorted_keys, top, mode, ws, ws_bytes, out2, stream);
 }
 
 extern "C" int ssg_region_query(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps,

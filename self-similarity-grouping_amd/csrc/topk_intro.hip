@@ -49,7 +49,10 @@ struct ProfAcc { unsigned long long a[16]; };
 #endif
 
 constexpr int SMALL = 15;          // ranges with pr - pl > SMALL are partitioned (numpy 2.2.6)
-constexpr int WAVE_N = 1024;       // ranges up to this many entries are handled by wave 0 alone
+#ifndef SSG_INTRO_WAVE_N
+#define SSG_INTRO_WAVE_N 1024
+#endif
+constexpr int WAVE_N = SSG_INTRO_WAVE_N;   // ranges up to this many entries are handled by wave 0 alone
 constexpr int STACK = 64;          // pending ranges that intersect [0, K): all disjoint with pl < K <= 64
 constexpr int IDX_BITS = 17;       // column bits of a packed entry (N <= 131072); the raw half (< 0x8000) sits above
 constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;
@@ -80,6 +83,14 @@ __device__ __forceinline__ uint32_t eraw(uint32_t e) { return e >> IDX_BITS; }
 __device__ __forceinline__ uint32_t norm_key(uint32_t raw, float fmx) {
   const hbits q = f2h(h2f((hbits)raw) / fmx);
   return h_isnan(q) ? KEY_NAN : (uint32_t)q;
+}
+
+// values that are wave-uniform by construction but live in VGPRs (loaded from LDS, shuffled): moving them to SGPRs lets the
+// compiler run loop control and 64-bit mask arithmetic on the scalar unit instead of issuing them for 64 lanes
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ uint64_t uni(uint64_t x) {
+  return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
 }
 
 template <bool WAVE>
@@ -174,6 +185,7 @@ __device__ __forceinline__ void key_class(uint32_t xp, float fmx, uint32_t& lo, 
 template <bool WAVE, int NT, class Arena>
 __device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int pl, int pr PROF_ARG) {
   constexpr int NW = NT / 64;
+  pl = uni(pl); pr = uni(pr);
   const int lane = lane_id();
   const int tid = WAVE ? lane : (int)threadIdx.x;
   constexpr int nthr = WAVE ? 64 : NT;
@@ -205,7 +217,8 @@ __device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& m
   gsync<WAVE>();
   PROF(WAVE ? 11 : 1);
   uint32_t tlo, thi;                    // key(raw) >= key(pivot) <=> raw >= tlo;  key(raw) <= key(pivot) <=> raw <= thi
-  key_class(sh->xp, fmx, tlo, thi);
+  key_class(uni(sh->xp), fmx, tlo, thi);
+  tlo = uni(tlo); thi = uni(thi);
 
   // ---- B: stopper masks of the scan region + running counts inside each chunk; four words (256 positions) per step,
   //         loads unconditional (clamped address), validity as a wave-uniform mask, one lane stores the group
@@ -250,7 +263,7 @@ __device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& m
   const uint32_t totL = (uint32_t)__builtin_amdgcn_readlane((int)inL, 63), totR = (uint32_t)__builtin_amdgcn_readlane((int)inR, 63);
   // crossing word = number of words at whose end g >= f still holds (monotone), counted 64 words at a time
   int wstar = 0;
-  for (int wb = 0; wb < W; wb += 64) {
+  for (int wb = 0; wb < W; wb += 64) {   // (W, cs, nch are scalars: pl and pr were made uniform above)
     const int w = wb + lane;
     const bool valid = w < W;
     const int wc = valid ? w : W - 1;
@@ -269,10 +282,10 @@ __device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& m
   if (wstar >= W) {
     m = totL; pstar = s1;
   } else {
-    const uint64_t lm = mk.L[wstar], rm = mk.R[wstar];
+    const uint64_t lm = uni(mk.L[wstar]), rm = uni(mk.R[wstar]);
     const int ch = wstar >> cs;
-    const uint32_t pw = mk.P[wstar];
-    const uint32_t pL = (pw & 0xffffu) + (uint32_t)__shfl((int)exL, ch), pR = (pw >> 16) + (uint32_t)__shfl((int)exR, ch);
+    const uint32_t pw = uni(mk.P[wstar]);
+    const uint32_t pL = (pw & 0xffffu) + uni((uint32_t)__shfl((int)exL, ch)), pR = (pw >> 16) + uni((uint32_t)__shfl((int)exR, ch));
     const uint32_t cumL = pL - (uint32_t)__popcll(lm);       // L-stoppers in words < wstar
     const uint32_t cumR = totR - pR;                         // R-stoppers in words > wstar
     const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
@@ -289,7 +302,8 @@ __device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& m
       pstar = s0 + (wstar << 6) + b;
     }
   }
-  const int pi = pstar + 1;
+  m = uni(m);
+  const int pi = uni(pstar) + 1;
   PROF(WAVE ? 14 : 4);
 
   // ---- E: swap the k-th L-stopper from the left with the k-th R-stopper from the right, k <= m
@@ -404,7 +418,7 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
       if (sp == 0) break;
       __syncthreads();
       --sp;
-      pl = sh->stack[3 * sp]; pr = sh->stack[3 * sp + 1]; cd = sh->stack[3 * sp + 2];
+      pl = uni(sh->stack[3 * sp]); pr = uni(sh->stack[3 * sp + 1]); cd = uni(sh->stack[3 * sp + 2]);
       if (cd < 0) {                       // popped past the depth budget: heapsort the whole range
         if (tid == 0) heapsort(A, fmx, pl, pr - pl + 1);
         continue;
@@ -441,7 +455,7 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
         if (lane == 0) sh->sp = wsp;
       }
       __syncthreads();
-      sp = sh->sp;
+      sp = uni(sh->sp);
     }
   }
   __syncthreads();

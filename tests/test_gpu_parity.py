@@ -800,3 +800,45 @@ def test_split_half_overflow_falls_back_to_f32(dev):
     a = ms.embed_with_flip(small); b = m32.embed_with_flip(small)
     assert not torch.equal(a, b) and float((a - b).abs().max()) < 5e-6
     del sd
+
+
+# ------------------------------------------------------------------ epsilon rule: sampled fast path vs radix select vs numpy
+def _eps_numpy(M, rho):
+    tri = np.triu(M, 1)                      # selftraining.py:289-293
+    tri = tri[np.nonzero(tri)]
+    tri = np.sort(tri, axis=None)
+    top = int(np.round(rho * tri.size))
+    return tri[:top].mean(), tri.size, top
+
+
+@pytest.mark.parametrize("case", ["uniform", "zeros", "unrepresentative_sample", "hidden_small_rows", "half_matrix"])
+def test_eps_rule_paths_agree_with_numpy(case, dev, monkeypatch):
+    """The sampled-threshold fast path is exact whenever it accepts its result and falls back to the radix select when the
+    strided row sample misjudges the quantile: both paths == numpy on matrices built to break the sample."""
+    from ssg_amd import cluster
+    rng = np.random.default_rng(9)
+    N, rho = 1500, 1.6e-3
+    M = rng.random((N, N)) + 0.05
+    if case == "zeros":
+        M[rng.random((N, N)) < 0.3] = 0.0
+    elif case == "unrepresentative_sample":        # sampled rows (0, stride, ...) look small, the rest is large: threshold too low
+        stride = max(1, N // 192)
+        M[::stride] *= 1e-3
+    elif case == "hidden_small_rows":               # the small values sit only in rows the sample never sees
+        stride = max(1, N // 192)
+        M[1::stride] *= 1e-3 if stride > 1 else 1.0
+        M[N // 2:] += 5.0
+    M = np.triu(M, 1); M = M + M.T
+    if case == "half_matrix":
+        Mh = M.astype(np.float16)
+        ref = _eps_numpy(Mh, rho)
+        for path in ("sampled", "radix"):
+            monkeypatch.setenv("SSG_EPS_PATH", path)
+            eps, cnt, top = cluster.eps_rule(Mh, rho)
+            assert (np.float16(eps).view(np.uint16), cnt, top) == (np.float16(ref[0]).view(np.uint16), ref[1], ref[2]), path
+        return
+    ref = _eps_numpy(M, rho)
+    for path in ("sampled", "radix"):
+        monkeypatch.setenv("SSG_EPS_PATH", path)
+        eps, cnt, top = cluster.eps_rule(M, rho)
+        assert (eps, cnt, top) == (float(ref[0]), ref[1], ref[2]), (case, path)
