@@ -78,6 +78,12 @@ int ssg_source_rowmin_f16(const float* tgt, const double* ntgt, const float* src
  * and tol must cover that pass's error; 0 = float32 MFMA bound pass. */
 int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t,
                                float scale_s, float* ws, uint32_t* rowmin, ssg_stream_t stream);
+/* The same with the bound pass as a plain fp16 GEMM (csrc/source_bound.hip: half copies of tgt*scale_t and src*scale_s, one
+ * v_mfma_f32_32x32x16_f16 product per term, 2 bytes per operand element instead of 4); tol must additionally cover 2^-10 |x||y| per
+ * dot product -- a few more granules are re-evaluated in float64, the result is the same.  Needs scale_t, scale_s > 0 (runs the
+ * three-product pass otherwise); ws as for ssg_source_rowmin_filtered with the split copies. */
+int ssg_source_rowmin_filtered1(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t,
+                                float scale_s, float* ws, uint32_t* rowmin, ssg_stream_t stream);
 /* v = half(1-exp(-rowmin)); *max_bits = max(v); v /= max(v)   (rerank.py:38-40).  A zero
  * max means the reference would produce NaNs (0/0): the caller must raise. */
 int ssg_source_vec_finish(const uint32_t* rowmin, int N, uint16_t* v, uint32_t* max_bits, ssg_stream_t stream);

@@ -80,6 +80,9 @@ struct ConvParams {
   const float* cscale = nullptr;
   // set to 1 when a value that does not fit the split-half output format (|v| >= 65520 or NaN) is encoded (nullptr = no check)
   int* overflow = nullptr;
+  // 1 = only the hi x hi product of the split-half operands (a plain fp16 GEMM: 1/3 of the matrix work, error 2^-10 |x||y|;
+  // used by the source-term bound pass, whose tolerance covers it); 3 = the fp32-class three-product form
+  int products = 3;
 };
 
 constexpr int CLD32 = 36;   // LDS row pitch in floats for BK=32 (BK=16 uses 20): pitch/4 odd -> conflict-free b128
@@ -535,7 +538,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
 // logical chunk pc ^ g(row) into physical slot pc) and again when the fragments are read.
 #define SSG_LDSP(ptr_) ((__attribute__((address_space(3))) void*)(ptr_))
 
-template <int BN>
+template <int BN, bool ONEPROD = false>
 __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
   constexpr int BM = 128, WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
   constexpr int WCOLS = BN / WN, NW = 2 * WCOLS;                     // 8 waves (2 x 4) for BN = 256, 4 waves (2 x 2) for BN = 128
@@ -608,10 +611,12 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
       ah_[i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offh); al_[i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offl); } \
     _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                                 \
       bh_[j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offh); bl_[j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offl); } \
-    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                    \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_[j], al_[i], acc[i][j], 0, 0, 0);                        \
-    _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                    \
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_[j], ah_[i], acc[i][j], 0, 0, 0);                        \
+    if constexpr (!ONEPROD) {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_[j], al_[i], acc[i][j], 0, 0, 0);                      \
+      _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_[j], ah_[i], acc[i][j], 0, 0, 0);                      \
+    }                                                                                                                \
     _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)                    \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_[j], ah_[i], acc[i][j], 0, 0, 0);                        \
   }
@@ -952,7 +957,8 @@ static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
   if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }
   if ((dma & 1) && (p.epi == 0 || p.epi == 3) && (int64_t)p.Cout * p.Kpad * 4 < 0x7fffffffLL) {   // (weights go through a 2 GiB buffer resource)
     const int tiles = ((p.M + 127) / 128) * (p.Cout / 256);
-    hipLaunchKernelGGL(conv_dma_kernel<256>, dim3(tiles), dim3(512), 0, stream, p);
+    if (p.products == 1) hipLaunchKernelGGL((conv_dma_kernel<256, true>), dim3(tiles), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(conv_dma_kernel<256>, dim3(tiles), dim3(512), 0, stream, p);
     return ssg_check_hip(hipGetLastError(), "conv_dma_kernel");
   }
   return launch_conv_bk<128, 256, 64, 64, false, 32, true>(p, stream);
@@ -1144,8 +1150,8 @@ __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restr
 // ws: nrows + Ns_pad + nrows*(Ns_pad/8) floats, plus (nrows + Ns_pad)*d floats when scale_t, scale_s > 0: the bound
 // pass then runs on the fp16 matrix cores over split-half copies of tgt*scale_t and src*scale_s (powers of two that
 // keep max|x|*scale < 65504); the caller's tol must cover that pass's error (3 products, 3d-term accumulation).
-extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
-                                          float* ws, uint32_t* rowmin, hipStream_t stream) {
+static int source_rowmin_filtered_impl(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
+                                       int one_product, float* ws, uint32_t* rowmin, hipStream_t stream) {
   if (nrows <= 0 || Ns <= 0 || Ns_pad < Ns || (Ns_pad % 128) || (d % 32) || (int64_t)nrows * d * 4 > 0x7fffffffLL) {
     ssg_set_error("ssg_source_rowmin_filtered: bad shape nrows=%d Ns=%d Ns_pad=%d d=%d", nrows, Ns, Ns_pad, d);
     return SSG_ERR_INVALID;
@@ -1156,6 +1162,19 @@ extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, in
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
   if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
   const bool split = scale_t > 0.f && scale_s > 0.f;
+  if (split && one_product && (Ns_pad % 128) == 0) {
+    // bound pass as a plain fp16 GEMM on half copies of the scaled operands (source_bound.hip): 2 bytes per element, 1 product
+    uintptr_t a = (uintptr_t)(tilemin + (int64_t)nrows * ntiles); a = (a + 15) & ~(uintptr_t)15;
+    _Float16* x16 = (_Float16*)a; _Float16* y16 = x16 + (int64_t)nrows * d;
+    hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, tgt, x16, (int64_t)nrows * d / 4, scale_t);
+    hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, src, y16, (int64_t)Ns_pad * d / 4, scale_s);
+    const int tiles = ((nrows + sbound::BM - 1) / sbound::BM) * (Ns_pad / sbound::BN);
+    hipLaunchKernelGGL(sbound::source_bound_kernel, dim3(tiles), dim3(256), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
+                       1.f / (scale_t * scale_s), tilemin, ntiles);
+    hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
+    SSG_LAUNCH_CHECK("source_bound / source_refine kernels");
+    return SSG_OK;
+  }
   const float* gt = tgt; const float* gs = src;
   if (split) {   // bound pass on the fp16 matrix cores: split-half copies of both operand sets (scaled into the half range)
     float* ts = tilemin + (int64_t)nrows * ntiles; float* ss = ts + (int64_t)nrows * d;
@@ -1176,6 +1195,18 @@ extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, in
   hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
   SSG_LAUNCH_CHECK("source_refine_kernel");
   return SSG_OK;
+}
+
+extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
+                                          float* ws, uint32_t* rowmin, hipStream_t stream) {
+  return source_rowmin_filtered_impl(tgt, src, nrows, Ns, Ns_pad, d, tol, scale_t, scale_s, 0, ws, rowmin, stream);
+}
+// the same with the bound pass on the hi halves only (one fp16 product per term instead of three: 1/3 of the matrix work); the
+// caller's tol must cover 2^-10 |x||y| per dot product on top of the accumulation error.  Needs scale_t, scale_s > 0 and
+// Ns_pad % 256 == 0, otherwise it runs the three-product pass.
+extern "C" int ssg_source_rowmin_filtered1(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
+                                           float* ws, uint32_t* rowmin, hipStream_t stream) {
+  return source_rowmin_filtered_impl(tgt, src, nrows, Ns, Ns_pad, d, tol, scale_t, scale_s, 1, ws, rowmin, stream);
 }
 
 extern "C" int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, hipStream_t stream) {

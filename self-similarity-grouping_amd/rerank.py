@@ -135,7 +135,9 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
             stats = torch.stack([tblk.abs().max(), src.abs().max(), tblk.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
         mt, ms, nx, ny = (float(s) for s in stats)
         u = 2.0 ** -24
-        split = os.environ.get("SSG_SOURCE_BOUND", "split") == "split"
+        bound = os.environ.get("SSG_SOURCE_BOUND", "half")
+        split = bound in ("split", "half")
+        one = bound == "half"        # bound pass on the hi halves only (plain fp16 GEMM); "split" = three products (fp32-class)
         st = ss = 0.0
         if split:
             # bound pass on the fp16 matrix cores (split-half operands): per product 3*2^-22 relative (two operand
@@ -146,14 +148,19 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
             ss = 256.0 if ms == 0 else min(256.0, 2.0 ** math.floor(math.log2(16384.0 / ms)))
             gam = 3.0 * d * u * 1.01 / (1.0 - 3.0 * d * u)
             dot_err = (gam + 12.0 * u) * nx * ny + u * math.sqrt(d) * (nx / ss + ny / st) * 1.01
+            if one:
+                # hi halves only: each operand carries a relative error 2^-11 (+ 2^-25 absolute below the half normals, covered
+                # by the second term above), so |x.y - xh.yh| <= (2^-10 + 2^-22) sum|x_k y_k| <= 2^-10 * 1.001 |x||y|; the
+                # accumulation is a d-term float32 chain (covered by gam)
+                dot_err += (2.0 ** -10) * 1.001 * nx * ny
         else:
             gam = d * u / (1.0 - d * u)
             dot_err = gam * nx * ny
         tol = 2.0 * (2.0 * dot_err + 40.0 * u * (nx * nx + ny * ny)) + 8.0 * u * (nx + ny) ** 2
         nws = nrows + Ns + npad + nrows * ((Ns + npad) // 8) + ((nrows + Ns + npad) * d if split else 0)
         ws = torch.empty(nws, dtype=torch.float32, device=tgt.device)
-        check(L.ssg_source_rowmin_filtered(ptr(tblk), ptr(srcp), nrows, Ns, Ns + npad, d, tol, st, ss, ptr(ws), ptr(rowmin), stream()),
-              "ssg_source_rowmin_filtered")
+        fn = L.ssg_source_rowmin_filtered1 if (split and one) else L.ssg_source_rowmin_filtered
+        check(fn(ptr(tblk), ptr(srcp), nrows, Ns, Ns + npad, d, tol, st, ss, ptr(ws), ptr(rowmin), stream()), "ssg_source_rowmin_filtered")
         return rowmin
     ntgt = torch.empty(N, dtype=torch.float64, device=tgt.device)
     nsrc = torch.empty(Ns, dtype=torch.float64, device=tgt.device)
