@@ -48,7 +48,7 @@ class KernelTimer:
     def __getattr__(self, k):
         fn = getattr(self.L, k)
         if not self.on or not self.sample or not k.startswith("ssg_") or k.endswith("_bytes") or k in (
-                "ssg_last_error", "ssg_krecip_row_capacity", "ssg_double_to_half_bits", "ssg_version"):
+                "ssg_last_error", "ssg_krecip_row_capacity", "ssg_double_to_half_bits", "ssg_version", "ssg_eps_mean_prepare"):
             return fn
 
         def timed(*a):
@@ -332,6 +332,13 @@ def main():
         hbm.append({"kernel": "ssg_source_rowmin_filtered", "bound": "mfma", "what": "source term by filter-and-refine: split-half fp16-MFMA bound pass (2*N*Ns*d flop, 3 products each) + fp64 "
                     "re-evaluation of candidate granules; time covers both; peak = fp16 MFMA / 3", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
                     "peak": round(PEAK_FP16_MFMA_TF / 3.0, 1), "unit": "TFLOP/s", "frac": round(tf / (PEAK_FP16_MFMA_TF / 3.0), 4)})
+    if "ssg_source_rowmin_filtered1" in tot:
+        n, ms = tot["ssg_source_rowmin_filtered1"]
+        tf = 2.0 * nrows * args.Ns * 2048 * n / (ms * 1e-3) / 1e12
+        hbm.append({"kernel": "ssg_source_rowmin_filtered1", "bound": "mfma", "what": "source term by filter-and-refine: bound pass = plain fp16 GEMM on half copies of the "
+                    "operands (2*N*Ns*d flop, one v_mfma_f32_32x32x16_f16 product per term) + fp64 re-evaluation of the candidate granules; time covers the encode, "
+                    "both passes and the row norms; peak = dense fp16 MFMA", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
+                    "peak": PEAK_FP16_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP16_MFMA_TF, 4)})
     hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
                                     "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_compact_below", "ssg_fill_u64",
                                     "ssg_sort_u64", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_dbscan_cc", "ssg_dbscan_cc_dev")

@@ -83,37 +83,44 @@ def _gpu_worker(rank, world, port, q, N, Ns, d):
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     g = dist.group.WORLD
-    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(3)]
-    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(3)]
+    Ns, d = Ns, d
+    nsplit = 3 if N < 10000 else 1
+    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(nsplit)]
+    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(nsplit)]
     lo, hi = sd.shard_bounds(N, rank, world)
     out = {}
-    for mode, no_rerank in (("rerank", False), ("norerank", True)):
+    for mode, no_rerank in ((("rerank", False), ("norerank", True)) if N < 10000 else (("rerank", False),)):
         e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2, group=g)
         args = SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3)
         labels, clusters = generate_selflabel(e_list, r_list, 0, args, [])
         hs = e_list if no_rerank else r_list
         assert all(h.row0 == lo and h.nrows == hi - lo for h in hs)
-        out[mode] = [(float(c.eps), l, h.M.cpu().numpy().view(np.uint16)) for c, l, h in zip(clusters, labels, hs)]
+        import hashlib
+        pack = (lambda m: hashlib.sha256(m.tobytes()).hexdigest()) if N > 10000 else (lambda m: m)
+        out[mode] = [(float(c.eps), l, pack(h.M.cpu().numpy().view(np.uint16))) for c, l, h in zip(clusters, labels, hs)]
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,N", [(2, 1536), (8, 1531)])
+@pytest.mark.parametrize("world,N", [(2, 1536), (8, 1531), (8, 30003)])
 def test_sharded_pipeline_matches_unsharded(world, N):
     """compute_dist -> generate_selflabel, 3 feature splits, rows sharded over `world` processes (gloo; they share the
-    test box's single GPU) with ragged row blocks (1531 = 8*191 + 3): eps, labels and every local block of the distance
-    matrix bit-identical to the unsharded run."""
+    test box's single GPU) with ragged row blocks (1531 = 8*191 + 3; 30003 = BASELINE configs[3]'s MSMT17-size problem, one split
+    over 8 ranks, with a non-divisible N): eps, labels and every local block of the distance matrix bit-identical to the
+    unsharded run.  (The 8-GPU RCCL leg itself is the driver's; this is the same code over gloo.)"""
     from types import SimpleNamespace
     from ssg_amd import compute_dist, generate_selflabel
     from ssg_amd.dist import shard_bounds
-    Ns, d = 640, 96
+    Ns, d = (640, 96) if N < 10000 else (4000, 128)
     dev = torch.device("cuda", 0)
-    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(3)]
-    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(3)]
+    nsplit = 3 if N < 10000 else 1           # the MSMT-size case: one split, re-rank mode (keeps the 8 processes on one GPU short)
+    modes = (("rerank", False), ("norerank", True)) if N < 10000 else (("rerank", False),)
+    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(nsplit)]
+    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(nsplit)]
     ref = {}
-    for mode, no_rerank in (("rerank", False), ("norerank", True)):
+    for mode, no_rerank in modes:
         e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2)
         args = SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3)
         labels, clusters = generate_selflabel(e_list, r_list, 0, args, [])
@@ -126,12 +133,16 @@ def test_sharded_pipeline_matches_unsharded(world, N):
     [p.start() for p in procs]
     res = dict(q.get(timeout=900) for _ in range(world))
     [p.join(120) for p in procs]
-    for mode in ("rerank", "norerank"):
-        for s in range(3):
+    for mode, _ in modes:
+        for s in range(nsplit):
             e0, l0, m0 = ref[mode][s]
             for r in range(world):
                 e, l, m = res[r][mode][s]
                 lo, hi = shard_bounds(N, r, world)
                 assert e == e0, (mode, s, r)
                 assert np.array_equal(l, l0), (mode, s, r)
-                assert np.array_equal(m, m0[lo:hi]), (mode, s, r)
+                if N > 10000:
+                    import hashlib
+                    assert m == hashlib.sha256(np.ascontiguousarray(m0[lo:hi]).tobytes()).hexdigest(), (mode, s, r)
+                else:
+                    assert np.array_equal(m, m0[lo:hi]), (mode, s, r)
