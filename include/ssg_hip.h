@@ -149,8 +149,12 @@ int ssg_eps_compact(const void* M, const uint16_t* v, int N, int row0, int nrows
  * threshold -> buf (cursor2[0] counts them, writes beyond cap dropped), cursor2[1] += exact zeros.  The caller sorts, and accepts
  * the result only if the top-th smallest key is below the threshold by more than the surrogate error (else: the radix select). */
 int ssg_eps_sample_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, int row_stride,
-                        uint64_t* hist, ssg_stream_t stream);
+                        const uint64_t* refine, uint64_t* hist, ssg_stream_t stream);
+/* thr = 5 uint64: {threshold float bits, sample size, selected coarse bin, sample elements below that bin, target rank} */
 int ssg_eps_select_threshold(const uint64_t* hist, double quantile, uint64_t* thr3, ssg_stream_t stream);
+/* second level: ssg_eps_sample_hist(..., refine = thr, hist2) counts the sample elements of the selected coarse bin in 1024 linear
+ * sub-bins (hist2 zeroed by the caller); this replaces thr[0] by the sub-bin edge (one guard sub-bin) */
+int ssg_eps_refine_threshold(const uint64_t* hist2, uint64_t* thr, ssg_stream_t stream);
 int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
                           const uint64_t* thr3, uint64_t* buf, uint64_t cap, uint64_t* cursor2, ssg_stream_t stream);
 int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t value, ssg_stream_t stream);

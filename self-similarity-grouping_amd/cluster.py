@@ -75,11 +75,17 @@ def _eps_rule_sampled(L, h, rho, st):
     upper_total = N * (N - 1) // 2
     expected_top = max(int(rho * upper_total), 1)
     stride = max(1, h.nrows // 192)
-    hist = torch.zeros(4097, dtype=torch.int64, device=dev)
-    check(L.ssg_eps_sample_hist(*args, stride, ptr(hist), st), "ssg_eps_sample_hist")
-    hist = _all_reduce(hist, h.group)                       # sharded rows: every rank selects from the same global sample
-    thr3 = torch.zeros(3, dtype=torch.int64, device=dev)
-    check(L.ssg_eps_select_threshold(ptr(hist), 1.3 * float(rho), ptr(thr3), st), "ssg_eps_select_threshold")
+    hist = torch.zeros(2 * 4097, dtype=torch.int64, device=dev)
+    hist1, hist2 = hist[:4097], hist[4097:]
+    check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist1), st), "ssg_eps_sample_hist")
+    hist1 = _all_reduce(hist1, h.group)                     # sharded rows: every rank selects from the same global sample
+    thr3 = torch.zeros(5, dtype=torch.int64, device=dev)
+    check(L.ssg_eps_select_threshold(ptr(hist1), 1.3 * float(rho), ptr(thr3), st), "ssg_eps_select_threshold")
+    # second level inside the selected 0.4 %-wide bin (1024 sub-bins): on a dense value distribution one coarse bin holds far
+    # more elements than the quantile margin
+    check(L.ssg_eps_sample_hist(*args, stride, ptr(thr3), ptr(hist2), st), "ssg_eps_sample_hist")
+    hist2 = _all_reduce(hist2, h.group)
+    check(L.ssg_eps_refine_threshold(ptr(hist2), ptr(thr3), st), "ssg_eps_refine_threshold")
     cap = max(6 * expected_top * h.nrows // N + (1 << 16), 1 << 16)
     n_cap = max(2048, 1 << (cap - 1).bit_length())
     buf = torch.empty(n_cap, dtype=torch.int64, device=dev)

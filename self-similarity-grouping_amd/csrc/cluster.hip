@@ -306,13 +306,20 @@ __device__ __forceinline__ void surrogate8(const MatView& mv, const RawChunk& r,
 }
 
 // sample histogram: local rows 0, stride, 2*stride, ...; strict upper triangle, exact zeros dropped; hist[4096] = sample size
+// refine != nullptr: second level -- only the sample elements of coarse bin refine[2] are counted, in 1024 linear sub-bins of
+// that bin's float range (hist[0..1023]); the coarse bins are 0.4 % wide, which on a dense value distribution is far more than
+// the quantile margin and would blow the candidate set up
 template <int MODE>
-__global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int stride, unsigned long long* __restrict__ hist) {
+__global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int stride, const unsigned long long* __restrict__ refine,
+                                                              unsigned long long* __restrict__ hist) {
   __shared__ unsigned int lh[4097];
   for (int b = (int)threadIdx.x; b < 4097; b += 256) lh[b] = 0;
   __syncthreads();
   const int lane = lane_id();
   const float lam32 = (float)mv.lambda_value;
+  const int rbin = refine ? (int)refine[2] : -1;
+  const float rlo = rbin > 0 ? sur_bin_upper(rbin - 1) : 0.f, rhi = rbin >= 0 ? sur_bin_upper(rbin) : 1.f;
+  const float rinv = 1024.f / (rhi - rlo);
   const int nsamp = (mv.nrows + stride - 1) / stride;
   for (int sidx = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); sidx < nsamp; sidx += (int)gridDim.x * 4) {
     const int il = sidx * stride, gi = mv.row0 + il;
@@ -334,7 +341,15 @@ __global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int st
 #pragma unroll
       for (int e = 0; e < 8; e++) {
         const int k = j0 + e;
-        if (k > gi && k < mv.N && !((zm >> e) & 1u)) { atomicAdd(&lh[sur_bin(sv[e])], 1u); cnt++; }
+        if (k > gi && k < mv.N && !((zm >> e) & 1u)) {
+          const int b = sur_bin(sv[e]);
+          if (!refine) { atomicAdd(&lh[b], 1u); cnt++; }
+          else if (b == rbin) {
+            int sb = (int)((sv[e] - rlo) * rinv);
+            sb = sb < 0 ? 0 : (sb > 1023 ? 1023 : sb);
+            atomicAdd(&lh[sb], 1u); cnt++;
+          }
+        }
       }
     }
     for (int sh = 1; sh < 64; sh <<= 1) cnt += (unsigned)__shfl_xor((int)cnt, sh, 64);
@@ -379,6 +394,36 @@ __global__ __launch_bounds__(1024) void eps_select_kernel(const unsigned long lo
     float thr = b >= 4094 ? __uint_as_float(0x7f800000u) : sur_bin_upper(b + 1);
     if (total == 0) thr = __uint_as_float(0x7f800000u);
     out3[0] = (unsigned long long)__float_as_uint(thr); out3[1] = total; out3[2] = (unsigned long long)b;
+  }
+  // for the refinement level: sample elements below the selected bin, and the target rank
+#pragma unroll
+  for (int u = 0; u < 4; u++) if (4 * t + u == bsel) out3[3] = part[t] - s + (u > 0 ? c[0] : 0) + (u > 1 ? c[1] : 0) + (u > 2 ? c[2] : 0);
+  if (t == 0) { out3[4] = target; if (bsel >= 4096) out3[3] = 0; }
+}
+
+// level 2: hist2 = 1024 sub-bins of coarse bin sel[2]; threshold = upper edge of the sub-bin AFTER the one where the cumulative
+// count (sel[3] + sub-bins) reaches the target sel[4] (one guard sub-bin, 4e-6 relative: ten times the surrogate error);
+// overwrites sel[0] when the bin was usable
+__global__ __launch_bounds__(1024) void eps_select2_kernel(const unsigned long long* __restrict__ hist2, unsigned long long* __restrict__ sel) {
+  __shared__ unsigned long long part[1024];
+  const int t = (int)threadIdx.x;
+  const unsigned long long c = hist2[t];
+  part[t] = c;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned long long add = t >= o ? part[t - o] : 0ull;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  const int b = (int)sel[2];
+  if (b < 1 || b >= 4094) return;                    // degenerate / open-ended bins keep the coarse threshold
+  const unsigned long long before = sel[3], target = sel[4];
+  const unsigned long long incl = before + part[t], excl = incl - c;
+  if (excl < target && incl >= target) {
+    const float lo = sur_bin_upper(b - 1), hi = sur_bin_upper(b);
+    const float thr = lo + (float)(t + 2) * ((hi - lo) * (1.f / 1024.f));
+    sel[0] = (unsigned long long)__float_as_uint(thr < sur_bin_upper(b + 1) ? thr : sur_bin_upper(b + 1));
   }
 }
 
@@ -850,12 +895,12 @@ extern "C" int ssg_eps_compact(const void* M, const uint16_t* v, int N, int row0
 
 // ---- K10 fast path (see eps_sample_hist_kernel): hist = 4097 uint64 zeroed by the caller; thr3 = 3 uint64 out
 extern "C" int ssg_eps_sample_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, int row_stride,
-                                   uint64_t* hist, hipStream_t stream) {
+                                   const uint64_t* refine, uint64_t* hist, hipStream_t stream) {
   int rc = check_view("ssg_eps_sample_hist", M, v, N, row0, nrows, mode); if (rc) return rc;
   if (row_stride < 1) { ssg_set_error("ssg_eps_sample_hist: row_stride must be >= 1"); return SSG_ERR_INVALID; }
   const int nsamp = (nrows + row_stride - 1) / row_stride;
 #define SSG_SH(MD) hipLaunchKernelGGL(eps_sample_hist_kernel<MD>, dim3(stream_grid(nsamp)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
-                     row_stride, (unsigned long long*)hist)
+                     row_stride, (const unsigned long long*)refine, (unsigned long long*)hist)
   if (mode == 0) SSG_SH(0); else if (mode == 1) SSG_SH(1); else SSG_SH(2);
 #undef SSG_SH
   SSG_LAUNCH_CHECK("eps_sample_hist_kernel");
@@ -865,6 +910,11 @@ extern "C" int ssg_eps_select_threshold(const uint64_t* hist, double quantile, u
   if (!(quantile > 0.0)) { ssg_set_error("ssg_eps_select_threshold: quantile must be positive"); return SSG_ERR_INVALID; }
   hipLaunchKernelGGL(eps_select_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)hist, quantile, (unsigned long long*)thr3);
   SSG_LAUNCH_CHECK("eps_select_kernel");
+  return SSG_OK;
+}
+extern "C" int ssg_eps_refine_threshold(const uint64_t* hist2, uint64_t* thr5, hipStream_t stream) {
+  hipLaunchKernelGGL(eps_select2_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)hist2, (unsigned long long*)thr5);
+  SSG_LAUNCH_CHECK("eps_select2_kernel");
   return SSG_OK;
 }
 extern "C" int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
