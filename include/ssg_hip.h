@@ -255,6 +255,11 @@ int ssg_set_jaccard_rows(const int32_t* a_idx, const int32_t* a_nnz, int capA, c
  * *overflow = number of queries with more than 2048 true matches (not evaluated). */
 int ssg_rank_metrics(const float* dist, int m, int n, int64_t ld, const int32_t* qid, const int32_t* qcam, const int32_t* gid,
                      const int32_t* gcam, int separate_cams, int32_t* first_rank, double* ap, int32_t* overflow, ssg_stream_t stream);
+/* the same plus the 'allshots' CMC bins (ranking.py:62-75 with first_match_break=False): nmatch[q] = valid true matches of query q,
+ * nm_before[q, s] (row stride nm_cap, s < min(nmatch[q], nm_cap)) = valid non-matching gallery entries ordered before its s-th match */
+int ssg_rank_metrics_all(const float* dist, int m, int n, int64_t ld, const int32_t* qid, const int32_t* qcam, const int32_t* gid,
+                         const int32_t* gcam, int separate_cams, int32_t* first_rank, double* ap, int32_t* overflow, int32_t* nm_before,
+                         int32_t* nmatch, int nm_cap, ssg_stream_t stream);
 
 /* ---- float32 re-ranking variant "re_ranking_init" (reid/rerank.py:171-234 == reid/rerank_initial.py:40-99) */
 /* out[i,j] = 2 - 2<x_i,y_j> (rerank.py:174-182); d % 32 == 0, n % 64 == 0; zeros = n floats of 0 */

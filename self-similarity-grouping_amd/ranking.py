@@ -3,9 +3,10 @@ reid/evaluators.py:88-129 (evaluate_all), :147-166 (Evaluator), computed on the 
 
 `cmc(...)`, `mean_ap(...)` and `evaluate_all(...)` keep the reference signatures and return types (numpy
 cumulative-match curve, float mAP, CMC top-1).  The distance block may be a numpy array, a CPU tensor or a CUDA
-tensor (the Evaluator keeps it on the device).  Supported protocol: the one evaluate_all uses (`first_match_break=True`,
-optionally `separate_camera_set`); the random `single_gallery_shot` protocol and the fractional 'allshots'
-accumulation are not part of the path and raise NotImplementedError.
+tensor (the Evaluator keeps it on the device).  Supported protocols: the deterministic ones -- 'market1501'
+(`first_match_break=True`, what evaluate_all uses) and 'allshots' (every match credited with 1/len), each optionally with
+`separate_camera_set`; the `single_gallery_shot` protocol draws random gallery subsets from numpy's global RNG
+(ranking.py:11-16,56-61; commented out in the reference's evaluate_all) and raises NotImplementedError.
 
 Equal distances are ordered by gallery index (numpy's default argsort leaves the tie order unspecified); mAP
 does not depend on it, and CMC only when a true match ties with a non-match.  No CPU fallback.
@@ -52,11 +53,47 @@ def per_query(distmat, query_ids=None, gallery_ids=None, query_cams=None, galler
     return first, ap
 
 
+def per_query_all(distmat, query_ids=None, gallery_ids=None, query_cams=None, gallery_cams=None, separate_camera_set=False):
+    """-> (nmatch int32[m], nm_before int32[m, cap]) numpy: per query the number of valid true matches and, for its s-th match,
+    the number of valid non-matching gallery entries ordered before it (the bins the all-shots CMC credits)."""
+    L = _lib.lib()
+    dev = _dev()
+    d = torch.as_tensor(distmat).to(dev, torch.float32)
+    if d.dim() != 2:
+        raise ValueError("distmat must be [m, n]")
+    if d.stride(1) != 1:
+        d = d.contiguous()
+    m, n = d.shape
+    qid = _ids(query_ids, m, np.arange, dev); gid = _ids(gallery_ids, n, np.arange, dev)
+    qcam = _ids(query_cams, m, lambda k: np.zeros(k), dev); gcam = _ids(gallery_cams, n, lambda k: np.ones(k), dev)
+    cap = int(min(2048, max(1, int(torch.bincount(gid.long()).max().item()))))      # no query can have more matches than the largest gallery identity
+    first = torch.empty(m, dtype=torch.int32, device=dev); ap = torch.empty(m, dtype=torch.float64, device=dev)
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    nmb = torch.zeros((m, cap), dtype=torch.int32, device=dev); nm = torch.zeros(m, dtype=torch.int32, device=dev)
+    check(L.ssg_rank_metrics_all(ptr(d), m, n, d.stride(0), ptr(qid), ptr(qcam), ptr(gid), ptr(gcam), 1 if separate_camera_set else 0,
+                                 ptr(first), ptr(ap), ptr(ovf), ptr(nmb), ptr(nm), cap, stream()), "ssg_rank_metrics_all")
+    if int(ovf.item()):
+        raise _lib.SSGError("ssg_rank_metrics: a query has more than 2048 true matches in the gallery")
+    return nm.cpu().numpy(), nmb.cpu().numpy()
+
+
 def cmc(distmat, query_ids=None, gallery_ids=None, query_cams=None, gallery_cams=None, topk=100,
         separate_camera_set=False, single_gallery_shot=False, first_match_break=False):
-    """ranking.py:18-79 for the first_match_break protocols."""
-    if single_gallery_shot or not first_match_break:
-        raise NotImplementedError("only the first_match_break protocols of evaluate_all ('market1501') run on the GPU path")
+    """ranking.py:18-79 for the deterministic protocols."""
+    if single_gallery_shot:
+        raise NotImplementedError("single_gallery_shot draws random gallery subsets from numpy's global RNG (ranking.py:11-16,56-61); "
+                                  "the deterministic protocols (first_match_break True/False, separate_camera_set) run on the GPU path")
+    if not first_match_break:
+        nm, nmb = per_query_all(distmat, query_ids, gallery_ids, query_cams, gallery_cams, separate_camera_set)
+        valid = nm > 0
+        if not valid.any():
+            raise RuntimeError("No valid query")
+        ret = np.zeros(topk)
+        for q in np.nonzero(valid)[0]:           # sequential adds in query / rank order, like the reference loop (ranking.py:68-75)
+            bins = nmb[q, :nm[q]]
+            bins = bins[: int(np.searchsorted(bins, topk, side="left"))]
+            np.add.at(ret, bins, 1. / nm[q])
+        return ret.cumsum() / int(valid.sum())
     first, _ = per_query(distmat, query_ids, gallery_ids, query_cams, gallery_cams, separate_camera_set)
     first = first.cpu().numpy()
     valid = first >= 0

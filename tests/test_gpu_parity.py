@@ -615,12 +615,13 @@ def test_rank_metrics_vs_reference_golden(golden, dev):
         assert np.nanmax(np.abs(ap.cpu().numpy() - ref_ap)) < 1e-12
         assert abs(ranking.mean_ap(*args) - float(g["map_" + tag])) < 1e-12
         assert np.array_equal(ranking.cmc(*args, first_match_break=True), g["cmc_" + tag])
+        assert np.array_equal(ranking.cmc(*args), g["cmc_all_" + tag]), "all-shots protocol (ranking.py defaults) vs the reference"
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
             top1 = ranking.evaluate_all(torch.from_numpy(args[0]).to(dev), query_ids=args[1], gallery_ids=args[2], query_cams=args[3], gallery_cams=args[4])
         assert top1 == g["cmc_" + tag][0] and "Mean AP" in buf.getvalue() and "top-1" in buf.getvalue()
     with pytest.raises(NotImplementedError):
-        ranking.cmc(*args)                      # fractional 'allshots' accumulation is not on the path
+        ranking.cmc(*args, single_gallery_shot=True)       # random gallery subsets from numpy's global RNG: not reproducible off the host
     with pytest.raises(RuntimeError):
         ranking.mean_ap(np.array([[0.1, 0.2, 0.3]], np.float32), [1], [1, 2, 3], [0], [0, 1, 1])
 
@@ -645,6 +646,9 @@ def test_rank_metrics_large_vs_oracle(dev):
     assert np.nanmax(np.abs(ap.cpu().numpy() - oap)) < 1e-12
     assert np.array_equal(ranking.cmc(dist, qid, gid, qcam, gcam, first_match_break=True, separate_camera_set=True),
                           eval_oracle.cmc(dist, qid, gid, qcam, gcam, first_match_break=True, separate_camera_set=True))
+    for sep in (False, True):        # all-shots protocol incl. exact ties between duplicated gallery rows
+        assert np.array_equal(ranking.cmc(dist, qid, gid, qcam, gcam, separate_camera_set=sep, topk=50),
+                              eval_oracle.cmc(dist, qid, gid, qcam, gcam, separate_camera_set=sep, topk=50)), sep
 
 
 def test_evaluator_dropin(golden, dev):
