@@ -1,0 +1,408 @@
+// bottleneck.hip -- one identity bottleneck block of the ResNet-50 backbone in ONE kernel (split-half path).
+//
+// reid/models/base.py:57-90 (torchvision Bottleneck without a downsample branch), eval mode, BatchNorm folded:
+//   out = relu( conv3_1x1( relu( conv2_3x3( relu( conv1_1x1(x) ) ) ) ) + x )
+// Run as three launches (conv.hip) a layer1 block moves 16 "units" of 64-channel activations through HBM (x is read by
+// conv1 and again as the residual, the two 64-channel intermediates are written and re-read) and its three GEMMs have short
+// reductions (K = 256 / 576 / 64): the launches sit at 4.4-4.9 TB/s or stall on their pipeline fill.  Here a workgroup owns
+// TH full-width image rows: it computes conv1 on TH+2 rows (one halo row above and below; the left/right halo is the zero
+// padding of conv2, never computed), keeps that intermediate in LDS in the split-half format, runs conv2 as an implicit GEMM
+// whose pixel operand is read from LDS (the 9 taps are 9 shifted fragment addresses), turns conv2's accumulators through LDS
+// again into the pixel operand of conv3 and finishes with bias + residual + ReLU + re-encoding.  HBM sees x once (plus the
+// halo rows, L2 hits for the neighbouring workgroup, plus the residual re-read, an L2 hit) and the output once.
+//
+// Numerics: the same three-product split-half multiply, the same reduction order and the same epilogues as the separate
+// launches (conv.hip), so the block output is bit-identical to the three-launch path.
+//
+// 4 waves, 2 workgroups per CU (<= 80 KB of LDS each).  All operand tiles are staged global -> registers -> LDS with the loads
+// several k-tiles ahead (register rings), one barrier per k-tile:
+//   phase 1  y1[(TH+2)*IW, MID] = relu(x W1^T)   k-tiles of 16 channels: x rows (64 B each) + W1 rows; wave = 3 x 1 MFMA tiles
+//   phase 2  y2[TH*IW, MID]     = relu(conv3x3(y1))   k-tiles = (32-channel chunk, tap): W2 rows (128 B); wave = 32 pixels x MID
+//   phase 3  out[TH*IW, C]      = relu(y2 W3^T + x)   k-tiles of 16 channels: W3 rows; wave = its own 32 pixels x all C channels
+#include "ssg_common.h"
+
+namespace ssg {
+namespace bneck {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // staging registers: arrays of HIP's float4 struct stay in scratch memory
+
+struct Params {
+  const float* x; float* out;
+  const float* w1; const float* b1; const float* cs1;   // [MID][C]      h8l8, rows pre-scaled by 1/cs1
+  const float* w2; const float* b2; const float* cs2;   // [MID][9*MID]  k = ((c/32)*9 + tap)*32 + c%32
+  const float* w3; const float* b3; const float* cs3;   // [C][MID]
+  int B, H;
+  int* overflow;
+};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int C, int MID, int IW, int TH>
+struct Cfg {
+  static constexpr int HROWS = TH + 2, NPIX1 = HROWS * IW, NPIX = TH * IW;
+  static constexpr int P1 = 80;                        // LDS pitch of a 64-byte k-tile row (pitch/16 odd: conflict-free b128)
+  static constexpr int P2 = 144;                       // ... of a 128-byte k-tile row
+  static constexpr int PY = MID * 4 + 16;              // ... of a y1 / y2 pixel row (all MID channels, h8l8)
+  static constexpr int BUF1 = (NPIX1 + MID) * P1;      // phase-1 stage: x rows, then W1 rows
+  static constexpr int ZERO_OFF = NPIX1 * PY;          // one all-zero pixel row (conv2's left / right padding)
+  static constexpr int W2_OFF = (ZERO_OFF + PY + 255) / 256 * 256, BUF2 = MID * P2;
+  static constexpr int W3_OFF = (NPIX * PY + 255) / 256 * 256, BUF3 = C * P1;
+  static constexpr int LDS = cmax(cmax(2 * BUF1, W2_OFF + 2 * BUF2), W3_OFF + 2 * BUF3);
+  static constexpr int NK1 = C / 16, NK2 = (MID / 32) * 9, NK3 = MID / 16;
+  static constexpr int PD1 = 4, PD2 = 6;               // k-tiles of global loads in flight ahead of the multiply
+  static_assert(NPIX == 128 && NPIX1 % 64 == 0 && MID % 64 == 0 && C % 64 == 0, "4 waves x 32 output pixels");
+  static_assert(2 * BUF1 <= ZERO_OFF, "the zero row is written while phase 1 runs");
+  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+};
+
+__device__ __forceinline__ unsigned pack2(_Float16 a, _Float16 b) {
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+__device__ __forceinline__ void encode4(const float4 v, uint2& hi, uint2& lo) {
+  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+  hi = make_uint2(pack2(h0, h1), pack2(h2, h3));
+  lo = make_uint2(pack2((_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1)), pack2((_Float16)(v.z - (float)h2), (_Float16)(v.w - (float)h3)));
+}
+// bits 15 / 31 of the result are set when a hi half is infinite or NaN (exponent field all ones: + 0x0400 carries into the sign
+// position, nothing smaller does); OR-accumulated over the kernel and tested once at the end
+__device__ __forceinline__ unsigned hi_nonfinite_bits(const uint2 hi) {
+  return ((hi.x & 0x7c007c00u) + 0x04000400u) | ((hi.y & 0x7c007c00u) + 0x04000400u);
+}
+__device__ __forceinline__ float hlo(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float hhi(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+__device__ __forceinline__ float4 decode4(const uint2 hi, const uint2 lo) {
+  return make_float4(hlo(hi.x) + hlo(lo.x), hhi(hi.x) + hhi(lo.x), hlo(hi.y) + hlo(lo.y), hhi(hi.y) + hhi(lo.y));
+}
+__device__ __forceinline__ float4 relu4(float4 v) {
+  return make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+}
+// x*w = xh*wl + xl*wh + xh*wh (the order of conv.hip's split_mma_step), weights as the first MFMA operand:
+// C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> channel
+
+template <int C, int MID, int IW, int TH>
+__global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
+  using K = Cfg<C, MID, IW, TH>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
+  const int tiles_img = p.H / TH, ntiles = p.B * tiles_img;
+  int T;
+  {   // workgroups are dealt round-robin to the 8 XCDs: give every XCD a contiguous run of tiles (halo rows hit its L2)
+    const int b = (int)blockIdx.x, q = ntiles / 8, r = ntiles % 8, x = b % 8, s = b / 8;
+    T = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
+  }
+  const int img = T / tiles_img, ty0 = (T - img * tiles_img) * TH;
+  if (tid < K::PY / 16) *reinterpret_cast<uint4*>(smem + K::ZERO_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  // =========================== phase 1: y1 = relu(conv1(x)) on the TH+2 halo rows ===========================
+  constexpr int AU = K::NPIX1 / 64, WU = MID / 64;          // 16-byte pieces per thread and k-tile: x rows, W1 rows
+  const int ck = tid & 3, r0 = tid >> 2;
+  const float* ximg = p.x + (int64_t)img * p.H * IW * C;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (unsigned)(p.H * IW * C * 4), 0x00020000);
+  unsigned aoff[AU];
+#pragma unroll
+  for (int u = 0; u < AU; u++) {
+    const int pix = (ty0 - 1) * IW + r0 + 64 * u;           // rows above / below the image: out-of-range offset -> the load returns zeros
+    aoff[u] = (pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * C + ck * 4) * 4) : 0x80000000u;
+  }
+  const float* w1p = p.w1 + (int64_t)r0 * C + ck * 4;
+  v4f sa[K::PD1][AU], sw[K::PD1][WU];
+#define SSG_BN_LOAD1(T_, S_)                                                                                         \
+  {                                                                                                                  \
+    _Pragma("unroll") for (int u = 0; u < AU; u++) {                                                                  \
+      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[u], (T_) * 64, 0);                            \
+      sa[S_][u] = __builtin_bit_cast(v4f, raw);                                                                     \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < WU; u++) sw[S_][u] = *reinterpret_cast<const v4f*>(w1p + (int64_t)(64 * u) * C + (T_) * 16); \
+  }
+#define SSG_BN_STORE1(BUF_, S_)                                                                                      \
+  {                                                                                                                  \
+    unsigned char* sb_ = smem + (BUF_) * K::BUF1;                                                                    \
+    _Pragma("unroll") for (int u = 0; u < AU; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + 64 * u) * K::P1 + ck * 16) = sa[S_][u]; \
+    _Pragma("unroll") for (int u = 0; u < WU; u++) *reinterpret_cast<v4f*>(sb_ + (K::NPIX1 + r0 + 64 * u) * K::P1 + ck * 16) = sw[S_][u]; \
+  }
+  // MFMA tiles of phase 1: (NPIX1/32) pixel tiles x (MID/32) channel tiles over 4 waves
+  constexpr int MT1 = K::NPIX1 / 32, NT1 = MID / 32;
+  // waves are split as WR x WC with WC = min(NT1, 2): each wave owns MT1/WR pixel tiles x NT1/WC channel tiles
+  constexpr int WC1 = NT1 >= 2 ? 2 : 1, WR1 = 4 / WC1, MTW1 = MT1 / WR1, NTW1 = NT1 / WC1;
+  static_assert(MT1 % WR1 == 0 && NT1 % WC1 == 0, "phase-1 tiles divide over the waves");
+  const int i1b = (wave / WC1) * MTW1, j1b = (wave % WC1) * NTW1;
+  v16f acc1[MTW1][NTW1];
+#pragma unroll
+  for (int i = 0; i < MTW1; i++)
+#pragma unroll
+    for (int j = 0; j < NTW1; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc1[i][j][r] = 0.f;
+#define SSG_BN_MMA1(BUF_)                                                                                            \
+  {                                                                                                                  \
+    const unsigned char* sb_ = smem + (BUF_) * K::BUF1;                                                              \
+    v8h xh_[MTW1], xl_[MTW1], wh_[NTW1], wl_[NTW1];                                                                  \
+    _Pragma("unroll") for (int i = 0; i < MTW1; i++) {                                                               \
+      const unsigned char* q_ = sb_ + ((i1b + i) * 32 + l32) * K::P1 + h * 32;                                       \
+      xh_[i] = *reinterpret_cast<const v8h*>(q_); xl_[i] = *reinterpret_cast<const v8h*>(q_ + 16); }                 \
+    _Pragma("unroll") for (int j = 0; j < NTW1; j++) {                                                               \
+      const unsigned char* q_ = sb_ + (K::NPIX1 + (j1b + j) * 32 + l32) * K::P1 + h * 32;                            \
+      wh_[j] = *reinterpret_cast<const v8h*>(q_); wl_[j] = *reinterpret_cast<const v8h*>(q_ + 16); }                 \
+    _Pragma("unroll") for (int i = 0; i < MTW1; i++) _Pragma("unroll") for (int j = 0; j < NTW1; j++)                \
+      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xl_[i], acc1[i][j], 0, 0, 0);                      \
+    _Pragma("unroll") for (int i = 0; i < MTW1; i++) _Pragma("unroll") for (int j = 0; j < NTW1; j++)                \
+      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[j], xh_[i], acc1[i][j], 0, 0, 0);                      \
+    _Pragma("unroll") for (int i = 0; i < MTW1; i++) _Pragma("unroll") for (int j = 0; j < NTW1; j++)                \
+      acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xh_[i], acc1[i][j], 0, 0, 0);                      \
+  }
+  // the register set of a tile is a LITERAL index (kt % PD1 of an unrolled loop variable leaves the rings in scratch memory)
+#define SSG_BN_STEP1(KT_, S_)                                                                                        \
+  {                                                                                                                  \
+    if ((KT_) + K::PD1 < K::NK1) SSG_BN_LOAD1((KT_) + K::PD1, S_)   /* the set of tile KT_ went to LDS one step ago */ \
+    SSG_BN_MMA1((S_) & 1)                                                                                            \
+    if ((KT_) + 1 < K::NK1) SSG_BN_STORE1(((S_) + 1) & 1, ((S_) + 1) % K::PD1)                                        \
+    __syncthreads();                                                                                                 \
+  }
+  static_assert(K::PD1 == 4 && K::NK1 % 4 == 0, "phase-1 ring of four register sets");
+  SSG_BN_LOAD1(0, 0) SSG_BN_LOAD1(1, 1) SSG_BN_LOAD1(2, 2) SSG_BN_LOAD1(3, 3)
+  SSG_BN_STORE1(0, 0)
+  __syncthreads();
+#pragma unroll
+  for (int kt0 = 0; kt0 < K::NK1; kt0 += 4) { SSG_BN_STEP1(kt0, 0) SSG_BN_STEP1(kt0 + 1, 1) SSG_BN_STEP1(kt0 + 2, 2) SSG_BN_STEP1(kt0 + 3, 3) }
+#undef SSG_BN_STEP1
+#undef SSG_BN_LOAD1
+#undef SSG_BN_STORE1
+#undef SSG_BN_MMA1
+
+  // ---- conv2 weights: first k-tiles on their way while y1 is written
+  constexpr int BU = MID / 32;                              // 16-byte pieces per thread and W2 k-tile (MID rows x 128 B)
+  const int ck8 = tid & 7, r8 = tid >> 3;
+  const float* w2p = p.w2 + (int64_t)r8 * (9 * MID) + ck8 * 4;
+  v4f sb2[K::PD2][BU];
+#define SSG_BN_LOAD2(T_, S_)                                                                                         \
+  { _Pragma("unroll") for (int u = 0; u < BU; u++) sb2[S_][u] = *reinterpret_cast<const v4f*>(w2p + (int64_t)(32 * u) * (9 * MID) + (T_) * 32); }
+#define SSG_BN_STORE2(BUF_, S_)                                                                                      \
+  { unsigned char* sb_ = smem + K::W2_OFF + (BUF_) * K::BUF2;                                                        \
+    _Pragma("unroll") for (int u = 0; u < BU; u++) *reinterpret_cast<v4f*>(sb_ + (r8 + 32 * u) * K::P2 + ck8 * 16) = sb2[S_][u]; }
+  static_assert(K::PD2 == 6 && K::NK2 % 6 == 0, "phase-2 ring of six register sets");
+  SSG_BN_LOAD2(0, 0) SSG_BN_LOAD2(1, 1) SSG_BN_LOAD2(2, 2) SSG_BN_LOAD2(3, 3) SSG_BN_LOAD2(4, 4) SSG_BN_LOAD2(5, 5)
+
+  // ---- y1 -> LDS (h8l8 pixel rows).  Rows outside the image are conv2's zero padding, not relu(bias).
+  unsigned ovf = 0u;
+#pragma unroll
+  for (int i = 0; i < MTW1; i++) {
+    const int hp0 = (i1b + i) * 32;                         // first halo pixel of this MFMA tile
+    const int irow = ty0 - 1 + (hp0 + l32) / IW;
+    const bool inside = irow >= 0 && irow < p.H;
+#pragma unroll
+    for (int j = 0; j < NTW1; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int ch = (j1b + j) * 32 + 8 * q + 4 * h;
+        const float4 cs = *reinterpret_cast<const float4*>(p.cs1 + ch), bi = *reinterpret_cast<const float4*>(p.b1 + ch);
+        float4 v = make_float4(acc1[i][j][4 * q] * cs.x + bi.x, acc1[i][j][4 * q + 1] * cs.y + bi.y, acc1[i][j][4 * q + 2] * cs.z + bi.z,
+                               acc1[i][j][4 * q + 3] * cs.w + bi.w);
+        v = relu4(v);
+        if (!inside) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint2 hi, lo;
+        encode4(v, hi, lo);
+        ovf |= hi_nonfinite_bits(hi);
+        unsigned char* d = smem + (hp0 + l32) * K::PY + (ch >> 3) * 32 + h * 8;
+        *reinterpret_cast<uint2*>(d) = hi; *reinterpret_cast<uint2*>(d + 16) = lo;
+      }
+  }
+  SSG_BN_STORE2(0, 0)
+  __syncthreads();
+
+  // =========================== phase 2: y2 = relu(conv2_3x3(y1)), pixel operand from LDS ===========================
+  constexpr int NT2 = MID / 32;
+  v16f acc2[NT2];
+#pragma unroll
+  for (int j = 0; j < NT2; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc2[j][r] = 0.f;
+  const int m2 = wave * 32 + l32, ty2 = m2 / IW, tx2 = m2 - ty2 * IW;      // this lane's output pixel (tile-local)
+#define SSG_BN_STEP2(KT_, S_)                                                                                        \
+  {                                                                                                                  \
+    if ((KT_) + K::PD2 < K::NK2) SSG_BN_LOAD2((KT_) + K::PD2, S_)                                                     \
+    {                                                                                                                \
+      const int chunk = (KT_) / 9, tap = (KT_) - chunk * 9, r = tap / 3, s = tap - r * 3;                            \
+      const int xin = tx2 + s - 1;                                                                                   \
+      const int abase = (xin >= 0 && xin < IW) ? ((ty2 + r) * IW + xin) * K::PY : K::ZERO_OFF;                       \
+      const unsigned char* wb = smem + K::W2_OFF + ((S_) & 1) * K::BUF2 + l32 * K::P2 + h * 32;                      \
+      v8h xh_[2], xl_[2], wh_[2][NT2], wl_[2][NT2];                                                                  \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {                                                             \
+        const unsigned char* q_ = smem + abase + (chunk * 4 + ks * 2 + h) * 32;                                      \
+        xh_[ks] = *reinterpret_cast<const v8h*>(q_); xl_[ks] = *reinterpret_cast<const v8h*>(q_ + 16);               \
+        _Pragma("unroll") for (int j = 0; j < NT2; j++) {                                                            \
+          wh_[ks][j] = *reinterpret_cast<const v8h*>(wb + j * 32 * K::P2 + ks * 64);                                 \
+          wl_[ks][j] = *reinterpret_cast<const v8h*>(wb + j * 32 * K::P2 + ks * 64 + 16); }                          \
+      }                                                                                                              \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {                                                             \
+        _Pragma("unroll") for (int j = 0; j < NT2; j++) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[ks][j], xl_[ks], acc2[j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NT2; j++) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[ks][j], xh_[ks], acc2[j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NT2; j++) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[ks][j], xh_[ks], acc2[j], 0, 0, 0); \
+      }                                                                                                              \
+    }                                                                                                                \
+    if ((KT_) + 1 < K::NK2) SSG_BN_STORE2(((S_) + 1) & 1, ((S_) + 1) % K::PD2)                                        \
+    __syncthreads();                                                                                                 \
+  }
+#pragma unroll
+  for (int kt0 = 0; kt0 < K::NK2; kt0 += 6) {
+    SSG_BN_STEP2(kt0, 0) SSG_BN_STEP2(kt0 + 1, 1) SSG_BN_STEP2(kt0 + 2, 2) SSG_BN_STEP2(kt0 + 3, 3) SSG_BN_STEP2(kt0 + 4, 4) SSG_BN_STEP2(kt0 + 5, 5)
+  }
+#undef SSG_BN_STEP2
+#undef SSG_BN_LOAD2
+#undef SSG_BN_STORE2
+
+  // ---- conv3 weights: k-tiles 0 and 1 on their way while y2 is written (every wave is past its last y1 / W2 read)
+  constexpr int CU3 = C / 64;                               // 16-byte pieces per thread and W3 k-tile (C rows x 64 B)
+  const float* w3p = p.w3 + (int64_t)r0 * MID + ck * 4;
+  v4f sc3[2][CU3];
+#define SSG_BN_LOAD3(T_, S_)                                                                                         \
+  { _Pragma("unroll") for (int u = 0; u < CU3; u++) sc3[S_][u] = *reinterpret_cast<const v4f*>(w3p + (int64_t)(64 * u) * MID + (T_) * 16); }
+#define SSG_BN_STORE3(BUF_, S_)                                                                                      \
+  { unsigned char* sb_ = smem + K::W3_OFF + (BUF_) * K::BUF3;                                                        \
+    _Pragma("unroll") for (int u = 0; u < CU3; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + 64 * u) * K::P1 + ck * 16) = sc3[S_][u]; }
+  SSG_BN_LOAD3(0, 0)
+  SSG_BN_LOAD3(1, 1)
+  // y2 rows of this wave's 32 pixels (written and read by this wave only)
+  unsigned char* myrows = smem + (wave * 32) * K::PY;
+#pragma unroll
+  for (int j = 0; j < NT2; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int ch = j * 32 + 8 * q + 4 * h;
+      const float4 cs = *reinterpret_cast<const float4*>(p.cs2 + ch), bi = *reinterpret_cast<const float4*>(p.b2 + ch);
+      float4 v = make_float4(acc2[j][4 * q] * cs.x + bi.x, acc2[j][4 * q + 1] * cs.y + bi.y, acc2[j][4 * q + 2] * cs.z + bi.z, acc2[j][4 * q + 3] * cs.w + bi.w);
+      v = relu4(v);
+      uint2 hi, lo;
+      encode4(v, hi, lo);
+      ovf |= hi_nonfinite_bits(hi);
+      unsigned char* d = myrows + l32 * K::PY + (ch >> 3) * 32 + h * 8;
+      *reinterpret_cast<uint2*>(d) = hi; *reinterpret_cast<uint2*>(d + 16) = lo;
+    }
+
+  // =========================== phase 3: out = relu(conv3(y2) + x) ===========================
+  constexpr int NT3 = C / 32;
+  static_assert(K::NK3 == 4, "phase 3 is written for MID = 64 (4 k-tiles in two rounds of two buffers)");
+  v16f acc3[NT3];
+#pragma unroll
+  for (int j = 0; j < NT3; j++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc3[j][r] = 0.f;
+#define SSG_BN_MMA3K(BUF_, KT_)                                                                                      \
+  {                                                                                                                  \
+    const unsigned char* q_ = myrows + l32 * K::PY + ((KT_) * 2 + h) * 32;                                           \
+    const v8h xh_ = *reinterpret_cast<const v8h*>(q_), xl_ = *reinterpret_cast<const v8h*>(q_ + 16);                 \
+    const unsigned char* wb_ = smem + K::W3_OFF + (BUF_) * K::BUF3 + l32 * K::P1 + h * 32;                           \
+    _Pragma("unroll") for (int jj = 0; jj < NT3; jj += 4) {                                                          \
+      v8h wh_[4], wl_[4];                                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                \
+        wh_[j] = *reinterpret_cast<const v8h*>(wb_ + (jj + j) * 32 * K::P1); wl_[j] = *reinterpret_cast<const v8h*>(wb_ + (jj + j) * 32 * K::P1 + 16); } \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) acc3[jj + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xl_, acc3[jj + j], 0, 0, 0); \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) acc3[jj + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[j], xh_, acc3[jj + j], 0, 0, 0); \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) acc3[jj + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xh_, acc3[jj + j], 0, 0, 0); \
+    }                                                                                                                \
+  }
+  SSG_BN_STORE3(0, 0)
+  SSG_BN_STORE3(1, 1)
+  SSG_BN_LOAD3(2, 0)
+  SSG_BN_LOAD3(3, 1)
+  __syncthreads();
+  SSG_BN_MMA3K(0, 0)
+  SSG_BN_MMA3K(1, 1)
+  __syncthreads();
+  SSG_BN_STORE3(0, 0)
+  SSG_BN_STORE3(1, 1)
+  __syncthreads();
+  SSG_BN_MMA3K(0, 2)
+  SSG_BN_MMA3K(1, 3)
+#undef SSG_BN_LOAD3
+#undef SSG_BN_STORE3
+#undef SSG_BN_MMA3K
+
+  // ---- epilogue: per channel tile a 32-pixel x 32-channel patch through LDS (this wave's own, now dead, y2 rows), then
+  // whole 128-byte row segments: bias, residual (x, h8l8), ReLU, re-encode, store.  Same code path as conv.hip.
+  constexpr int EP = 36, CPR = 8, RPI = 8, ITS = 4;
+  static_assert(32 * EP * 4 <= 32 * K::PY, "patch fits in the wave's y2 rows");
+  float* patch = reinterpret_cast<float*>(myrows);
+  const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
+  const int64_t gpix0 = ((int64_t)img * p.H + ty0) * IW + wave * 32;       // first output pixel of this wave (pixels are contiguous)
+  const float* __restrict__ resp = p.x + gpix0 * C;
+  float* __restrict__ outp = p.out + gpix0 * C;
+  float4 rr[2][ITS];
+#pragma unroll
+  for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + chunk * 4);
+#pragma unroll
+  for (int j = 0; j < NT3; j++) {
+    const int col = j * 32 + chunk * 4;
+    if (j + 1 < NT3) {
+#pragma unroll
+      for (int it = 0; it < ITS; it++) rr[(j + 1) & 1][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + col + 32);
+    }
+    const float4 bias = *reinterpret_cast<const float4*>(p.b3 + col), cs = *reinterpret_cast<const float4*>(p.cs3 + col);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      *reinterpret_cast<float4*>(patch + l32 * EP + 8 * q + 4 * h) = make_float4(acc3[j][4 * q], acc3[j][4 * q + 1], acc3[j][4 * q + 2], acc3[j][4 * q + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int it = 0; it < ITS; it++) {
+      const int pr = it * RPI + prow;
+      float4 v = *reinterpret_cast<const float4*>(patch + pr * EP + chunk * 4);
+      v.x = v.x * cs.x + bias.x; v.y = v.y * cs.y + bias.y; v.z = v.z * cs.z + bias.z; v.w = v.w * cs.w + bias.w;
+      const float4 rw = rr[j & 1][it];
+      float4 r4;
+      {   // even lane holds hi0..7 of the 8-channel group, odd lane lo0..7; each needs hi and lo of ITS four channels
+        // (component-wise selects: a select between uint2 / float4 aggregates goes through scratch memory)
+        const unsigned a0 = __float_as_uint(rw.x), a1 = __float_as_uint(rw.y), a2 = __float_as_uint(rw.z), a3 = __float_as_uint(rw.w);
+        const unsigned g0 = (unsigned)__shfl_xor((int)(odd ? a0 : a2), 1, 64), g1 = (unsigned)__shfl_xor((int)(odd ? a1 : a3), 1, 64);
+        const unsigned h0 = odd ? g0 : a0, h1 = odd ? g1 : a1, l0 = odd ? a2 : g0, l1 = odd ? a3 : g1;
+        r4 = decode4(make_uint2(h0, h1), make_uint2(l0, l1));
+      }
+      v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      v = relu4(v);
+      uint2 hp, lp;
+      encode4(v, hp, lp);
+      ovf |= hi_nonfinite_bits(hp);
+      const unsigned rx = (unsigned)__shfl_xor((int)(odd ? hp.x : lp.x), 1, 64), ry = (unsigned)__shfl_xor((int)(odd ? hp.y : lp.y), 1, 64);
+      const uint4 stv = make_uint4(odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry);
+      *reinterpret_cast<uint4*>(outp + (int64_t)pr * C + col) = stv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if ((ovf & 0x80008000u) && p.overflow) *p.overflow = 1;
+}
+
+}  // namespace bneck
+}  // namespace ssg
+
+// 1 when ssg_bottleneck_nhwc_x has a kernel for this block shape
+extern "C" int ssg_bottleneck_supported(int H, int W, int C, int MID) {
+  return (C == 256 && MID == 64 && W == 32 && H > 0 && H % 4 == 0) ? 1 : 0;
+}
+
+// Identity bottleneck block (no downsample branch, stride 1), split-half tensors:
+//   out = relu(conv3(relu(conv2(relu(conv1(x))))) + x),  x / out [B,H,W,C] h8l8, weights as ssg_conv2d_nhwc_x takes them
+//   (w1 [MID][C], w2 [MID][9*MID] in the k = (32-channel chunk, tap, channel) order, w3 [C][MID], each row pre-multiplied by a
+//   power of two that ch_scale* undoes), biases fp32.  out must not alias x (halo rows are read by other workgroups).
+extern "C" int ssg_bottleneck_nhwc_x(const void* x, const void* w1, const float* b1, const float* cs1, const void* w2, const float* b2, const float* cs2,
+                                     const void* w3, const float* b3, const float* cs3, void* out, int B, int H, int W, int C, int MID,
+                                     int32_t* overflow, hipStream_t stream) {
+  using namespace ssg::bneck;
+  if (B <= 0 || !ssg_bottleneck_supported(H, W, C, MID) || !cs1 || !cs2 || !cs3 || x == out) {
+    ssg_set_error("ssg_bottleneck_nhwc_x: unsupported block B=%d H=%d W=%d C=%d MID=%d (see ssg_bottleneck_supported)", B, H, W, C, MID);
+    return SSG_ERR_INVALID;
+  }
+  Params p;
+  p.x = (const float*)x; p.out = (float*)out;
+  p.w1 = (const float*)w1; p.b1 = b1; p.cs1 = cs1; p.w2 = (const float*)w2; p.b2 = b2; p.cs2 = cs2; p.w3 = (const float*)w3; p.b3 = b3; p.cs3 = cs3;
+  p.B = B; p.H = H; p.overflow = overflow;
+  using K = Cfg<256, 64, 32, 4>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SSG_HIP(hipFuncSetAttribute((const void*)bottleneck_kernel<256, 64, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bottleneck_kernel<256, 64, 32, 4>), dim3(B * (H / 4)), dim3(256), K::LDS, stream, p);
+  SSG_LAUNCH_CHECK("bottleneck_kernel");
+  return SSG_OK;
+}

@@ -304,6 +304,19 @@ class ResNet:
                                         flags, ds.acc_scale, ptr(getattr(ds, "cscale", None)), ptr(ovf), stream()), "ssg_conv1x1_dual_nhwc_x")
         return out
 
+    @staticmethod
+    def _bottleneck(L, y, blk, ovf=None):
+        """identity block in one launch (ssg_bottleneck_nhwc_x); None when there is no fused kernel for this shape"""
+        B, H, W, C = y.shape
+        c1, c2, c3 = blk["c1"], blk["c2"], blk["c3"]
+        if os.environ.get("SSG_FUSED_BOTTLENECK", "1") == "0" or not L.ssg_bottleneck_supported(H, W, C, c1.cout):
+            return None
+        out = torch.empty_like(y)
+        check(L.ssg_bottleneck_nhwc_x(ptr(y), ptr(c1.w), ptr(c1.bias), ptr(c1.cscale), ptr(c2.w), ptr(c2.bias), ptr(c2.cscale),
+                                      ptr(c3.w), ptr(c3.bias), ptr(c3.cscale), ptr(out), B, H, W, C, c1.cout, ptr(ovf), stream()),
+              "ssg_bottleneck_nhwc_x")
+        return out
+
     def _fmap(self, x, flip=False):
         """-> (layer4 map [B,h,w,2048], is_split): with precision='split' the float32 tensor is a container of
         h8l8 split halves (decode with ssg_h8l8_decode)."""
@@ -329,6 +342,11 @@ class ResNet:
             check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
         y = p
         for blk in net["blocks"]:
+            if sp and blk["ds"] is None:
+                fused = self._bottleneck(L, y, blk, ovf)
+                if fused is not None:
+                    y = fused
+                    continue
             o = self._conv(L, y, blk["c1"], out_split=sp, ovf=ovf)
             o = self._conv(L, o, blk["c2"], out_split=sp, ovf=ovf)
             if blk["ds"] is not None:

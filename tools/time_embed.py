@@ -33,9 +33,9 @@ def main():
         rows = []
         orig = resnet.ResNet._conv
 
-        def timed(L_, x_, f, res=None, relu=True, out_split=False):
+        def timed(L_, x_, f, res=None, relu=True, out_split=False, ovf=None):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); out = orig(L_, x_, f, res, relu, out_split); e1.record(); e1.synchronize()
+            e0.record(); out = orig(L_, x_, f, res, relu, out_split, ovf); e1.record(); e1.synchronize()
             B, H, W, _ = x_.shape
             flop = 2.0 * out.numel() * f.k * f.k * (3 if f.cin == 4 else f.cin)
             byt = 4.0 * (x_.numel() + out.numel() * (2 if res is not None else 1) + f.w.numel())
@@ -43,9 +43,9 @@ def main():
             return out
         orig_d = resnet.ResNet._conv_dual
 
-        def timed_d(L_, o, x_, c3, ds, out_split=False):
+        def timed_d(L_, o, x_, c3, ds, out_split=False, ovf=None):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); out = orig_d(L_, o, x_, c3, ds, out_split); e1.record(); e1.synchronize()
+            e0.record(); out = orig_d(L_, o, x_, c3, ds, out_split, ovf); e1.record(); e1.synchronize()
             B, H, W, _ = o.shape
             flop = 2.0 * out.numel() * (c3.cin + ds.cin)
             byt = 4.0 * (o.numel() + x_.numel() / (ds.stride ** 2) + out.numel() + ds.w.numel())
