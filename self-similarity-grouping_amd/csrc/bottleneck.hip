@@ -8,8 +8,11 @@
 // TH full-width image rows: it computes conv1 on TH+2 rows (one halo row above and below; the left/right halo is the zero
 // padding of conv2, never computed), keeps that intermediate in LDS in the split-half format, runs conv2 as an implicit GEMM
 // whose pixel operand is read from LDS (the 9 taps are 9 shifted fragment addresses), turns conv2's accumulators through LDS
-// again into the pixel operand of conv3 and finishes with bias + residual + ReLU + re-encoding.  HBM sees x once (plus the
-// halo rows, L2 hits for the neighbouring workgroup, plus the residual re-read, an L2 hit) and the output once.
+// again into the pixel operand of conv3 and finishes with bias + residual + ReLU + re-encoding.  Measured (TCC_EA0_RDREQ): the
+// L2 fetches 2.07 x |x| per launch -- x once, the halo rows mostly L2 hits of the neighbouring workgroup, and the residual
+// re-read (14 us after phase 1, 64 workgroups streaming through each 4 MB L2) once more from HBM -- and writes |out| once:
+// 3.1 units against the 16 of the three launches.  (Keeping the residual lines recent with touch loads during phase 2 does not
+// work: the touches already miss.)
 //
 // Numerics: the same three-product split-half multiply, the same reduction order and the same epilogues as the separate
 // launches (conv.hip), so the block output is bit-identical to the three-launch path.
@@ -36,7 +39,13 @@ struct Params {
   const float* w3; const float* b3; const float* cs3;   // [C][MID]
   int B, H;
   int* overflow;
+  unsigned long long* prof = nullptr;   // SSG_BN_PROF builds: 8 phase timestamps (s_memtime) per workgroup
 };
+#ifdef SSG_BN_PROF
+#define SSG_BN_STAMP(I_) { if (p.prof && threadIdx.x == 0) p.prof[(size_t)blockIdx.x * 8 + (I_)] = __builtin_readcyclecounter(); }
+#else
+#define SSG_BN_STAMP(I_)
+#endif
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -52,7 +61,7 @@ struct Cfg {
   static constexpr int W3_OFF = (NPIX * PY + 255) / 256 * 256, BUF3 = C * P1;
   static constexpr int LDS = cmax(cmax(2 * BUF1, W2_OFF + 2 * BUF2), W3_OFF + 2 * BUF3);
   static constexpr int NK1 = C / 16, NK2 = (MID / 32) * 9, NK3 = MID / 16;
-  static constexpr int PD1 = 4, PD2 = 6;               // k-tiles of global loads in flight ahead of the multiply
+  static constexpr int PD1 = 8, PD2 = 6;               // (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)               // k-tiles of global loads in flight ahead of the multiply
   static_assert(NPIX == 128 && NPIX1 % 64 == 0 && MID % 64 == 0 && C % 64 == 0, "4 waves x 32 output pixels");
   static_assert(2 * BUF1 <= ZERO_OFF, "the zero row is written while phase 1 runs");
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
@@ -94,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
     T = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + s;
   }
   const int img = T / tiles_img, ty0 = (T - img * tiles_img) * TH;
+  SSG_BN_STAMP(0)
   if (tid < K::PY / 16) *reinterpret_cast<uint4*>(smem + K::ZERO_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
   // =========================== phase 1: y1 = relu(conv1(x)) on the TH+2 halo rows ===========================
@@ -161,13 +171,25 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
     if ((KT_) + 1 < K::NK1) SSG_BN_STORE1(((S_) + 1) & 1, ((S_) + 1) % K::PD1)                                        \
     __syncthreads();                                                                                                 \
   }
-  static_assert(K::PD1 == 4 && K::NK1 % 4 == 0, "phase-1 ring of four register sets");
-  SSG_BN_LOAD1(0, 0) SSG_BN_LOAD1(1, 1) SSG_BN_LOAD1(2, 2) SSG_BN_LOAD1(3, 3)
+  static_assert(K::PD1 == 8 && K::NK1 % 8 == 0, "phase-1 ring of eight register sets");
+  SSG_BN_LOAD1(0, 0) SSG_BN_LOAD1(1, 1) SSG_BN_LOAD1(2, 2) SSG_BN_LOAD1(3, 3) SSG_BN_LOAD1(4, 4) SSG_BN_LOAD1(5, 5) SSG_BN_LOAD1(6, 6) SSG_BN_LOAD1(7, 7)
+  // folded BatchNorm scale / bias of this wave's conv1 channels (needed after the loop: no L2 round trip there)
+  float4 cs1r[NTW1][4], b1r[NTW1][4];
+#pragma unroll
+  for (int j = 0; j < NTW1; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      cs1r[j][q] = *reinterpret_cast<const float4*>(p.cs1 + (j1b + j) * 32 + 8 * q + 4 * h); b1r[j][q] = *reinterpret_cast<const float4*>(p.b1 + (j1b + j) * 32 + 8 * q + 4 * h);
+    }
   SSG_BN_STORE1(0, 0)
   __syncthreads();
 #pragma unroll
-  for (int kt0 = 0; kt0 < K::NK1; kt0 += 4) { SSG_BN_STEP1(kt0, 0) SSG_BN_STEP1(kt0 + 1, 1) SSG_BN_STEP1(kt0 + 2, 2) SSG_BN_STEP1(kt0 + 3, 3) }
+  for (int kt0 = 0; kt0 < K::NK1; kt0 += 8) {
+    SSG_BN_STEP1(kt0, 0) SSG_BN_STEP1(kt0 + 1, 1) SSG_BN_STEP1(kt0 + 2, 2) SSG_BN_STEP1(kt0 + 3, 3)
+    SSG_BN_STEP1(kt0 + 4, 4) SSG_BN_STEP1(kt0 + 5, 5) SSG_BN_STEP1(kt0 + 6, 6) SSG_BN_STEP1(kt0 + 7, 7)
+  }
 #undef SSG_BN_STEP1
+  SSG_BN_STAMP(1)
 #undef SSG_BN_LOAD1
 #undef SSG_BN_STORE1
 #undef SSG_BN_MMA1
@@ -197,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int ch = (j1b + j) * 32 + 8 * q + 4 * h;
-        const float4 cs = *reinterpret_cast<const float4*>(p.cs1 + ch), bi = *reinterpret_cast<const float4*>(p.b1 + ch);
+        const float4 cs = cs1r[j][q], bi = b1r[j][q];
         float4 v = make_float4(acc1[i][j][4 * q] * cs.x + bi.x, acc1[i][j][4 * q + 1] * cs.y + bi.y, acc1[i][j][4 * q + 2] * cs.z + bi.z,
                                acc1[i][j][4 * q + 3] * cs.w + bi.w);
         v = relu4(v);
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   }
   SSG_BN_STORE2(0, 0)
   __syncthreads();
+  SSG_BN_STAMP(2)
 
   // =========================== phase 2: y2 = relu(conv2_3x3(y1)), pixel operand from LDS ===========================
   constexpr int NT2 = MID / 32;
@@ -220,6 +243,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc2[j][r] = 0.f;
   const int m2 = wave * 32 + l32, ty2 = m2 / IW, tx2 = m2 - ty2 * IW;      // this lane's output pixel (tile-local)
+  float4 cs2r[NT2][4], b2r[NT2][4];                        // needed right after the loop
+#pragma unroll
+  for (int j = 0; j < NT2; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      cs2r[j][q] = *reinterpret_cast<const float4*>(p.cs2 + j * 32 + 8 * q + 4 * h); b2r[j][q] = *reinterpret_cast<const float4*>(p.b2 + j * 32 + 8 * q + 4 * h);
+    }
 #define SSG_BN_STEP2(KT_, S_)                                                                                        \
   {                                                                                                                  \
     if ((KT_) + K::PD2 < K::NK2) SSG_BN_LOAD2((KT_) + K::PD2, S_)                                                     \
@@ -250,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
     SSG_BN_STEP2(kt0, 0) SSG_BN_STEP2(kt0 + 1, 1) SSG_BN_STEP2(kt0 + 2, 2) SSG_BN_STEP2(kt0 + 3, 3) SSG_BN_STEP2(kt0 + 4, 4) SSG_BN_STEP2(kt0 + 5, 5)
   }
 #undef SSG_BN_STEP2
+  SSG_BN_STAMP(3)
 #undef SSG_BN_LOAD2
 #undef SSG_BN_STORE2
 
@@ -271,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int ch = j * 32 + 8 * q + 4 * h;
-      const float4 cs = *reinterpret_cast<const float4*>(p.cs2 + ch), bi = *reinterpret_cast<const float4*>(p.b2 + ch);
+      const float4 cs = cs2r[j][q], bi = b2r[j][q];
       float4 v = make_float4(acc2[j][4 * q] * cs.x + bi.x, acc2[j][4 * q + 1] * cs.y + bi.y, acc2[j][4 * q + 2] * cs.z + bi.z, acc2[j][4 * q + 3] * cs.w + bi.w);
       v = relu4(v);
       uint2 hi, lo;
@@ -313,33 +344,37 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   __syncthreads();
   SSG_BN_STORE3(0, 0)
   SSG_BN_STORE3(1, 1)
+  // epilogue operands of the first channel tile: on their way during the second half of the multiply (the W3 staging registers are free now)
+  constexpr int EP = 36, CPR = 8, RPI = 8, ITS = 4;
+  const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
+  const int64_t gpix0 = ((int64_t)img * p.H + ty0) * IW + wave * 32;       // first output pixel of this wave (pixels are contiguous)
+  const float* __restrict__ resp = p.x + gpix0 * C;
+  float* __restrict__ outp = p.out + gpix0 * C;
+  float4 rr[2][ITS], b3r[2], cs3r[2];
+#pragma unroll
+  for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + chunk * 4);
+  b3r[0] = *reinterpret_cast<const float4*>(p.b3 + chunk * 4); cs3r[0] = *reinterpret_cast<const float4*>(p.cs3 + chunk * 4);
   __syncthreads();
   SSG_BN_MMA3K(0, 2)
   SSG_BN_MMA3K(1, 3)
+  SSG_BN_STAMP(4)
 #undef SSG_BN_LOAD3
 #undef SSG_BN_STORE3
 #undef SSG_BN_MMA3K
 
   // ---- epilogue: per channel tile a 32-pixel x 32-channel patch through LDS (this wave's own, now dead, y2 rows), then
   // whole 128-byte row segments: bias, residual (x, h8l8), ReLU, re-encode, store.  Same code path as conv.hip.
-  constexpr int EP = 36, CPR = 8, RPI = 8, ITS = 4;
   static_assert(32 * EP * 4 <= 32 * K::PY, "patch fits in the wave's y2 rows");
   float* patch = reinterpret_cast<float*>(myrows);
-  const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
-  const int64_t gpix0 = ((int64_t)img * p.H + ty0) * IW + wave * 32;       // first output pixel of this wave (pixels are contiguous)
-  const float* __restrict__ resp = p.x + gpix0 * C;
-  float* __restrict__ outp = p.out + gpix0 * C;
-  float4 rr[2][ITS];
-#pragma unroll
-  for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + chunk * 4);
 #pragma unroll
   for (int j = 0; j < NT3; j++) {
     const int col = j * 32 + chunk * 4;
     if (j + 1 < NT3) {
 #pragma unroll
       for (int it = 0; it < ITS; it++) rr[(j + 1) & 1][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + col + 32);
+      b3r[(j + 1) & 1] = *reinterpret_cast<const float4*>(p.b3 + col + 32); cs3r[(j + 1) & 1] = *reinterpret_cast<const float4*>(p.cs3 + col + 32);
     }
-    const float4 bias = *reinterpret_cast<const float4*>(p.b3 + col), cs = *reinterpret_cast<const float4*>(p.cs3 + col);
+    const float4 bias = b3r[j & 1], cs = cs3r[j & 1];
 #pragma unroll
     for (int q = 0; q < 4; q++)
       *reinterpret_cast<float4*>(patch + l32 * EP + 8 * q + 4 * h) = make_float4(acc3[j][4 * q], acc3[j][4 * q + 1], acc3[j][4 * q + 2], acc3[j][4 * q + 3]);
@@ -365,11 +400,16 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       ovf |= hi_nonfinite_bits(hp);
       const unsigned rx = (unsigned)__shfl_xor((int)(odd ? hp.x : lp.x), 1, 64), ry = (unsigned)__shfl_xor((int)(odd ? hp.y : lp.y), 1, 64);
       const uint4 stv = make_uint4(odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry);
+#ifdef SSG_BN_NT_STORE
+      { const v4u sv_ = {stv.x, stv.y, stv.z, stv.w}; __builtin_nontemporal_store(sv_, reinterpret_cast<v4u*>(outp + (int64_t)pr * C + col)); }
+#else
       *reinterpret_cast<uint4*>(outp + (int64_t)pr * C + col) = stv;
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   if ((ovf & 0x80008000u) && p.overflow) *p.overflow = 1;
+  SSG_BN_STAMP(5)
 }
 
 }  // namespace bneck
