@@ -218,11 +218,16 @@ int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const void* w, cons
  * w2 [MID][9*MID] (k = (32-channel chunk, tap, channel)), w3 [C][MID] as ssg_conv2d_nhwc_x takes them, rows pre-multiplied by
  * powers of two that cs1/cs2/cs3 undo; b* fp32 folded BatchNorm biases.  Bit-identical to the three ssg_conv2d_nhwc_x launches;
  * the two MID-channel intermediates stay in LDS.  ssg_bottleneck_supported() tells which block shapes have a kernel
- * (layer1 of ResNet-50 at 256x128 input: H x 32 x 256, MID 64). */
-int ssg_bottleneck_supported(int H, int W, int C, int MID);
+ * (layer1 of ResNet-50 at 256x128 input: H x 32 x 256, MID 64; CIN == C for the identity block, CIN = 64 for the first block).
+ * ssg_bottleneck_ds_nhwc_x: the block with a stride-1 downsample branch, out = relu(conv3(...) + downsample(x)); x [B,H,W,CIN],
+ * w3cat [C][MID + CIN] = conv3 | downsample weights along K and b3 = b3 + b_ds, as ssg_conv1x1_dual_nhwc_x takes them. */
+int ssg_bottleneck_supported(int H, int W, int CIN, int C, int MID);
 int ssg_bottleneck_nhwc_x(const void* x, const void* w1, const float* b1, const float* cs1, const void* w2, const float* b2, const float* cs2,
                           const void* w3, const float* b3, const float* cs3, void* out, int B, int H, int W, int C, int MID,
                           int32_t* overflow, ssg_stream_t stream);
+int ssg_bottleneck_ds_nhwc_x(const void* x, const void* w1, const float* b1, const float* cs1, const void* w2, const float* b2, const float* cs2,
+                             const void* w3cat, const float* b3, const float* cs3, void* out, int B, int H, int W, int CIN, int C, int MID,
+                             int32_t* overflow, ssg_stream_t stream);
 /* stem input for the split path: [B,3,H,W] NCHW fp32 -> [B,H,W] pixels of 16 bytes [4 x half hi][4 x half lo] ("h4l4",
  * 4th channel 0); ssg_conv2d_nhwc_x with Cin = 4 and SSG_CONV_IN_SPLIT takes these, with w in the same per-tap layout */
 int ssg_nchw_to_nhwc4_h4l4(const float* in, void* out, int B, int H, int W, int flip, ssg_stream_t stream);

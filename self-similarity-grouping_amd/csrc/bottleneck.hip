@@ -17,6 +17,10 @@
 // Numerics: the same three-product split-half multiply, the same reduction order and the same epilogues as the separate
 // launches (conv.hip), so the block output is bit-identical to the three-launch path.
 //
+// DS variant (the first block of layer1, base.py:75-90 with a stride-1 downsample branch): x has CIN = 64 channels, the
+// downsample 1x1 convolution rides in conv3's reduction (K = MID + CIN, weights concatenated, as ssg_conv1x1_dual_nhwc_x does)
+// and replaces the residual; its pixel operand (this wave's 32 pixels x CIN channels) is loaded straight into MFMA fragments.
+//
 // 4 waves, 2 workgroups per CU (<= 80 KB of LDS each).  All operand tiles are staged global -> registers -> LDS with the loads
 // several k-tiles ahead (register rings), one barrier per k-tile:
 //   phase 1  y1[(TH+2)*IW, MID] = relu(x W1^T)   k-tiles of 16 channels: x rows (64 B each) + W1 rows; wave = 3 x 1 MFMA tiles
@@ -49,7 +53,7 @@ struct Params {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int C, int MID, int IW, int TH>
+template <int C, int MID, int IW, int TH, int CIN = C>
 struct Cfg {
   static constexpr int HROWS = TH + 2, NPIX1 = HROWS * IW, NPIX = TH * IW;
   static constexpr int P1 = 80;                        // LDS pitch of a 64-byte k-tile row (pitch/16 odd: conflict-free b128)
@@ -60,8 +64,9 @@ struct Cfg {
   static constexpr int W2_OFF = (ZERO_OFF + PY + 255) / 256 * 256, BUF2 = MID * P2;
   static constexpr int W3_OFF = (NPIX * PY + 255) / 256 * 256, BUF3 = C * P1;
   static constexpr int LDS = cmax(cmax(2 * BUF1, W2_OFF + 2 * BUF2), W3_OFF + 2 * BUF3);
-  static constexpr int NK1 = C / 16, NK2 = (MID / 32) * 9, NK3 = MID / 16;
-  static constexpr int PD1 = 8, PD2 = 6;               // (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)               // k-tiles of global loads in flight ahead of the multiply
+  static constexpr int DS = CIN != C;                  // downsample variant: conv3's reduction is [y2 | x]
+  static constexpr int NK1 = CIN / 16, NK2 = (MID / 32) * 9, NK3 = (MID + (DS ? CIN : 0)) / 16;
+  static constexpr int PD1 = NK1 < 8 ? NK1 : 8, PD2 = 6;               // (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)               // k-tiles of global loads in flight ahead of the multiply
   static_assert(NPIX == 128 && NPIX1 % 64 == 0 && MID % 64 == 0 && C % 64 == 0, "4 waves x 32 output pixels");
   static_assert(2 * BUF1 <= ZERO_OFF, "the zero row is written while phase 1 runs");
   static_assert(LDS <= 80 * 1024, "two workgroups per CU");
@@ -91,9 +96,10 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 // x*w = xh*wl + xl*wh + xh*wh (the order of conv.hip's split_mma_step), weights as the first MFMA operand:
 // C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> channel
 
-template <int C, int MID, int IW, int TH>
+template <int C, int MID, int IW, int TH, int CIN>
 __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
-  using K = Cfg<C, MID, IW, TH>;
+  using K = Cfg<C, MID, IW, TH, CIN>;
+  constexpr bool DS = K::DS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
   const int tiles_img = p.H / TH, ntiles = p.B * tiles_img;
@@ -109,15 +115,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   // =========================== phase 1: y1 = relu(conv1(x)) on the TH+2 halo rows ===========================
   constexpr int AU = K::NPIX1 / 64, WU = MID / 64;          // 16-byte pieces per thread and k-tile: x rows, W1 rows
   const int ck = tid & 3, r0 = tid >> 2;
-  const float* ximg = p.x + (int64_t)img * p.H * IW * C;
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (unsigned)(p.H * IW * C * 4), 0x00020000);
+  const float* ximg = p.x + (int64_t)img * p.H * IW * CIN;
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (unsigned)(p.H * IW * CIN * 4), 0x00020000);
   unsigned aoff[AU];
 #pragma unroll
   for (int u = 0; u < AU; u++) {
     const int pix = (ty0 - 1) * IW + r0 + 64 * u;           // rows above / below the image: out-of-range offset -> the load returns zeros
-    aoff[u] = (pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * C + ck * 4) * 4) : 0x80000000u;
+    aoff[u] = (pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * CIN + ck * 4) * 4) : 0x80000000u;
   }
-  const float* w1p = p.w1 + (int64_t)r0 * C + ck * 4;
+  const float* w1p = p.w1 + (int64_t)r0 * CIN + ck * 4;
   v4f sa[K::PD1][AU], sw[K::PD1][WU];
 #define SSG_BN_LOAD1(T_, S_)                                                                                         \
   {                                                                                                                  \
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[u], (T_) * 64, 0);                            \
       sa[S_][u] = __builtin_bit_cast(v4f, raw);                                                                     \
     }                                                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < WU; u++) sw[S_][u] = *reinterpret_cast<const v4f*>(w1p + (int64_t)(64 * u) * C + (T_) * 16); \
+    _Pragma("unroll") for (int u = 0; u < WU; u++) sw[S_][u] = *reinterpret_cast<const v4f*>(w1p + (int64_t)(64 * u) * CIN + (T_) * 16); \
   }
 #define SSG_BN_STORE1(BUF_, S_)                                                                                      \
   {                                                                                                                  \
@@ -171,8 +177,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
     if ((KT_) + 1 < K::NK1) SSG_BN_STORE1(((S_) + 1) & 1, ((S_) + 1) % K::PD1)                                        \
     __syncthreads();                                                                                                 \
   }
-  static_assert(K::PD1 == 8 && K::NK1 % 8 == 0, "phase-1 ring of eight register sets");
-  SSG_BN_LOAD1(0, 0) SSG_BN_LOAD1(1, 1) SSG_BN_LOAD1(2, 2) SSG_BN_LOAD1(3, 3) SSG_BN_LOAD1(4, 4) SSG_BN_LOAD1(5, 5) SSG_BN_LOAD1(6, 6) SSG_BN_LOAD1(7, 7)
+  static_assert(K::NK1 % K::PD1 == 0 && K::PD1 <= 8, "phase-1 ring of PD1 register sets");
+#define SSG_BN_LOAD1_IF(S_) if constexpr ((S_) < K::PD1) SSG_BN_LOAD1(S_, S_)
+  SSG_BN_LOAD1_IF(0) SSG_BN_LOAD1_IF(1) SSG_BN_LOAD1_IF(2) SSG_BN_LOAD1_IF(3) SSG_BN_LOAD1_IF(4) SSG_BN_LOAD1_IF(5) SSG_BN_LOAD1_IF(6) SSG_BN_LOAD1_IF(7)
+#undef SSG_BN_LOAD1_IF
   // folded BatchNorm scale / bias of this wave's conv1 channels (needed after the loop: no L2 round trip there)
   float4 cs1r[NTW1][4], b1r[NTW1][4];
 #pragma unroll
@@ -183,11 +191,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
     }
   SSG_BN_STORE1(0, 0)
   __syncthreads();
+#define SSG_BN_STEP1_IF(KT_, S_) if constexpr ((S_) < K::PD1) SSG_BN_STEP1(KT_, S_)
 #pragma unroll
-  for (int kt0 = 0; kt0 < K::NK1; kt0 += 8) {
-    SSG_BN_STEP1(kt0, 0) SSG_BN_STEP1(kt0 + 1, 1) SSG_BN_STEP1(kt0 + 2, 2) SSG_BN_STEP1(kt0 + 3, 3)
-    SSG_BN_STEP1(kt0 + 4, 4) SSG_BN_STEP1(kt0 + 5, 5) SSG_BN_STEP1(kt0 + 6, 6) SSG_BN_STEP1(kt0 + 7, 7)
+  for (int kt0 = 0; kt0 < K::NK1; kt0 += K::PD1) {
+    SSG_BN_STEP1_IF(kt0, 0) SSG_BN_STEP1_IF(kt0 + 1, 1) SSG_BN_STEP1_IF(kt0 + 2, 2) SSG_BN_STEP1_IF(kt0 + 3, 3)
+    SSG_BN_STEP1_IF(kt0 + 4, 4) SSG_BN_STEP1_IF(kt0 + 5, 5) SSG_BN_STEP1_IF(kt0 + 6, 6) SSG_BN_STEP1_IF(kt0 + 7, 7)
   }
+#undef SSG_BN_STEP1_IF
 #undef SSG_BN_STEP1
   SSG_BN_STAMP(1)
 #undef SSG_BN_LOAD1
@@ -286,15 +296,25 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 
   // ---- conv3 weights: k-tiles 0 and 1 on their way while y2 is written (every wave is past its last y1 / W2 read)
   constexpr int CU3 = C / 64;                               // 16-byte pieces per thread and W3 k-tile (C rows x 64 B)
-  const float* w3p = p.w3 + (int64_t)r0 * MID + ck * 4;
+  constexpr int K3 = MID + (DS ? CIN : 0);                 // conv3's reduction length (the weight row)
+  const float* w3p = p.w3 + (int64_t)r0 * K3 + ck * 4;
   v4f sc3[2][CU3];
 #define SSG_BN_LOAD3(T_, S_)                                                                                         \
-  { _Pragma("unroll") for (int u = 0; u < CU3; u++) sc3[S_][u] = *reinterpret_cast<const v4f*>(w3p + (int64_t)(64 * u) * MID + (T_) * 16); }
+  { _Pragma("unroll") for (int u = 0; u < CU3; u++) sc3[S_][u] = *reinterpret_cast<const v4f*>(w3p + (int64_t)(64 * u) * K3 + (T_) * 16); }
 #define SSG_BN_STORE3(BUF_, S_)                                                                                      \
   { unsigned char* sb_ = smem + K::W3_OFF + (BUF_) * K::BUF3;                                                        \
     _Pragma("unroll") for (int u = 0; u < CU3; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + 64 * u) * K::P1 + ck * 16) = sc3[S_][u]; }
   SSG_BN_LOAD3(0, 0)
   SSG_BN_LOAD3(1, 1)
+  const int64_t gpix0 = ((int64_t)img * p.H + ty0) * IW + wave * 32;       // first output pixel of this wave (pixels are contiguous)
+  // DS: the downsample operand, this lane's pixel, k-tiles MID/16 .. NK3-1 = channels of x: [8 hi][8 lo] of group h per k-tile
+  constexpr int NXK = DS ? CIN / 16 : 1;
+  v8h xrh[NXK], xrl[NXK];
+  if constexpr (DS) {
+    const float* xq = p.x + (gpix0 + l32) * CIN + h * 8;
+#pragma unroll
+    for (int t = 0; t < NXK; t++) { xrh[t] = *reinterpret_cast<const v8h*>(xq + t * 16); xrl[t] = *reinterpret_cast<const v8h*>(xq + t * 16 + 4); }
+  }
   // y2 rows of this wave's 32 pixels (written and read by this wave only)
   unsigned char* myrows = smem + (wave * 32) * K::PY;
 #pragma unroll
@@ -314,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 
   // =========================== phase 3: out = relu(conv3(y2) + x) ===========================
   constexpr int NT3 = C / 32;
-  static_assert(K::NK3 == 4, "phase 3 is written for MID = 64 (4 k-tiles in two rounds of two buffers)");
+  static_assert(K::NK3 % 2 == 0, "phase 3 takes its k-tiles in rounds of two buffers");
   v16f acc3[NT3];
 #pragma unroll
   for (int j = 0; j < NT3; j++)
@@ -322,8 +342,12 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
     for (int r = 0; r < 16; r++) acc3[j][r] = 0.f;
 #define SSG_BN_MMA3K(BUF_, KT_)                                                                                      \
   {                                                                                                                  \
-    const unsigned char* q_ = myrows + l32 * K::PY + ((KT_) * 2 + h) * 32;                                           \
-    const v8h xh_ = *reinterpret_cast<const v8h*>(q_), xl_ = *reinterpret_cast<const v8h*>(q_ + 16);                 \
+    v8h xh_, xl_;                                                                                                    \
+    if constexpr (DS && (KT_) >= MID / 16) { xh_ = xrh[((KT_) - MID / 16) % NXK]; xl_ = xrl[((KT_) - MID / 16) % NXK]; } \
+    else {                                                                                                           \
+      const unsigned char* q_ = myrows + l32 * K::PY + (((KT_) % (MID / 16)) * 2 + h) * 32;                          \
+      xh_ = *reinterpret_cast<const v8h*>(q_); xl_ = *reinterpret_cast<const v8h*>(q_ + 16);                         \
+    }                                                                                                                \
     const unsigned char* wb_ = smem + K::W3_OFF + (BUF_) * K::BUF3 + l32 * K::P1 + h * 32;                           \
     _Pragma("unroll") for (int jj = 0; jj < NT3; jj += 4) {                                                          \
       v8h wh_[4], wl_[4];                                                                                            \
@@ -334,29 +358,37 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       _Pragma("unroll") for (int j = 0; j < 4; j++) acc3[jj + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xh_, acc3[jj + j], 0, 0, 0); \
     }                                                                                                                \
   }
-  SSG_BN_STORE3(0, 0)
-  SSG_BN_STORE3(1, 1)
-  SSG_BN_LOAD3(2, 0)
-  SSG_BN_LOAD3(3, 1)
-  __syncthreads();
-  SSG_BN_MMA3K(0, 0)
-  SSG_BN_MMA3K(1, 1)
-  __syncthreads();
-  SSG_BN_STORE3(0, 0)
-  SSG_BN_STORE3(1, 1)
-  // epilogue operands of the first channel tile: on their way during the second half of the multiply (the W3 staging registers are free now)
+  // epilogue addressing / operands (the first channel tile's are fetched during the last round of the multiply)
   constexpr int EP = 36, CPR = 8, RPI = 8, ITS = 4;
   const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
-  const int64_t gpix0 = ((int64_t)img * p.H + ty0) * IW + wave * 32;       // first output pixel of this wave (pixels are contiguous)
-  const float* __restrict__ resp = p.x + gpix0 * C;
+  const float* __restrict__ resp = p.x + gpix0 * C;        // residual (identity blocks only)
   float* __restrict__ outp = p.out + gpix0 * C;
   float4 rr[2][ITS], b3r[2], cs3r[2];
-#pragma unroll
-  for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + chunk * 4);
-  b3r[0] = *reinterpret_cast<const float4*>(p.b3 + chunk * 4); cs3r[0] = *reinterpret_cast<const float4*>(p.cs3 + chunk * 4);
+  SSG_BN_STORE3(0, 0)
+  SSG_BN_STORE3(1, 1)
+  if constexpr (K::NK3 > 2) { SSG_BN_LOAD3(2, 0) SSG_BN_LOAD3(3, 1) }
   __syncthreads();
-  SSG_BN_MMA3K(0, 2)
-  SSG_BN_MMA3K(1, 3)
+  static_assert(K::NK3 / 2 <= 4, "at most four rounds");
+#define SSG_BN_ROUND3(R_)                                                                                            \
+  if constexpr ((R_) < K::NK3 / 2) {                                                                                 \
+    SSG_BN_MMA3K(0, 2 * (R_))                                                                                        \
+    SSG_BN_MMA3K(1, 2 * (R_) + 1)                                                                                    \
+    if constexpr ((R_) + 1 < K::NK3 / 2) {                                                                           \
+      __syncthreads();                       /* everybody is done reading the two buffers */                         \
+      SSG_BN_STORE3(0, 0)                                                                                            \
+      SSG_BN_STORE3(1, 1)                                                                                            \
+      if constexpr ((R_) + 2 < K::NK3 / 2) { SSG_BN_LOAD3(2 * (R_) + 4, 0) SSG_BN_LOAD3(2 * (R_) + 5, 1) }           \
+      else {                                 /* last round ahead: the W3 staging registers are free for the epilogue's first operands */ \
+        if constexpr (!DS) {                                                                                         \
+          _Pragma("unroll") for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + chunk * 4); \
+        }                                                                                                            \
+        b3r[0] = *reinterpret_cast<const float4*>(p.b3 + chunk * 4); cs3r[0] = *reinterpret_cast<const float4*>(p.cs3 + chunk * 4); \
+      }                                                                                                              \
+      __syncthreads();                                                                                               \
+    }                                                                                                                \
+  }
+  SSG_BN_ROUND3(0) SSG_BN_ROUND3(1) SSG_BN_ROUND3(2) SSG_BN_ROUND3(3)
+#undef SSG_BN_ROUND3
   SSG_BN_STAMP(4)
 #undef SSG_BN_LOAD3
 #undef SSG_BN_STORE3
@@ -370,8 +402,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   for (int j = 0; j < NT3; j++) {
     const int col = j * 32 + chunk * 4;
     if (j + 1 < NT3) {
+      if constexpr (!DS) {
 #pragma unroll
-      for (int it = 0; it < ITS; it++) rr[(j + 1) & 1][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + col + 32);
+        for (int it = 0; it < ITS; it++) rr[(j + 1) & 1][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + col + 32);
+      }
       b3r[(j + 1) & 1] = *reinterpret_cast<const float4*>(p.b3 + col + 32); cs3r[(j + 1) & 1] = *reinterpret_cast<const float4*>(p.cs3 + col + 32);
     }
     const float4 bias = b3r[j & 1], cs = cs3r[j & 1];
@@ -384,6 +418,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       const int pr = it * RPI + prow;
       float4 v = *reinterpret_cast<const float4*>(patch + pr * EP + chunk * 4);
       v.x = v.x * cs.x + bias.x; v.y = v.y * cs.y + bias.y; v.z = v.z * cs.z + bias.z; v.w = v.w * cs.w + bias.w;
+      if constexpr (!DS) {
       const float4 rw = rr[j & 1][it];
       float4 r4;
       {   // even lane holds hi0..7 of the 8-channel group, odd lane lo0..7; each needs hi and lo of ITS four channels
@@ -394,6 +429,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
         r4 = decode4(make_uint2(h0, h1), make_uint2(l0, l1));
       }
       v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+      }
       v = relu4(v);
       uint2 hp, lp;
       encode4(v, hp, lp);
@@ -415,9 +451,23 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 }  // namespace bneck
 }  // namespace ssg
 
-// 1 when ssg_bottleneck_nhwc_x has a kernel for this block shape
-extern "C" int ssg_bottleneck_supported(int H, int W, int C, int MID) {
-  return (C == 256 && MID == 64 && W == 32 && H > 0 && H % 4 == 0) ? 1 : 0;
+// 1 when ssg_bottleneck_nhwc_x / ssg_bottleneck_ds_nhwc_x has a kernel for this block shape (CIN == C: identity block)
+extern "C" int ssg_bottleneck_supported(int H, int W, int CIN, int C, int MID) {
+  return (C == 256 && MID == 64 && (CIN == 256 || CIN == 64) && W == 32 && H > 0 && H % 4 == 0) ? 1 : 0;
+}
+
+template <int CIN>
+static int launch_bottleneck(const ssg::bneck::Params& p, hipStream_t stream) {
+  using namespace ssg::bneck;
+  using K = Cfg<256, 64, 32, 4, CIN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    SSG_HIP(hipFuncSetAttribute((const void*)bottleneck_kernel<256, 64, 32, 4, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bottleneck_kernel<256, 64, 32, 4, CIN>), dim3(p.B * (p.H / 4)), dim3(256), K::LDS, stream, p);
+  SSG_LAUNCH_CHECK("bottleneck_kernel");
+  return SSG_OK;
 }
 
 // Identity bottleneck block (no downsample branch, stride 1), split-half tensors:
@@ -428,7 +478,7 @@ extern "C" int ssg_bottleneck_nhwc_x(const void* x, const void* w1, const float*
                                      const void* w3, const float* b3, const float* cs3, void* out, int B, int H, int W, int C, int MID,
                                      int32_t* overflow, hipStream_t stream) {
   using namespace ssg::bneck;
-  if (B <= 0 || !ssg_bottleneck_supported(H, W, C, MID) || !cs1 || !cs2 || !cs3 || x == out) {
+  if (B <= 0 || !ssg_bottleneck_supported(H, W, C, C, MID) || !cs1 || !cs2 || !cs3 || x == out) {
     ssg_set_error("ssg_bottleneck_nhwc_x: unsupported block B=%d H=%d W=%d C=%d MID=%d (see ssg_bottleneck_supported)", B, H, W, C, MID);
     return SSG_ERR_INVALID;
   }
@@ -436,13 +486,23 @@ extern "C" int ssg_bottleneck_nhwc_x(const void* x, const void* w1, const float*
   p.x = (const float*)x; p.out = (float*)out;
   p.w1 = (const float*)w1; p.b1 = b1; p.cs1 = cs1; p.w2 = (const float*)w2; p.b2 = b2; p.cs2 = cs2; p.w3 = (const float*)w3; p.b3 = b3; p.cs3 = cs3;
   p.B = B; p.H = H; p.overflow = overflow;
-  using K = Cfg<256, 64, 32, 4>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SSG_HIP(hipFuncSetAttribute((const void*)bottleneck_kernel<256, 64, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
-    attr_set = true;
+  return launch_bottleneck<256>(p, stream);
+}
+
+// Bottleneck block with a stride-1 downsample branch (the first block of layer1):
+//   out = relu(conv3(relu(conv2(relu(conv1(x))))) + downsample(x)),  x [B,H,W,CIN], out [B,H,W,C] h8l8;
+//   w3cat [C][MID + CIN] = conv3 | downsample weights concatenated along K (the layout of ssg_conv1x1_dual_nhwc_x), b3 = b3 + b_ds.
+extern "C" int ssg_bottleneck_ds_nhwc_x(const void* x, const void* w1, const float* b1, const float* cs1, const void* w2, const float* b2, const float* cs2,
+                                        const void* w3cat, const float* b3, const float* cs3, void* out, int B, int H, int W, int CIN, int C, int MID,
+                                        int32_t* overflow, hipStream_t stream) {
+  using namespace ssg::bneck;
+  if (B <= 0 || CIN == C || !ssg_bottleneck_supported(H, W, CIN, C, MID) || !cs1 || !cs2 || !cs3) {
+    ssg_set_error("ssg_bottleneck_ds_nhwc_x: unsupported block B=%d H=%d W=%d CIN=%d C=%d MID=%d (see ssg_bottleneck_supported)", B, H, W, CIN, C, MID);
+    return SSG_ERR_INVALID;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<256, 64, 32, 4>), dim3(B * (H / 4)), dim3(256), K::LDS, stream, p);
-  SSG_LAUNCH_CHECK("bottleneck_kernel");
-  return SSG_OK;
+  Params p;
+  p.x = (const float*)x; p.out = (float*)out;
+  p.w1 = (const float*)w1; p.b1 = b1; p.cs1 = cs1; p.w2 = (const float*)w2; p.b2 = b2; p.cs2 = cs2; p.w3 = (const float*)w3cat; p.b3 = b3; p.cs3 = cs3;
+  p.B = B; p.H = H; p.overflow = overflow;
+  return launch_bottleneck<64>(p, stream);
 }

@@ -306,15 +306,23 @@ class ResNet:
 
     @staticmethod
     def _bottleneck(L, y, blk, ovf=None):
-        """identity block in one launch (ssg_bottleneck_nhwc_x); None when there is no fused kernel for this shape"""
-        B, H, W, C = y.shape
-        c1, c2, c3 = blk["c1"], blk["c2"], blk["c3"]
-        if os.environ.get("SSG_FUSED_BOTTLENECK", "1") == "0" or not L.ssg_bottleneck_supported(H, W, C, c1.cout):
+        """whole bottleneck block in one launch (ssg_bottleneck_nhwc_x / ssg_bottleneck_ds_nhwc_x); None when there is no fused
+        kernel for this block (stride-2 blocks, other shapes)"""
+        B, H, W, CIN = y.shape
+        c1, c2, c3, ds = blk["c1"], blk["c2"], blk["c3"], blk["ds"]
+        if os.environ.get("SSG_FUSED_BOTTLENECK", "1") == "0" or c2.stride != 1 or (ds is not None and ds.stride != 1):
             return None
-        out = torch.empty_like(y)
-        check(L.ssg_bottleneck_nhwc_x(ptr(y), ptr(c1.w), ptr(c1.bias), ptr(c1.cscale), ptr(c2.w), ptr(c2.bias), ptr(c2.cscale),
-                                      ptr(c3.w), ptr(c3.bias), ptr(c3.cscale), ptr(out), B, H, W, C, c1.cout, ptr(ovf), stream()),
-              "ssg_bottleneck_nhwc_x")
+        if not L.ssg_bottleneck_supported(H, W, CIN, c3.cout, c1.cout):
+            return None
+        out = torch.empty((B, H, W, c3.cout), dtype=torch.float32, device=y.device)
+        if ds is None:
+            check(L.ssg_bottleneck_nhwc_x(ptr(y), ptr(c1.w), ptr(c1.bias), ptr(c1.cscale), ptr(c2.w), ptr(c2.bias), ptr(c2.cscale),
+                                          ptr(c3.w), ptr(c3.bias), ptr(c3.cscale), ptr(out), B, H, W, CIN, c1.cout, ptr(ovf), stream()),
+                  "ssg_bottleneck_nhwc_x")
+        else:       # ds.w = [conv3 | downsample] weights along K, ds.bias = b3 + b_ds (see _prepare)
+            check(L.ssg_bottleneck_ds_nhwc_x(ptr(y), ptr(c1.w), ptr(c1.bias), ptr(c1.cscale), ptr(c2.w), ptr(c2.bias), ptr(c2.cscale),
+                                             ptr(ds.w), ptr(ds.bias), ptr(ds.cscale), ptr(out), B, H, W, CIN, c3.cout, c1.cout, ptr(ovf), stream()),
+                  "ssg_bottleneck_ds_nhwc_x")
         return out
 
     def _fmap(self, x, flip=False):
@@ -342,7 +350,7 @@ class ResNet:
             check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
         y = p
         for blk in net["blocks"]:
-            if sp and blk["ds"] is None:
+            if sp:
                 fused = self._bottleneck(L, y, blk, ovf)
                 if fused is not None:
                     y = fused

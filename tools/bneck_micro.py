@@ -14,7 +14,8 @@ def main():
     L = _lib.lib(); dev = torch.device("cuda", 0)
     m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False).cuda().eval()
     net = m._prepare(); blk = net["blocks"][blk_i]
-    C, H, W = blk["c1"].cin, {256: 64, 512: 32, 1024: 16, 2048: 8}[blk["c1"].cin], {256: 32, 512: 16, 1024: 8, 2048: 4}[blk["c1"].cin]
+    C = blk["c1"].cin; CO = blk["c3"].cout
+    H, W = {256: 64, 512: 32, 1024: 16, 2048: 8}[CO], {256: 32, 512: 16, 1024: 8, 2048: 4}[CO]
     x = torch.relu(torch.randn(B, H, W, C, device=dev)) * 0.7
     xs = torch.empty_like(x); check(L.ssg_h8l8_encode(ptr(x), ptr(xs), x.numel(), 1.0, stream()), "enc")
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -22,6 +23,8 @@ def main():
     def unfused():
         o = m._conv(L, xs, blk["c1"], out_split=True, ovf=ovf)
         o = m._conv(L, o, blk["c2"], out_split=True, ovf=ovf)
+        if blk["ds"] is not None:
+            return m._conv_dual(L, o, xs, blk["c3"], blk["ds"], out_split=True, ovf=ovf)
         return m._conv(L, o, blk["c3"], res=xs, relu=True, out_split=True, ovf=ovf)
 
     def fused():
@@ -37,7 +40,7 @@ def main():
     if neq:
         idx = (ai != bi).nonzero()[:5]
         print("first mismatches (b,y,x,c):", idx.tolist())
-        bad = (ai != bi).view(B, H, W, C).any(dim=3)
+        bad = (ai != bi).view(B, H, W, CO).any(dim=3)
         print("bad pixels per image row (image 0):", bad[0].sum(dim=1).tolist())
     for name, f in (("unfused", unfused), ("fused", fused)):
         f(); torch.cuda.synchronize()
@@ -46,7 +49,7 @@ def main():
         for _ in range(20): f()
         e1.record(); e1.synchronize()
         ms = e0.elapsed_time(e1) / 20
-        print("  %-8s %.3f ms  (%.2f TB/s on read x + write out)" % (name, ms, 2 * 4.0 * x.numel() / ms / 1e9))
+        print("  %-8s %.3f ms  (%.2f TB/s on read x + write out)" % (name, ms, 4.0 * (x.numel() + a.numel()) / ms / 1e9))
 
 
 if __name__ == "__main__":

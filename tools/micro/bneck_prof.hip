@@ -32,11 +32,11 @@ int main(int argc, char** argv) {
   p.x = (const float*)x; p.out = (float*)out; p.w1 = (const float*)w1; p.b1 = bi; p.cs1 = cs; p.w2 = (const float*)w2; p.b2 = bi; p.cs2 = cs;
   p.w3 = (const float*)w3; p.b3 = bi; p.cs3 = cs; p.B = B; p.H = H; p.overflow = nullptr; p.prof = prof;
   using K = Cfg<256, 64, 32, 4>;
-  hipFuncSetAttribute((const void*)bottleneck_kernel<256, 64, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
+  hipFuncSetAttribute((const void*)bottleneck_kernel<256, 64, 32, 4, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 4; rep++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((bottleneck_kernel<256, 64, 32, 4>), dim3(ntiles), dim3(256), K::LDS, 0, p);
+    hipLaunchKernelGGL((bottleneck_kernel<256, 64, 32, 4, 256>), dim3(ntiles), dim3(256), K::LDS, 0, p);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("B=%d tiles=%d LDS=%d  %.3f ms  (%.2f TB/s x+out)\n", B, ntiles, K::LDS, ms, 2.0 * nx * 4 / ms / 1e9);
