@@ -228,6 +228,13 @@ int ssg_bottleneck_nhwc_x(const void* x, const void* w1, const float* b1, const 
 int ssg_bottleneck_ds_nhwc_x(const void* x, const void* w1, const float* b1, const float* cs1, const void* w2, const float* b2, const float* cs2,
                              const void* w3cat, const float* b3, const float* cs3, void* out, int B, int H, int W, int CIN, int C, int MID,
                              int32_t* overflow, ssg_stream_t stream);
+/* The stem in ONE launch (base.py:101-105 conv1 + bn1 + relu + maxpool, with the fliplr of evaluators.py:12-16 folded into the
+ * image read): images [B,3,H,W] float32 NCHW -> out [B,H/4,W/4,64] h8l8.  w [64][224] / bias / ch_scale: the stem weights as
+ * ssg_conv2d_nhwc_x takes them (Cin = 4 "h4l4" layout).  Bit-identical to ssg_nchw_to_nhwc4_h4l4 + ssg_conv2d_nhwc_x +
+ * ssg_maxpool3x3s2_h8l8; the 64-channel stem map never reaches HBM.  ssg_stem_pool_supported(): W == 128, H % 4 == 0. */
+int ssg_stem_pool_supported(int H, int W);
+int ssg_stem_pool_nchw_x(const float* images, int flip, const void* w, const float* bias, const float* ch_scale, void* out, int B, int H, int W,
+                         int32_t* overflow, ssg_stream_t stream);
 /* stem input for the split path: [B,3,H,W] NCHW fp32 -> [B,H,W] pixels of 16 bytes [4 x half hi][4 x half lo] ("h4l4",
  * 4th channel 0); ssg_conv2d_nhwc_x with Cin = 4 and SSG_CONV_IN_SPLIT takes these, with w in the same per-tap layout */
 int ssg_nchw_to_nhwc4_h4l4(const float* in, void* out, int B, int H, int W, int flip, ssg_stream_t stream);

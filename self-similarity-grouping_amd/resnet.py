@@ -335,20 +335,27 @@ class ResNet:
         B, C, H, W = x.shape
         if C != 3:
             raise ValueError("expected RGB images [B,3,H,W]")
-        x4 = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
-        if sp:
-            check(L.ssg_nchw_to_nhwc4_h4l4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4_h4l4")
-        else:
-            check(L.ssg_nchw_to_nhwc4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4")
         ovf = self._overflow_flag() if sp else None
-        y = self._conv(L, x4, net["stem"], out_split=sp, ovf=ovf)
-        _, H2, W2, _ = y.shape
-        p = torch.empty((B, (H2 + 1) // 2, (W2 + 1) // 2, 64), dtype=torch.float32, device=self.device)
-        if sp:
-            check(L.ssg_maxpool3x3s2_h8l8(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_h8l8")
+        if sp and os.environ.get("SSG_FUSED_STEM", "1") != "0" and L.ssg_stem_pool_supported(H, W):
+            # conv1 + bn1 + relu + maxpool (+ the layout change and the flip) in one launch: the stem map stays on chip
+            st = net["stem"]
+            y = torch.empty((B, H // 4, W // 4, 64), dtype=torch.float32, device=self.device)
+            check(L.ssg_stem_pool_nchw_x(ptr(x), 1 if flip else 0, ptr(st.w), ptr(st.bias), ptr(st.cscale), ptr(y), B, H, W, ptr(ovf), stream()),
+                  "ssg_stem_pool_nchw_x")
         else:
-            check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
-        y = p
+            x4 = torch.empty((B, H, W, 4), dtype=torch.float32, device=self.device)
+            if sp:
+                check(L.ssg_nchw_to_nhwc4_h4l4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4_h4l4")
+            else:
+                check(L.ssg_nchw_to_nhwc4(ptr(x), ptr(x4), B, H, W, 1 if flip else 0, stream()), "ssg_nchw_to_nhwc4")
+            y = self._conv(L, x4, net["stem"], out_split=sp, ovf=ovf)
+            _, H2, W2, _ = y.shape
+            p = torch.empty((B, (H2 + 1) // 2, (W2 + 1) // 2, 64), dtype=torch.float32, device=self.device)
+            if sp:
+                check(L.ssg_maxpool3x3s2_h8l8(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_h8l8")
+            else:
+                check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
+            y = p
         for blk in net["blocks"]:
             if sp:
                 fused = self._bottleneck(L, y, blk, ovf)
