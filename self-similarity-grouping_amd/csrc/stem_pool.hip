@@ -12,7 +12,8 @@
 //     strip adds 4 rows, fetched into registers during the previous step's multiply;
 //   * the implicit GEMM  conv[192 pixels, 64] = patch-taps[192, 224] x W^T  takes its pixel fragments from the LDS patch (a
 //     filter tap is an address offset) and its weight fragments from registers (loaded once per wave): no barrier in the loop;
-//   * the conv tile goes to LDS as fp32, the 3x3/2 max is taken there, the result is stored as h8l8.
+//   * the conv rows go to LDS as fp32 (a ring of three: a step computes rows 2p and 2p+1, row 2p-1 is the previous step's), the
+//     3x3/2 max is taken there, the result is stored as h8l8.
 // Numerics are those of the three launches bit for bit: the same k-steps (4 taps each, taps in r*7+s order, 49..55 zero),
 // the same product order, bias / ReLU / encode, and the pool sees decode(encode(v)) like the separate kernel did.
 #include "ssg_common.h"
@@ -77,9 +78,56 @@ __device__ __forceinline__ void store_item(unsigned char* dst, const Item& it, i
   }
 }
 
+// NT pixel tiles (32 pixels each, LDS byte offset acol[i] of the tile's first tap column) of one conv row whose 7 tap rows sit
+// at roff[0..6] in the patch ring: acc[i] += taps x W^T over the 14 k-steps
+template <int NT>
+__device__ __forceinline__ void conv_row_gemm(const unsigned char* patch, const int (&acol)[NT], const int (&roff)[7], const v8h (&wh)[KSTEPS],
+                                              const v8h (&wl)[KSTEPS], const int h, v16f (&acc)[NT]) {
+#pragma unroll
+  for (int t = 0; t < KSTEPS; t++) {
+    // taps of this half-wave: 4t + 2h and the next one (slots 49..55 carry zero weights: any valid address will do)
+    constexpr int NTAP = 49;
+    const int ta0 = 4 * t < NTAP ? 4 * t : 0, tb0 = 4 * t + 1 < NTAP ? 4 * t + 1 : 0, ta1 = 4 * t + 2 < NTAP ? 4 * t + 2 : 0, tb1 = 4 * t + 3 < NTAP ? 4 * t + 3 : 0;
+    const int oa = h ? roff[ta1 / 7] + (ta1 % 7) * 16 : roff[ta0 / 7] + (ta0 % 7) * 16;
+    const int ob = h ? roff[tb1 / 7] + (tb1 % 7) * 16 : roff[tb0 / 7] + (tb0 % 7) * 16;
+    v8h xh[NT], xl[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+      const v4f t0 = *reinterpret_cast<const v4f*>(patch + acol[i] + oa), t1 = *reinterpret_cast<const v4f*>(patch + acol[i] + ob);
+      const v4f hi = {t0.x, t0.y, t1.x, t1.y}, lo = {t0.z, t0.w, t1.z, t1.w};
+      xh[i] = __builtin_bit_cast(v8h, hi); xl[i] = __builtin_bit_cast(v8h, lo);
+    }
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xl[i], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], xh[i], acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NT; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xh[i], acc[i], 0, 0, 0);
+  }
+}
+
+// one 32-pixel x 32-channel accumulator tile -> conv tile in LDS (fp32): bias, ReLU, and the encode / decode round trip the
+// separate maxpool kernel saw; returns the non-finite bits of the encoded values
+__device__ __forceinline__ unsigned tile_to_lds(const v16f& acc, const float* csb, unsigned char* dst_pixel, const int chbase) {
+  unsigned ovf = 0u;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int ch = chbase + 8 * q;
+    const float4 c4 = *reinterpret_cast<const float4*>(csb + ch), b4 = *reinterpret_cast<const float4*>(csb + 64 + ch);
+    float4 v = make_float4(acc[4 * q] * c4.x + b4.x, acc[4 * q + 1] * c4.y + b4.y, acc[4 * q + 2] * c4.z + b4.z, acc[4 * q + 3] * c4.w + b4.w);
+    v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+    uint2 hi, lo;
+    enc4(v, hi, lo);
+    ovf |= ((hi.x & 0x7c007c00u) + 0x04000400u) | ((hi.y & 0x7c007c00u) + 0x04000400u);
+    *reinterpret_cast<float4*>(dst_pixel + ch * 4) = dec4(hi, lo);
+  }
+  return ovf;
+}
+
 // A workgroup walks down a strip of `rs` pooled rows of one image: the weight fragments are loaded once, the image patch is
 // a ring of 12 row slots in LDS (each step brings 4 new image rows, prefetched into registers under the previous step's
-// multiply), the conv tile (3 rows x 64 pixels x 64 channels fp32) sits beside it.
+// multiply), the conv rows live in a ring of 3 row slots (a step computes the two new rows 2p, 2p+1; row 2p-1 is the
+// previous step's).
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float* __restrict__ img, int flip, const float* __restrict__ w, const float* __restrict__ bias,
                                                            const float* __restrict__ cs, float* __restrict__ out, int B, int H, int rs, int* overflow) {
   __shared__ __attribute__((aligned(16))) unsigned char patch[RING * ROWB];
@@ -90,8 +138,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float* __restri
   const int b = (int)blockIdx.x / strips, pr0 = ((int)blockIdx.x - b * strips) * rs, pr1 = min(pr0 + rs, OHP);
   SSG_STEM_T0()
 
-  // ---- this wave: 32 output channels (j1) of the 3 conv rows of one 32-pixel half of the row (half): tile i = conv row i
-  const int j1 = wave & 1, half = wave >> 1;
+  // ---- this wave: 32 output channels (j1) of ONE of the two new conv rows (nr) of a step, both 32-pixel halves of the row
+  const int j1 = wave & 1, nr = __builtin_amdgcn_readfirstlane(wave >> 1);
   v8h wh[KSTEPS], wl[KSTEPS];                         // weight fragments, all 14 k-steps (half-wave h takes taps 4t+2h, 4t+2h+1)
   {
     const float* wr = w + (int64_t)(j1 * 32 + l32) * KROW + h * 8;
@@ -114,83 +162,65 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float* __restri
     store_item(patch + ((rot + py) % RING) * ROWB + g * 64, im, flip);
   }
   __syncthreads();
+  unsigned ovf = 0u;
+  const int acol[2] = {(2 * l32 + 1) * 16, (2 * (32 + l32) + 1) * 16};   // tap (r, s) of a conv row = its r-th tap row slot, + s*16
+  if (pr0 > 0) {
+    // conv row 2*pr0 - 1 (window rows py = 0..6) is the previous strip's: recomputed here, one tile per wave
+    int roff[7];
+#pragma unroll
+    for (int r = 0; r < 7; r++) roff[r] = ((rot + r) % RING) * ROWB;
+    v16f a1[1];
+#pragma unroll
+    for (int r = 0; r < 16; r++) a1[0][r] = 0.f;
+    const int ac1[1] = {nr ? acol[1] : acol[0]};      // (this wave's `nr` picks the half of the row here)
+    conv_row_gemm<1>(patch, ac1, roff, wh, wl, h, a1);
+    ovf |= tile_to_lds(a1[0], csb, ctile + (((2 * pr0 - 1) % 3) * OW + nr * 32 + l32) * CPITCH, j1 * 32 + 4 * h);
+  }
   SSG_STEM_ACC(0)
 
-  const int acol = (2 * (half * 32 + l32) + 1) * 16;  // tap (r, s) of conv row i = row slot of py = 2i + r, + s*16
   const int npy = tid / (PCOLS / 4), ng = tid - npy * (PCOLS / 4);      // next-window item of this thread (threads 0..135)
   const int pp = tid >> 3, cg = tid & 7;              // pool: (pooled pixel, 8 channels)
-  unsigned ovf = 0u;
   for (int pr = pr0; pr < pr1; pr++) {
     const bool has_next = pr + 1 < pr1 && tid < 4 * (PCOLS / 4);
     // the 4 image rows the next window adds (its py = 7..10: iy = 4*pr + 6 + npy), in flight during the multiply
     const Item nx = load_item(ib, plane, H, has_next ? 4 * pr + 6 + npy : -1, ng, flip);
-    int roff[PROWS];
+    int roff[7];                                     // conv row 2*pr + nr: window rows py = 2 + 2*nr + r
 #pragma unroll
-    for (int py = 0; py < PROWS; py++) roff[py] = ((rot + py) % RING) * ROWB;
-
-    v16f acc[3];
+    for (int r = 0; r < 7; r++) roff[r] = ((rot + 2 + 2 * nr + r) % RING) * ROWB;
+    v16f acc[2];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < 2; i++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
-#pragma unroll
-    for (int t = 0; t < KSTEPS; t++) {
-      // taps of this half-wave: 4t + 2h and the next one (slots 49..55 carry zero weights: any valid address will do)
-      constexpr int NTAP = 49;
-      const int ta0 = 4 * t < NTAP ? 4 * t : 0, tb0 = 4 * t + 1 < NTAP ? 4 * t + 1 : 0, ta1 = 4 * t + 2 < NTAP ? 4 * t + 2 : 0, tb1 = 4 * t + 3 < NTAP ? 4 * t + 3 : 0;
-      v8h xh[3], xl[3];
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        const int oa = h ? roff[2 * i + ta1 / 7] + (ta1 % 7) * 16 : roff[2 * i + ta0 / 7] + (ta0 % 7) * 16;
-        const int ob = h ? roff[2 * i + tb1 / 7] + (tb1 % 7) * 16 : roff[2 * i + tb0 / 7] + (tb0 % 7) * 16;
-        const v4f t0 = *reinterpret_cast<const v4f*>(patch + acol + oa), t1 = *reinterpret_cast<const v4f*>(patch + acol + ob);
-        const v4f hi = {t0.x, t0.y, t1.x, t1.y}, lo = {t0.z, t0.w, t1.z, t1.w};
-        xh[i] = __builtin_bit_cast(v8h, hi); xl[i] = __builtin_bit_cast(v8h, lo);
-      }
-#pragma unroll
-      for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xl[i], acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[t], xh[i], acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < 3; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[t], xh[i], acc[i], 0, 0, 0);
-    }
-    __syncthreads();                                 // every wave is done with this window (and with the previous conv tile)
+    conv_row_gemm<2>(patch, acol, roff, wh, wl, h, acc);
+    __syncthreads();                                 // every wave is done with this window (and the previous step's pool with the conv rows)
     SSG_STEM_ACC(1)
 
     // next window's rows go to the slots this window no longer needs: py' = 7 + npy of rot' = rot + 4
     if (has_next) store_item(patch + ((rot + 11 + npy) % RING) * ROWB + ng * 64, nx, flip);
-    // conv tile -> LDS (fp32): bias, ReLU, and the encode / decode round trip the separate maxpool kernel saw
+    {
+      unsigned char* crow = ctile + (((2 * pr + nr) % 3) * OW) * CPITCH;
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
-      const int cp = i * OW + half * 32 + l32;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int ch = j1 * 32 + 8 * q + 4 * h;
-        const float4 c4 = *reinterpret_cast<const float4*>(csb + ch), b4 = *reinterpret_cast<const float4*>(csb + 64 + ch);
-        float4 v = make_float4(acc[i][4 * q] * c4.x + b4.x, acc[i][4 * q + 1] * c4.y + b4.y, acc[i][4 * q + 2] * c4.z + b4.z, acc[i][4 * q + 3] * c4.w + b4.w);
-        v = make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
-        uint2 hi, lo;
-        enc4(v, hi, lo);
-        ovf |= ((hi.x & 0x7c007c00u) + 0x04000400u) | ((hi.y & 0x7c007c00u) + 0x04000400u);
-        *reinterpret_cast<float4*>(ctile + cp * CPITCH + ch * 4) = dec4(hi, lo);
-      }
+      for (int i = 0; i < 2; i++) ovf |= tile_to_lds(acc[i], csb, crow + (i * 32 + l32) * CPITCH, j1 * 32 + 4 * h);
     }
     __syncthreads();
     SSG_STEM_ACC(2)
 
-    // MaxPool 3x3 / 2, pad 1 over the tile
+    // MaxPool 3x3 / 2, pad 1 over conv rows 2*pr - 1 .. 2*pr + 1
     float4 m0 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY), m1 = m0;
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      if (2 * pr - 1 + r < 0) continue;              // (2*pr + 1 <= H/2 - 1 always)
+      const int c = 2 * pr - 1 + r;
+      if (c < 0) continue;                           // (2*pr + 1 <= H/2 - 1 always)
+      const unsigned char* crow = ctile + ((c % 3) * OW) * CPITCH;
 #pragma unroll
       for (int s = 0; s < 3; s++) {
         const int ox = 2 * pp - 1 + s;
         if (ox < 0) continue;
-        const float* q = reinterpret_cast<const float*>(ctile + (r * OW + ox) * CPITCH) + cg * 8;
-        const float4 a = *reinterpret_cast<const float4*>(q), c = *reinterpret_cast<const float4*>(q + 4);
+        const float* q = reinterpret_cast<const float*>(crow + ox * CPITCH) + cg * 8;
+        const float4 a = *reinterpret_cast<const float4*>(q), c4 = *reinterpret_cast<const float4*>(q + 4);
         m0.x = fmaxf(m0.x, a.x); m0.y = fmaxf(m0.y, a.y); m0.z = fmaxf(m0.z, a.z); m0.w = fmaxf(m0.w, a.w);
-        m1.x = fmaxf(m1.x, c.x); m1.y = fmaxf(m1.y, c.y); m1.z = fmaxf(m1.z, c.z); m1.w = fmaxf(m1.w, c.w);
+        m1.x = fmaxf(m1.x, c4.x); m1.y = fmaxf(m1.y, c4.y); m1.z = fmaxf(m1.z, c4.z); m1.w = fmaxf(m1.w, c4.w);
       }
     }
     uint2 ha, la, hb, lb;
@@ -220,7 +250,7 @@ extern "C" int ssg_stem_pool_nchw_x(const float* images, int flip, const void* w
     return SSG_ERR_INVALID;
   }
   static int rs = -1;                          // pooled rows per workgroup (SSG_STEM_STRIP, tuning knob)
-  if (rs < 0) { const char* e = getenv("SSG_STEM_STRIP"); rs = e ? atoi(e) : 8; if (rs < 1) rs = 1; }
+  if (rs < 0) { const char* e = getenv("SSG_STEM_STRIP"); rs = e ? atoi(e) : 16; if (rs < 1) rs = 1; }
   const int strips = (H / 4 + rs - 1) / rs;
   hipLaunchKernelGGL(ssg::stem::stem_pool_kernel, dim3(B * strips), dim3(256), 0, stream, images, flip, (const float*)w, bias, ch_scale, (float*)out, B, H,
                      rs, overflow);
