@@ -784,6 +784,43 @@ def test_split_half_on_checkpoint_like_weights(dev):
     assert errs["f32"] < 1e-5 and errs["split"] < 1e-5 and errs["split"] < 3.0 * errs["f32"] + 2e-7
 
 
+@pytest.mark.parametrize("B,H", [(3, 256), (2, 96), (2, 104)])
+def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkeypatch):
+    """ssg_stem_pool_nchw_x (image -> conv1 + bn + relu -> maxpool in one launch) and ssg_bottleneck[_ds]_nhwc_x (a whole layer1
+    block in one launch) against the launch-per-layer path they replace: same k-steps, product order and epilogues, so the
+    layer4 map must be bit-identical.  H = 104: ragged last strip of the stem, layer1 height 26 has no fused block kernel
+    (falls back per block); H = 96: short images through both fused kernels."""
+    import ssg_amd
+    from ssg_amd import _lib
+    m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=5).cuda().eval()
+    imgs = torch.randn(B, 3, H, 128, generator=torch.Generator().manual_seed(21)).cuda()
+    L = _lib.lib()
+    assert L.ssg_stem_pool_supported(H, 128) == 1 and L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64) == (1 if (H // 4) % 4 == 0 else 0)
+    assert L.ssg_bottleneck_supported(H // 4, 32, 64, 256, 64) == L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64)
+    assert L.ssg_bottleneck_supported(32, 16, 512, 512, 128) == 0         # layer2 shapes: separate launches
+    maps = {}
+    for stem, bneck in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("SSG_FUSED_STEM", stem); monkeypatch.setenv("SSG_FUSED_BOTTLENECK", bneck)
+        for flip in (False, True):
+            y, sp = m._fmap(imgs, flip=flip)
+            assert sp and not m._overflowed()
+            maps[(stem, bneck, flip)] = y.clone()
+    for flip in (False, True):
+        ref = maps[("0", "0", flip)]
+        for k in (("1", "1"), ("0", "1"), ("1", "0")):
+            assert torch.equal(maps[k + (flip,)].view(torch.int32), ref.view(torch.int32)), (k, flip)
+    assert not torch.equal(maps[("1", "1", False)], maps[("1", "1", True)])
+    # the fused kernels raise the same range flag as the separate launches
+    big = 3.0e4 * imgs
+    m._fmap(big); assert m._overflowed()
+    with pytest.raises(ValueError, match="unsupported block"):       # shapes without a fused kernel are refused, not mis-run
+        x = torch.zeros(1, 16, 16, 128, device="cuda")
+        blk = m._prepare()["blocks"][4]
+        _lib.check(L.ssg_bottleneck_nhwc_x(_lib.ptr(x), _lib.ptr(blk["c1"].w), _lib.ptr(blk["c1"].bias), _lib.ptr(blk["c1"].cscale), _lib.ptr(blk["c2"].w),
+                                           _lib.ptr(blk["c2"].bias), _lib.ptr(blk["c2"].cscale), _lib.ptr(blk["c3"].w), _lib.ptr(blk["c3"].bias),
+                                           _lib.ptr(blk["c3"].cscale), _lib.ptr(torch.empty_like(x)), 1, 16, 16, 512, 128, None, _lib.stream()), "bottleneck")
+
+
 def test_split_half_overflow_falls_back_to_f32(dev):
     """Activations beyond the half range (|v| >= 65520): every entry point notices (device flag raised by the encoding
     epilogue), warns once and returns the fp32-path result instead of inf / NaN / clipped features."""
