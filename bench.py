@@ -47,7 +47,7 @@ class KernelTimer:
 
     def __getattr__(self, k):
         fn = getattr(self.L, k)
-        if not self.on or not self.sample or not k.startswith("ssg_") or k.endswith("_bytes") or k in (
+        if not self.on or not self.sample or not k.startswith("ssg_") or k.endswith("_bytes") or k.endswith("_supported") or k in (
                 "ssg_last_error", "ssg_krecip_row_capacity", "ssg_double_to_half_bits", "ssg_version", "ssg_eps_mean_prepare"):
             return fn
 
@@ -261,8 +261,12 @@ def main():
         return
     n_img = args.N + args.Ns
     # ---- roofline of the dominant kernel: implicit-GEMM convolution on the fp32 matrix cores
-    convs = [tot[k] for k in ("ssg_conv2d_nhwc_x", "ssg_conv1x1_dual_nhwc_x", "ssg_conv2d_nhwc_f32", "ssg_conv1x1_dual_nhwc_f32") if k in tot]
+    CONV_ABI = ("ssg_conv2d_nhwc_x", "ssg_conv1x1_dual_nhwc_x", "ssg_conv2d_nhwc_f32", "ssg_conv1x1_dual_nhwc_f32",
+                "ssg_stem_pool_nchw_x", "ssg_bottleneck_nhwc_x", "ssg_bottleneck_ds_nhwc_x")     # every launch that carries convolution flops
+    convs = [tot[k] for k in CONV_ABI if k in tot]
     n_conv, ms_conv = (sum(c[0] for c in convs), sum(c[1] for c in convs)) if convs else (1, float("nan"))
+    n_conv_per_fwd = round(n_conv * args.batch / max(2 * timer.sampled_images, 1)) if convs else 0
+    launches_by_abi = {k: {"launches": tot[k][0], "ms": round(tot[k][1], 3)} for k in CONV_ABI if k in tot}
     imgs_rank = (t_hi - t_lo) + (s_hi - s_lo)
     conv_tf = timer.sampled_images * FLOP_PER_IMAGE / (ms_conv * 1e-3) / 1e12     # launches and images of the sampled batches
     split = precision == "split"
@@ -270,18 +274,19 @@ def main():
     # fp32-equivalent ceiling of the fp16 matrix cores is a third of their dense peak; frac = executed/peak either way
     peak = PEAK_FP16_MFMA_TF / 3.0 if split else PEAK_FP32_MFMA_TF
     roof = {"bound": "mfma",
-            "kernel": ("conv_igemm_kernel, split-half fp32 on v_mfma_f32_32x32x16_f16 (3 MFMA products per multiply, fp32 accumulate), "
-                       "53 convs x 2 orientations per image" if split else
+            "kernel": ("the convolution stack of the embedding, split-half fp32 on v_mfma_f32_32x32x16_f16 (3 MFMA products per multiply, fp32 "
+                       "accumulate): conv_dma_kernel / conv_igemm_kernel launches plus the fused stem (conv1 + bn + relu + maxpool) and the fused "
+                       "layer1 bottleneck blocks; 53 convolutions x 2 orientations per image in %d launches per forward" % (n_conv_per_fwd,) if split else
                        "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2, 53 convs x 2 orientations per image)"),
             "achieved": round(conv_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
-            "traffic": None, "launches": n_conv, "avg_launch_ms": round(ms_conv / max(n_conv, 1), 4),
-            "algorithmic": "10.68 GFLOP per image (2 forwards x 5.34 GFLOP); HIP events around every conv launch of every 4th batch: %d of the "
+            "traffic": None, "launches": n_conv, "avg_launch_ms": round(ms_conv / max(n_conv, 1), 4), "launches_by_abi": launches_by_abi,
+            "algorithmic": "10.68 GFLOP per image (2 forwards x 5.34 GFLOP); HIP events around every convolution-carrying launch of every 4th batch: %d of the "
                            "%d images embedded in the timed steps" % (timer.sampled_images, imgs_rank * args.steps)}
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, collected on this
     # kernel set at the same batch size); null when the configuration differs from the profiled one
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")))
-        if split and pm["batch"] == args.batch:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv_traffic.json")))
+        if split and pm["batch"] == args.batch and pm["launches_per_forward"] == n_conv_per_fwd:
             per = (pm["fetch_bytes_per_forward"] + pm["write_bytes_per_forward"]) / pm["launches_per_forward"]
             roof["traffic"] = round(per)
             roof["traffic_note"] = ("HBM bytes per conv launch (average over the %d launches of a forward, batch %d) from %s; algorithmic %.0f"

@@ -151,6 +151,11 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     if (NCH > 4) *reinterpret_cast<uint4*>(b_ + lo[4]) = p##S##4;                                     \
     if (NCH > 5) *reinterpret_cast<uint4*>(b_ + lo[5]) = p##S##5;                                     \
   }
+#ifdef SSG_GI_NO_LOADS          // ablation (tools/micro/gram_prof.hip): stage 0 only, the loop re-stores the same registers
+#undef SSG_GL
+#define SSG_GL(S, ST) { if ((ST) == 0 && st_dummy_ == 0) { p##S##0 = gp[0][0]; if (NCH > 1) p##S##1 = gp[1][0]; if (NCH > 2) p##S##2 = gp[2][0]; } }
+  const int st_dummy_ = 0;
+#endif
   SSG_GL(a, 0)
   SSG_LS(a, 0)
   { const int s1 = min(1, nst - 1); SSG_GL(a, s1) }
@@ -172,6 +177,15 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
 #undef SSG_GL
 #undef SSG_LS
 
+#ifdef SSG_GI_NO_EPI            // ablation: one store per lane keeps the accumulators alive
+  { int sum_ = 0;
+#pragma unroll
+    for (int w = 0; w < NACC; w++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) sum_ += acc[w][r];
+    if (sum_ == 0x7fffffff) D[0] = (hbits)sum_;
+    return; }
+#endif
   // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31 -> B row (j), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> A row (i).
   const int gj = tn * GI_T + wn * 32 + l32;
   const bool jok = gj < N;
