@@ -53,13 +53,15 @@ struct Params {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
-template <int C, int MID, int IW, int TH, int CIN = C>
+template <int C, int MID, int IW, int TH, int CIN = C, int NW = 4>
 struct Cfg {
   static constexpr int HROWS = TH + 2, NPIX1 = HROWS * IW, NPIX = TH * IW;
+  static constexpr int NTHR = NW * 64, RPP = NTHR / 4;  // 64-byte k-tile rows staged per pass of the workgroup
+  static constexpr int XROWS = (NPIX1 + RPP - 1) / RPP * RPP;      // x rows of a phase-1 stage, padded to whole passes (the padding loads return zeros)
   static constexpr int P1 = 80;                        // LDS pitch of a 64-byte k-tile row (pitch/16 odd: conflict-free b128)
   static constexpr int P2 = 144;                       // ... of a 128-byte k-tile row
   static constexpr int PY = MID * 4 + 16;              // ... of a y1 / y2 pixel row (all MID channels, h8l8)
-  static constexpr int BUF1 = (NPIX1 + MID) * P1;      // phase-1 stage: x rows, then W1 rows
+  static constexpr int BUF1 = (XROWS + MID) * P1;      // phase-1 stage: x rows, then W1 rows
   static constexpr int ZERO_OFF = NPIX1 * PY;          // one all-zero pixel row (conv2's left / right padding)
   static constexpr int W2_OFF = (ZERO_OFF + PY + 255) / 256 * 256, BUF2 = MID * P2;
   static constexpr int W3_OFF = (NPIX * PY + 255) / 256 * 256, BUF3 = C * P1;
@@ -67,9 +69,10 @@ struct Cfg {
   static constexpr int DS = CIN != C;                  // downsample variant: conv3's reduction is [y2 | x]
   static constexpr int NK1 = CIN / 16, NK2 = (MID / 32) * 9, NK3 = (MID + (DS ? CIN : 0)) / 16;
   static constexpr int PD1 = NK1 < 8 ? NK1 : 8, PD2 = 6;               // (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)               // k-tiles of global loads in flight ahead of the multiply
-  static_assert(NPIX == 128 && NPIX1 % 64 == 0 && MID % 64 == 0 && C % 64 == 0, "4 waves x 32 output pixels");
+  static_assert((NW == 4 || NW == 8) && NPIX == 128 && NPIX1 % 32 == 0 && MID % RPP == 0 && C % RPP == 0 && MID % (NW * 8) == 0, "128 output pixels, whole staging passes");
   static_assert(2 * BUF1 <= ZERO_OFF, "the zero row is written while phase 1 runs");
-  static_assert(LDS <= 80 * 1024, "two workgroups per CU");
+  static_assert(LDS <= (NW == 4 ? 80 : 160) * 1024, "4 waves: two workgroups per CU; 8 waves: one");
+  static_assert(NW == 4 || NW * 32 * 36 * 4 <= 2 * BUF3, "8 waves: the epilogue patches take over the W3 stages");
 };
 
 __device__ __forceinline__ unsigned pack2(_Float16 a, _Float16 b) {
@@ -96,9 +99,9 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 // x*w = xh*wl + xl*wh + xh*wh (the order of conv.hip's split_mma_step), weights as the first MFMA operand:
 // C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> channel
 
-template <int C, int MID, int IW, int TH, int CIN>
-__global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
-  using K = Cfg<C, MID, IW, TH, CIN>;
+template <int C, int MID, int IW, int TH, int CIN, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Params p) {
+  using K = Cfg<C, MID, IW, TH, CIN, NW>;
   constexpr bool DS = K::DS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, h = lane >> 5;
@@ -113,15 +116,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   if (tid < K::PY / 16) *reinterpret_cast<uint4*>(smem + K::ZERO_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
   // =========================== phase 1: y1 = relu(conv1(x)) on the TH+2 halo rows ===========================
-  constexpr int AU = K::NPIX1 / 64, WU = MID / 64;          // 16-byte pieces per thread and k-tile: x rows, W1 rows
+  constexpr int RPP = K::RPP, AU = K::XROWS / RPP, WU = MID / RPP;   // 16-byte pieces per thread and k-tile: x rows, W1 rows
   const int ck = tid & 3, r0 = tid >> 2;
   const float* ximg = p.x + (int64_t)img * p.H * IW * CIN;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (unsigned)(p.H * IW * CIN * 4), 0x00020000);
   unsigned aoff[AU];
 #pragma unroll
   for (int u = 0; u < AU; u++) {
-    const int pix = (ty0 - 1) * IW + r0 + 64 * u;           // rows above / below the image: out-of-range offset -> the load returns zeros
-    aoff[u] = (pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * CIN + ck * 4) * 4) : 0x80000000u;
+    const int hp = r0 + RPP * u, pix = (ty0 - 1) * IW + hp;  // rows above / below the image (and the padding rows of the stage): out-of-range offset -> the load returns zeros
+    aoff[u] = (hp < K::NPIX1 && pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * CIN + ck * 4) * 4) : 0x80000000u;
   }
   const float* w1p = p.w1 + (int64_t)r0 * CIN + ck * 4;
   v4f sa[K::PD1][AU], sw[K::PD1][WU];
@@ -131,19 +134,20 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[u], (T_) * 64, 0);                            \
       sa[S_][u] = __builtin_bit_cast(v4f, raw);                                                                     \
     }                                                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < WU; u++) sw[S_][u] = *reinterpret_cast<const v4f*>(w1p + (int64_t)(64 * u) * CIN + (T_) * 16); \
+    _Pragma("unroll") for (int u = 0; u < WU; u++) sw[S_][u] = *reinterpret_cast<const v4f*>(w1p + (int64_t)(RPP * u) * CIN + (T_) * 16); \
   }
 #define SSG_BN_STORE1(BUF_, S_)                                                                                      \
   {                                                                                                                  \
     unsigned char* sb_ = smem + (BUF_) * K::BUF1;                                                                    \
-    _Pragma("unroll") for (int u = 0; u < AU; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + 64 * u) * K::P1 + ck * 16) = sa[S_][u]; \
-    _Pragma("unroll") for (int u = 0; u < WU; u++) *reinterpret_cast<v4f*>(sb_ + (K::NPIX1 + r0 + 64 * u) * K::P1 + ck * 16) = sw[S_][u]; \
+    _Pragma("unroll") for (int u = 0; u < AU; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + RPP * u) * K::P1 + ck * 16) = sa[S_][u]; \
+    _Pragma("unroll") for (int u = 0; u < WU; u++) *reinterpret_cast<v4f*>(sb_ + (K::XROWS + r0 + RPP * u) * K::P1 + ck * 16) = sw[S_][u]; \
   }
-  // MFMA tiles of phase 1: (NPIX1/32) pixel tiles x (MID/32) channel tiles over 4 waves
+  // MFMA tiles of phase 1: (NPIX1/32) pixel tiles x (MID/32) channel tiles over the waves
   constexpr int MT1 = K::NPIX1 / 32, NT1 = MID / 32;
-  // waves are split as WR x WC with WC = min(NT1, 2): each wave owns MT1/WR pixel tiles x NT1/WC channel tiles
-  constexpr int WC1 = NT1 >= 2 ? 2 : 1, WR1 = 4 / WC1, MTW1 = MT1 / WR1, NTW1 = NT1 / WC1;
-  static_assert(MT1 % WR1 == 0 && NT1 % WC1 == 0, "phase-1 tiles divide over the waves");
+  // waves are split as WR x WC with WC = min(NT1, NW/2): each wave owns ceil(MT1/WR) pixel tiles x NT1/WC channel tiles (a pixel tile
+  // beyond MT1 multiplies the zero padding rows of the stage and is not written)
+  constexpr int WC1 = NT1 < NW / 2 ? NT1 : NW / 2, WR1 = NW / WC1, MTW1 = (MT1 + WR1 - 1) / WR1, NTW1 = NT1 / WC1;
+  static_assert(NT1 % WC1 == 0 && (WR1 * MTW1) * 32 <= K::XROWS, "phase-1 tiles divide over the waves");
   const int i1b = (wave / WC1) * MTW1, j1b = (wave % WC1) * NTW1;
   v16f acc1[MTW1][NTW1];
 #pragma unroll
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       const unsigned char* q_ = sb_ + ((i1b + i) * 32 + l32) * K::P1 + h * 32;                                       \
       xh_[i] = *reinterpret_cast<const v8h*>(q_); xl_[i] = *reinterpret_cast<const v8h*>(q_ + 16); }                 \
     _Pragma("unroll") for (int j = 0; j < NTW1; j++) {                                                               \
-      const unsigned char* q_ = sb_ + (K::NPIX1 + (j1b + j) * 32 + l32) * K::P1 + h * 32;                            \
+      const unsigned char* q_ = sb_ + (K::XROWS + (j1b + j) * 32 + l32) * K::P1 + h * 32;                            \
       wh_[j] = *reinterpret_cast<const v8h*>(q_); wl_[j] = *reinterpret_cast<const v8h*>(q_ + 16); }                 \
     _Pragma("unroll") for (int i = 0; i < MTW1; i++) _Pragma("unroll") for (int j = 0; j < NTW1; j++)                \
       acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xl_[i], acc1[i][j], 0, 0, 0);                      \
@@ -205,15 +209,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 #undef SSG_BN_MMA1
 
   // ---- conv2 weights: first k-tiles on their way while y1 is written
-  constexpr int BU = MID / 32;                              // 16-byte pieces per thread and W2 k-tile (MID rows x 128 B)
+  constexpr int RP8 = K::NTHR / 8, BU = MID / RP8;          // 16-byte pieces per thread and W2 k-tile (MID rows x 128 B)
   const int ck8 = tid & 7, r8 = tid >> 3;
   const float* w2p = p.w2 + (int64_t)r8 * (9 * MID) + ck8 * 4;
   v4f sb2[K::PD2][BU];
 #define SSG_BN_LOAD2(T_, S_)                                                                                         \
-  { _Pragma("unroll") for (int u = 0; u < BU; u++) sb2[S_][u] = *reinterpret_cast<const v4f*>(w2p + (int64_t)(32 * u) * (9 * MID) + (T_) * 32); }
+  { _Pragma("unroll") for (int u = 0; u < BU; u++) sb2[S_][u] = *reinterpret_cast<const v4f*>(w2p + (int64_t)(RP8 * u) * (9 * MID) + (T_) * 32); }
 #define SSG_BN_STORE2(BUF_, S_)                                                                                      \
   { unsigned char* sb_ = smem + K::W2_OFF + (BUF_) * K::BUF2;                                                        \
-    _Pragma("unroll") for (int u = 0; u < BU; u++) *reinterpret_cast<v4f*>(sb_ + (r8 + 32 * u) * K::P2 + ck8 * 16) = sb2[S_][u]; }
+    _Pragma("unroll") for (int u = 0; u < BU; u++) *reinterpret_cast<v4f*>(sb_ + (r8 + RP8 * u) * K::P2 + ck8 * 16) = sb2[S_][u]; }
   static_assert(K::PD2 == 6 && K::NK2 % 6 == 0, "phase-2 ring of six register sets");
   SSG_BN_LOAD2(0, 0) SSG_BN_LOAD2(1, 1) SSG_BN_LOAD2(2, 2) SSG_BN_LOAD2(3, 3) SSG_BN_LOAD2(4, 4) SSG_BN_LOAD2(5, 5)
 
@@ -221,6 +225,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   unsigned ovf = 0u;
 #pragma unroll
   for (int i = 0; i < MTW1; i++) {
+    if (i1b + i >= MT1) continue;                           // (a padding tile of the last wave row)
     const int hp0 = (i1b + i) * 32;                         // first halo pixel of this MFMA tile
     const int irow = ty0 - 1 + (hp0 + l32) / IW;
     const bool inside = irow >= 0 && irow < p.H;
@@ -246,19 +251,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   SSG_BN_STAMP(2)
 
   // =========================== phase 2: y2 = relu(conv2_3x3(y1)), pixel operand from LDS ===========================
-  constexpr int NT2 = MID / 32;
+  // waves: 4 pixel tiles x WC2 channel groups of NT2 channel tiles each
+  constexpr int WC2 = NW / 4, NT2 = MID / 32 / WC2;
+  const int pt2 = wave / WC2, cb2 = (wave % WC2) * NT2;
   v16f acc2[NT2];
 #pragma unroll
   for (int j = 0; j < NT2; j++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc2[j][r] = 0.f;
-  const int m2 = wave * 32 + l32, ty2 = m2 / IW, tx2 = m2 - ty2 * IW;      // this lane's output pixel (tile-local)
+  const int m2 = pt2 * 32 + l32, ty2 = m2 / IW, tx2 = m2 - ty2 * IW;       // this lane's output pixel (tile-local)
   float4 cs2r[NT2][4], b2r[NT2][4];                        // needed right after the loop
 #pragma unroll
   for (int j = 0; j < NT2; j++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      cs2r[j][q] = *reinterpret_cast<const float4*>(p.cs2 + j * 32 + 8 * q + 4 * h); b2r[j][q] = *reinterpret_cast<const float4*>(p.b2 + j * 32 + 8 * q + 4 * h);
+      cs2r[j][q] = *reinterpret_cast<const float4*>(p.cs2 + (cb2 + j) * 32 + 8 * q + 4 * h); b2r[j][q] = *reinterpret_cast<const float4*>(p.b2 + (cb2 + j) * 32 + 8 * q + 4 * h);
     }
 #define SSG_BN_STEP2(KT_, S_)                                                                                        \
   {                                                                                                                  \
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       const int chunk = (KT_) / 9, tap = (KT_) - chunk * 9, r = tap / 3, s = tap - r * 3;                            \
       const int xin = tx2 + s - 1;                                                                                   \
       const int abase = (xin >= 0 && xin < IW) ? ((ty2 + r) * IW + xin) * K::PY : K::ZERO_OFF;                       \
-      const unsigned char* wb = smem + K::W2_OFF + ((S_) & 1) * K::BUF2 + l32 * K::P2 + h * 32;                      \
+      const unsigned char* wb = smem + K::W2_OFF + ((S_) & 1) * K::BUF2 + (cb2 * 32 + l32) * K::P2 + h * 32;         \
       v8h xh_[2], xl_[2], wh_[2][NT2], wl_[2][NT2];                                                                  \
       _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {                                                             \
         const unsigned char* q_ = smem + abase + (chunk * 4 + ks * 2 + h) * 32;                                      \
@@ -295,18 +302,21 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 #undef SSG_BN_STORE2
 
   // ---- conv3 weights: k-tiles 0 and 1 on their way while y2 is written (every wave is past its last y1 / W2 read)
-  constexpr int CU3 = C / 64;                               // 16-byte pieces per thread and W3 k-tile (C rows x 64 B)
+  constexpr int CU3 = C / RPP;                              // 16-byte pieces per thread and W3 k-tile (C rows x 64 B)
   constexpr int K3 = MID + (DS ? CIN : 0);                 // conv3's reduction length (the weight row)
   const float* w3p = p.w3 + (int64_t)r0 * K3 + ck * 4;
   v4f sc3[2][CU3];
 #define SSG_BN_LOAD3(T_, S_)                                                                                         \
-  { _Pragma("unroll") for (int u = 0; u < CU3; u++) sc3[S_][u] = *reinterpret_cast<const v4f*>(w3p + (int64_t)(64 * u) * K3 + (T_) * 16); }
+  { _Pragma("unroll") for (int u = 0; u < CU3; u++) sc3[S_][u] = *reinterpret_cast<const v4f*>(w3p + (int64_t)(RPP * u) * K3 + (T_) * 16); }
 #define SSG_BN_STORE3(BUF_, S_)                                                                                      \
   { unsigned char* sb_ = smem + K::W3_OFF + (BUF_) * K::BUF3;                                                        \
-    _Pragma("unroll") for (int u = 0; u < CU3; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + 64 * u) * K::P1 + ck * 16) = sc3[S_][u]; }
+    _Pragma("unroll") for (int u = 0; u < CU3; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + RPP * u) * K::P1 + ck * 16) = sc3[S_][u]; }
   SSG_BN_LOAD3(0, 0)
   SSG_BN_LOAD3(1, 1)
-  const int64_t gpix0 = ((int64_t)img * p.H + ty0) * IW + wave * 32;       // first output pixel of this wave (pixels are contiguous)
+  // phase-3 waves: 4 pixel tiles x WC3 channel groups of NT3 channel tiles each
+  constexpr int WC3 = NW / 4, NT3 = C / 32 / WC3;
+  const int pt3 = wave / WC3, cb3 = (wave % WC3) * NT3;
+  const int64_t gpix0 = ((int64_t)img * p.H + ty0) * IW + pt3 * 32;        // first output pixel of this wave (pixels are contiguous)
   // DS: the downsample operand, this lane's pixel, k-tiles MID/16 .. NK3-1 = channels of x: [8 hi][8 lo] of group h per k-tile
   constexpr int NXK = DS ? CIN / 16 : 1;
   v8h xrh[NXK], xrl[NXK];
@@ -315,25 +325,25 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 #pragma unroll
     for (int t = 0; t < NXK; t++) { xrh[t] = *reinterpret_cast<const v8h*>(xq + t * 16); xrl[t] = *reinterpret_cast<const v8h*>(xq + t * 16 + 4); }
   }
-  // y2 rows of this wave's 32 pixels (written and read by this wave only)
-  unsigned char* myrows = smem + (wave * 32) * K::PY;
+  // y2 rows: phase 2 writes the rows of pixel tile pt2 (its channel group), phase 3 reads those of pt3 (4 waves: the same
+  // wave, 8 waves: a wave pair -- the barrier before the first multiply of phase 3 publishes them either way)
+  unsigned char* myrows = smem + (pt3 * 32) * K::PY;
 #pragma unroll
   for (int j = 0; j < NT2; j++)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int ch = j * 32 + 8 * q + 4 * h;
+      const int ch = (cb2 + j) * 32 + 8 * q + 4 * h;
       const float4 cs = cs2r[j][q], bi = b2r[j][q];
       float4 v = make_float4(acc2[j][4 * q] * cs.x + bi.x, acc2[j][4 * q + 1] * cs.y + bi.y, acc2[j][4 * q + 2] * cs.z + bi.z, acc2[j][4 * q + 3] * cs.w + bi.w);
       v = relu4(v);
       uint2 hi, lo;
       encode4(v, hi, lo);
       ovf |= hi_nonfinite_bits(hi);
-      unsigned char* d = myrows + l32 * K::PY + (ch >> 3) * 32 + h * 8;
+      unsigned char* d = smem + (pt2 * 32 + l32) * K::PY + (ch >> 3) * 32 + h * 8;
       *reinterpret_cast<uint2*>(d) = hi; *reinterpret_cast<uint2*>(d + 16) = lo;
     }
 
   // =========================== phase 3: out = relu(conv3(y2) + x) ===========================
-  constexpr int NT3 = C / 32;
   static_assert(K::NK3 % 2 == 0, "phase 3 takes its k-tiles in rounds of two buffers");
   v16f acc3[NT3];
 #pragma unroll
@@ -348,7 +358,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       const unsigned char* q_ = myrows + l32 * K::PY + (((KT_) % (MID / 16)) * 2 + h) * 32;                          \
       xh_ = *reinterpret_cast<const v8h*>(q_); xl_ = *reinterpret_cast<const v8h*>(q_ + 16);                         \
     }                                                                                                                \
-    const unsigned char* wb_ = smem + K::W3_OFF + (BUF_) * K::BUF3 + l32 * K::P1 + h * 32;                           \
+    const unsigned char* wb_ = smem + K::W3_OFF + (BUF_) * K::BUF3 + (cb3 * 32 + l32) * K::P1 + h * 32;              \
     _Pragma("unroll") for (int jj = 0; jj < NT3; jj += 4) {                                                          \
       v8h wh_[4], wl_[4];                                                                                            \
       _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                                \
@@ -380,9 +390,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
       if constexpr ((R_) + 2 < K::NK3 / 2) { SSG_BN_LOAD3(2 * (R_) + 4, 0) SSG_BN_LOAD3(2 * (R_) + 5, 1) }           \
       else {                                 /* last round ahead: the W3 staging registers are free for the epilogue's first operands */ \
         if constexpr (!DS) {                                                                                         \
-          _Pragma("unroll") for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + chunk * 4); \
+          _Pragma("unroll") for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + cb3 * 32 + chunk * 4); \
         }                                                                                                            \
-        b3r[0] = *reinterpret_cast<const float4*>(p.b3 + chunk * 4); cs3r[0] = *reinterpret_cast<const float4*>(p.cs3 + chunk * 4); \
+        b3r[0] = *reinterpret_cast<const float4*>(p.b3 + cb3 * 32 + chunk * 4); cs3r[0] = *reinterpret_cast<const float4*>(p.cs3 + cb3 * 32 + chunk * 4); \
       }                                                                                                              \
       __syncthreads();                                                                                               \
     }                                                                                                                \
@@ -397,10 +407,15 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
   // ---- epilogue: per channel tile a 32-pixel x 32-channel patch through LDS (this wave's own, now dead, y2 rows), then
   // whole 128-byte row segments: bias, residual (x, h8l8), ReLU, re-encode, store.  Same code path as conv.hip.
   static_assert(32 * EP * 4 <= 32 * K::PY, "patch fits in the wave's y2 rows");
-  float* patch = reinterpret_cast<float*>(myrows);
+  float* patch;
+  if constexpr (WC3 == 1) patch = reinterpret_cast<float*>(myrows);       // its y2 rows are this wave's alone and dead now
+  else {                                                                  // rows shared by a wave pair: the patches take over the W3 stages
+    __syncthreads();
+    patch = reinterpret_cast<float*>(smem + K::W3_OFF) + wave * (32 * EP);
+  }
 #pragma unroll
   for (int j = 0; j < NT3; j++) {
-    const int col = j * 32 + chunk * 4;
+    const int col = (cb3 + j) * 32 + chunk * 4;
     if (j + 1 < NT3) {
       if constexpr (!DS) {
 #pragma unroll
@@ -451,21 +466,25 @@ __global__ __launch_bounds__(256, 2) void bottleneck_kernel(Params p) {
 }  // namespace bneck
 }  // namespace ssg
 
-// 1 when ssg_bottleneck_nhwc_x / ssg_bottleneck_ds_nhwc_x has a kernel for this block shape (CIN == C: identity block)
+// 1 when ssg_bottleneck_nhwc_x / ssg_bottleneck_ds_nhwc_x has a kernel for this block shape (CIN == C: identity block):
+//   layer1 of ResNet-50 at 256x128 input: H x 32 x 256, MID 64 (identity blocks and the first block, CIN = 64), 4-row tiles;
+//   layer2 identity blocks: H x 16 x 512, MID 128, 8-row tiles (one 8-wave workgroup per CU: the 128-channel halo intermediate is 85 KB)
 extern "C" int ssg_bottleneck_supported(int H, int W, int CIN, int C, int MID) {
-  return (C == 256 && MID == 64 && (CIN == 256 || CIN == 64) && W == 32 && H > 0 && H % 4 == 0) ? 1 : 0;
+  if (C == 256 && MID == 64 && (CIN == 256 || CIN == 64) && W == 32 && H > 0 && H % 4 == 0) return 1;
+  if (C == 512 && MID == 128 && CIN == 512 && W == 16 && H > 0 && H % 8 == 0) return 1;
+  return 0;
 }
 
-template <int CIN>
+template <int C, int MID, int IW, int TH, int CIN, int NW>
 static int launch_bottleneck(const ssg::bneck::Params& p, hipStream_t stream) {
   using namespace ssg::bneck;
-  using K = Cfg<256, 64, 32, 4, CIN>;
+  using K = Cfg<C, MID, IW, TH, CIN, NW>;
   static bool attr_set = false;
   if (!attr_set) {
-    SSG_HIP(hipFuncSetAttribute((const void*)bottleneck_kernel<256, 64, 32, 4, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
+    SSG_HIP(hipFuncSetAttribute((const void*)bottleneck_kernel<C, MID, IW, TH, CIN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS));
     attr_set = true;
   }
-  hipLaunchKernelGGL((bottleneck_kernel<256, 64, 32, 4, CIN>), dim3(p.B * (p.H / 4)), dim3(256), K::LDS, stream, p);
+  hipLaunchKernelGGL((bottleneck_kernel<C, MID, IW, TH, CIN, NW>), dim3(p.B * (p.H / TH)), dim3(NW * 64), K::LDS, stream, p);
   SSG_LAUNCH_CHECK("bottleneck_kernel");
   return SSG_OK;
 }
@@ -486,7 +505,8 @@ extern "C" int ssg_bottleneck_nhwc_x(const void* x, const void* w1, const float*
   p.x = (const float*)x; p.out = (float*)out;
   p.w1 = (const float*)w1; p.b1 = b1; p.cs1 = cs1; p.w2 = (const float*)w2; p.b2 = b2; p.cs2 = cs2; p.w3 = (const float*)w3; p.b3 = b3; p.cs3 = cs3;
   p.B = B; p.H = H; p.overflow = overflow;
-  return launch_bottleneck<256>(p, stream);
+  if (C == 512) return launch_bottleneck<512, 128, 16, 8, 512, 8>(p, stream);
+  return launch_bottleneck<256, 64, 32, 4, 256, 4>(p, stream);
 }
 
 // Bottleneck block with a stride-1 downsample branch (the first block of layer1):
@@ -504,5 +524,5 @@ extern "C" int ssg_bottleneck_ds_nhwc_x(const void* x, const void* w1, const flo
   p.x = (const float*)x; p.out = (float*)out;
   p.w1 = (const float*)w1; p.b1 = b1; p.cs1 = cs1; p.w2 = (const float*)w2; p.b2 = b2; p.cs2 = cs2; p.w3 = (const float*)w3cat; p.b3 = b3; p.cs3 = cs3;
   p.B = B; p.H = H; p.overflow = overflow;
-  return launch_bottleneck<64>(p, stream);
+  return launch_bottleneck<256, 64, 32, 4, 64, 4>(p, stream);
 }

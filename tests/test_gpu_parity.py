@@ -788,8 +788,8 @@ def test_split_half_on_checkpoint_like_weights(dev):
 def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkeypatch):
     """ssg_stem_pool_nchw_x (image -> conv1 + bn + relu -> maxpool in one launch) and ssg_bottleneck[_ds]_nhwc_x (a whole layer1
     block in one launch) against the launch-per-layer path they replace: same k-steps, product order and epilogues, so the
-    layer4 map must be bit-identical.  H = 104: ragged last strip of the stem, layer1 height 26 has no fused block kernel
-    (falls back per block); H = 96: short images through both fused kernels."""
+    layer4 map must be bit-identical.  H = 104: ragged last strip of the stem, layer1 / layer2 heights 26 / 13 have no fused block
+    kernel (fall back per block); H = 96: short images, layer2 height 12 falls back, layer1 height 24 is fused."""
     import ssg_amd
     from ssg_amd import _lib
     m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=5).cuda().eval()
@@ -797,7 +797,8 @@ def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkey
     L = _lib.lib()
     assert L.ssg_stem_pool_supported(H, 128) == 1 and L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64) == (1 if (H // 4) % 4 == 0 else 0)
     assert L.ssg_bottleneck_supported(H // 4, 32, 64, 256, 64) == L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64)
-    assert L.ssg_bottleneck_supported(32, 16, 512, 512, 128) == 0         # layer2 shapes: separate launches
+    assert L.ssg_bottleneck_supported(32, 16, 512, 512, 128) == 1 and L.ssg_bottleneck_supported(28, 16, 512, 512, 128) == 0   # layer2 identity blocks: 8-row tiles
+    assert L.ssg_bottleneck_supported(16, 8, 1024, 1024, 256) == 0        # layer3 / layer4: separate launches
     maps = {}
     for stem, bneck in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
         monkeypatch.setenv("SSG_FUSED_STEM", stem); monkeypatch.setenv("SSG_FUSED_BOTTLENECK", bneck)
@@ -814,11 +815,11 @@ def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkey
     big = 3.0e4 * imgs
     m._fmap(big); assert m._overflowed()
     with pytest.raises(ValueError, match="unsupported block"):       # shapes without a fused kernel are refused, not mis-run
-        x = torch.zeros(1, 16, 16, 128, device="cuda")
-        blk = m._prepare()["blocks"][4]
+        x = torch.zeros(1, 16, 8, 1024, device="cuda")
+        blk = m._prepare()["blocks"][8]
         _lib.check(L.ssg_bottleneck_nhwc_x(_lib.ptr(x), _lib.ptr(blk["c1"].w), _lib.ptr(blk["c1"].bias), _lib.ptr(blk["c1"].cscale), _lib.ptr(blk["c2"].w),
                                            _lib.ptr(blk["c2"].bias), _lib.ptr(blk["c2"].cscale), _lib.ptr(blk["c3"].w), _lib.ptr(blk["c3"].bias),
-                                           _lib.ptr(blk["c3"].cscale), _lib.ptr(torch.empty_like(x)), 1, 16, 16, 512, 128, None, _lib.stream()), "bottleneck")
+                                           _lib.ptr(blk["c3"].cscale), _lib.ptr(torch.empty_like(x)), 1, 16, 8, 1024, 256, None, _lib.stream()), "bottleneck")
 
 
 def test_split_half_overflow_falls_back_to_f32(dev):

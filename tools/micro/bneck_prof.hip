@@ -15,7 +15,13 @@ static void fill_halves(std::vector<uint16_t>& v, unsigned seed, int emin, int e
 
 int main(int argc, char** argv) {
   using namespace ssg::bneck;
+#ifdef BN_LAYER2
+  constexpr int KC = 512, KMID = 128, KIW = 16, KTH = 8, KNW = 8;
+  const int B = argc > 1 ? atoi(argv[1]) : 512, H = 32, W = 16, C = 512, MID = 128;
+#else
+  constexpr int KC = 256, KMID = 64, KIW = 32, KTH = 4, KNW = 4;
   const int B = argc > 1 ? atoi(argv[1]) : 512, H = 64, W = 32, C = 256, MID = 64;
+#endif
   const size_t nx = (size_t)B * H * W * C;
   std::vector<uint16_t> hx(nx * 2), hw1((size_t)MID * C * 2), hw2((size_t)MID * 9 * MID * 2), hw3((size_t)C * MID * 2);
   fill_halves(hx, 1, 8, 6); fill_halves(hw1, 2, 6, 6); fill_halves(hw2, 3, 6, 6); fill_halves(hw3, 4, 6, 6);
@@ -23,7 +29,7 @@ int main(int argc, char** argv) {
   void *x, *out, *w1, *w2, *w3; float *cs, *bi; unsigned long long* prof;
   hipMalloc(&x, nx * 4); hipMalloc(&out, nx * 4); hipMalloc(&w1, hw1.size() * 2); hipMalloc(&w2, hw2.size() * 2); hipMalloc(&w3, hw3.size() * 2);
   hipMalloc(&cs, C * 4); hipMalloc(&bi, C * 4);
-  const int ntiles = B * (H / 4);
+  const int ntiles = B * (H / KTH);
   hipMalloc(&prof, (size_t)ntiles * 8 * 8);
   hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice); hipMemcpy(w1, hw1.data(), hw1.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(w2, hw2.data(), hw2.size() * 2, hipMemcpyHostToDevice); hipMemcpy(w3, hw3.data(), hw3.size() * 2, hipMemcpyHostToDevice);
@@ -31,12 +37,12 @@ int main(int argc, char** argv) {
   Params p;
   p.x = (const float*)x; p.out = (float*)out; p.w1 = (const float*)w1; p.b1 = bi; p.cs1 = cs; p.w2 = (const float*)w2; p.b2 = bi; p.cs2 = cs;
   p.w3 = (const float*)w3; p.b3 = bi; p.cs3 = cs; p.B = B; p.H = H; p.overflow = nullptr; p.prof = prof;
-  using K = Cfg<256, 64, 32, 4>;
-  hipFuncSetAttribute((const void*)bottleneck_kernel<256, 64, 32, 4, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
+  using K = Cfg<KC, KMID, KIW, KTH, KC, KNW>;
+  hipFuncSetAttribute((const void*)bottleneck_kernel<KC, KMID, KIW, KTH, KC, KNW>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int rep = 0; rep < 4; rep++) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((bottleneck_kernel<256, 64, 32, 4, 256>), dim3(ntiles), dim3(256), K::LDS, 0, p);
+    hipLaunchKernelGGL((bottleneck_kernel<KC, KMID, KIW, KTH, KC, KNW>), dim3(ntiles), dim3(KNW * 64), K::LDS, 0, p);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("B=%d tiles=%d LDS=%d  %.3f ms  (%.2f TB/s x+out)\n", B, ntiles, K::LDS, ms, 2.0 * nx * 4 / ms / 1e9);
