@@ -43,3 +43,7 @@ if __name__ == "__main__":
     elif cfg == "c3b": run(B, 32, 16, 128, 128, 3, 1, 1, False, 40)
     elif cfg == "c3a": run(B, 64, 32, 64, 64, 3, 1, 1, False, 40)
     elif cfg == "l4": run(B, 8, 4, 512, 512, 3, 1, 1, False, 40)
+    elif cfg == "l4a": run(B, 8, 4, 2048, 512, 1, 1, 0, False, 40)
+    elif cfg == "l4c": run(B, 8, 4, 512, 2048, 1, 1, 0, True, 40)
+    elif cfg == "l3a": run(B, 16, 8, 1024, 256, 1, 1, 0, False, 40)
+    elif cfg == "l3c": run(B, 16, 8, 256, 1024, 1, 1, 0, True, 40)
