@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--N", type=int, default=16000)
     ap.add_argument("--Ns", type=int, default=12936)
-    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=1000)     # images per embedding call (1000 x 64 x 32 x 256 x 4 B stays under the 2 GiB buffer range)
     ap.add_argument("--lambda_value", type=float, default=0.3)
     ap.add_argument("--rho", type=float, default=1.6e-3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
