@@ -59,7 +59,8 @@ struct Cfg {
   static constexpr int NTHR = NW * 64, RPP = NTHR / 4;  // 64-byte k-tile rows staged per pass of the workgroup
   static constexpr int XROWS = (NPIX1 + RPP - 1) / RPP * RPP;      // x rows of a phase-1 stage, padded to whole passes (the padding loads return zeros)
   static constexpr int P1 = 80;                        // LDS pitch of a 64-byte k-tile row (pitch/16 odd: conflict-free b128)
-  static constexpr int P2 = 144;                       // ... of a 128-byte k-tile row
+  static constexpr int KT2 = NW == 8 ? 2 : 1;          // 32-channel (chunk, tap) k-tiles of conv2 per LDS stage: the 8-wave workgroup (alone on its CU) halves its barriers
+  static constexpr int P2 = KT2 * 128 + 16;            // ... of a phase-2 stage row (KT2 x 128 bytes of a W2 row)
   static constexpr int PY = MID * 4 + 16;              // ... of a y1 / y2 pixel row (all MID channels, h8l8)
   static constexpr int BUF1 = (XROWS + MID) * P1;      // phase-1 stage: x rows, then W1 rows
   static constexpr int ZERO_OFF = NPIX1 * PY;          // one all-zero pixel row (conv2's left / right padding)
@@ -67,8 +68,9 @@ struct Cfg {
   static constexpr int W3_OFF = (NPIX * PY + 255) / 256 * 256, BUF3 = C * P1;
   static constexpr int LDS = cmax(cmax(2 * BUF1, W2_OFF + 2 * BUF2), W3_OFF + 2 * BUF3);
   static constexpr int DS = CIN != C;                  // downsample variant: conv3's reduction is [y2 | x]
-  static constexpr int NK1 = CIN / 16, NK2 = (MID / 32) * 9, NK3 = (MID + (DS ? CIN : 0)) / 16;
-  static constexpr int PD1 = NK1 < 8 ? NK1 : 8, PD2 = 6;               // (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)               // k-tiles of global loads in flight ahead of the multiply
+  static constexpr int NK1 = CIN / 16, NK2 = (MID / 32) * 9 / KT2, NK3 = (MID + (DS ? CIN : 0)) / 16;
+  static constexpr int PD1 = NK1 < 8 ? NK1 : 8, PD2 = KT2 == 1 ? 6 : 3;               // (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)               // k-tiles of global loads in flight ahead of the multiply
+  static_assert(((MID / 32) * 9) % KT2 == 0 && NK2 % PD2 == 0, "phase-2 stages and ring");
   static_assert((NW == 4 || NW == 8) && NPIX == 128 && NPIX1 % 32 == 0 && MID % RPP == 0 && C % RPP == 0 && MID % (NW * 8) == 0, "128 output pixels, whole staging passes");
   static_assert(2 * BUF1 <= ZERO_OFF, "the zero row is written while phase 1 runs");
   static_assert(LDS <= (NW == 4 ? 80 : 160) * 1024, "4 waves: two workgroups per CU; 8 waves: one");
@@ -209,17 +211,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
 #undef SSG_BN_MMA1
 
   // ---- conv2 weights: first k-tiles on their way while y1 is written
-  constexpr int RP8 = K::NTHR / 8, BU = MID / RP8;          // 16-byte pieces per thread and W2 k-tile (MID rows x 128 B)
-  const int ck8 = tid & 7, r8 = tid >> 3;
+  constexpr int CPR2 = 8 * K::KT2, RP8 = K::NTHR / CPR2, BU = MID / RP8;   // 16-byte pieces per thread and W2 stage (MID rows x KT2 x 128 B)
+  const int ck8 = tid % CPR2, r8 = tid / CPR2;
   const float* w2p = p.w2 + (int64_t)r8 * (9 * MID) + ck8 * 4;
   v4f sb2[K::PD2][BU];
 #define SSG_BN_LOAD2(T_, S_)                                                                                         \
-  { _Pragma("unroll") for (int u = 0; u < BU; u++) sb2[S_][u] = *reinterpret_cast<const v4f*>(w2p + (int64_t)(RP8 * u) * (9 * MID) + (T_) * 32); }
+  { _Pragma("unroll") for (int u = 0; u < BU; u++) sb2[S_][u] = *reinterpret_cast<const v4f*>(w2p + (int64_t)(RP8 * u) * (9 * MID) + (T_) * (32 * K::KT2)); }
 #define SSG_BN_STORE2(BUF_, S_)                                                                                      \
   { unsigned char* sb_ = smem + K::W2_OFF + (BUF_) * K::BUF2;                                                        \
     _Pragma("unroll") for (int u = 0; u < BU; u++) *reinterpret_cast<v4f*>(sb_ + (r8 + RP8 * u) * K::P2 + ck8 * 16) = sb2[S_][u]; }
-  static_assert(K::PD2 == 6 && K::NK2 % 6 == 0, "phase-2 ring of six register sets");
-  SSG_BN_LOAD2(0, 0) SSG_BN_LOAD2(1, 1) SSG_BN_LOAD2(2, 2) SSG_BN_LOAD2(3, 3) SSG_BN_LOAD2(4, 4) SSG_BN_LOAD2(5, 5)
+#define SSG_BN_LOAD2_IF(S_) if constexpr ((S_) < K::PD2) SSG_BN_LOAD2(S_, S_)
+  SSG_BN_LOAD2_IF(0) SSG_BN_LOAD2_IF(1) SSG_BN_LOAD2_IF(2) SSG_BN_LOAD2_IF(3) SSG_BN_LOAD2_IF(4) SSG_BN_LOAD2_IF(5)
+#undef SSG_BN_LOAD2_IF
 
   // ---- y1 -> LDS (h8l8 pixel rows).  Rows outside the image are conv2's zero padding, not relu(bias).
   unsigned ovf = 0u;
@@ -267,14 +270,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
     for (int q = 0; q < 4; q++) {
       cs2r[j][q] = *reinterpret_cast<const float4*>(p.cs2 + (cb2 + j) * 32 + 8 * q + 4 * h); b2r[j][q] = *reinterpret_cast<const float4*>(p.b2 + (cb2 + j) * 32 + 8 * q + 4 * h);
     }
-#define SSG_BN_STEP2(KT_, S_)                                                                                        \
+#define SSG_BN_STEP2(KT_, S_, B_)                                                                                     \
   {                                                                                                                  \
     if ((KT_) + K::PD2 < K::NK2) SSG_BN_LOAD2((KT_) + K::PD2, S_)                                                     \
-    {                                                                                                                \
-      const int chunk = (KT_) / 9, tap = (KT_) - chunk * 9, r = tap / 3, s = tap - r * 3;                            \
+    _Pragma("unroll") for (int sub = 0; sub < K::KT2; sub++) {                                                       \
+      const int kt_ = (KT_) * K::KT2 + sub;                                                                          \
+      const int chunk = kt_ / 9, tap = kt_ - chunk * 9, r = tap / 3, s = tap - r * 3;                                \
       const int xin = tx2 + s - 1;                                                                                   \
       const int abase = (xin >= 0 && xin < IW) ? ((ty2 + r) * IW + xin) * K::PY : K::ZERO_OFF;                       \
-      const unsigned char* wb = smem + K::W2_OFF + ((S_) & 1) * K::BUF2 + (cb2 * 32 + l32) * K::P2 + h * 32;         \
+      const unsigned char* wb = smem + K::W2_OFF + (B_) * K::BUF2 + (cb2 * 32 + l32) * K::P2 + sub * 128 + h * 32;     \
       v8h xh_[2], xl_[2], wh_[2][NT2], wl_[2][NT2];                                                                  \
       _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {                                                             \
         const unsigned char* q_ = smem + abase + (chunk * 4 + ks * 2 + h) * 32;                                      \
@@ -289,12 +293,15 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
         _Pragma("unroll") for (int j = 0; j < NT2; j++) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[ks][j], xh_[ks], acc2[j], 0, 0, 0); \
       }                                                                                                              \
     }                                                                                                                \
-    if ((KT_) + 1 < K::NK2) SSG_BN_STORE2(((S_) + 1) & 1, ((S_) + 1) % K::PD2)                                        \
+    if ((KT_) + 1 < K::NK2) SSG_BN_STORE2((B_) ^ 1, ((S_) + 1) % K::PD2)                                              \
     __syncthreads();                                                                                                 \
   }
+  // six steps per trip: the register set of step i is i % PD2 (PD2 = 6 or 3), its LDS buffer i & 1
+  static_assert(K::NK2 % 6 == 0 && 6 % K::PD2 == 0, "phase-2 ring");
 #pragma unroll
   for (int kt0 = 0; kt0 < K::NK2; kt0 += 6) {
-    SSG_BN_STEP2(kt0, 0) SSG_BN_STEP2(kt0 + 1, 1) SSG_BN_STEP2(kt0 + 2, 2) SSG_BN_STEP2(kt0 + 3, 3) SSG_BN_STEP2(kt0 + 4, 4) SSG_BN_STEP2(kt0 + 5, 5)
+    SSG_BN_STEP2(kt0, 0 % K::PD2, 0) SSG_BN_STEP2(kt0 + 1, 1 % K::PD2, 1) SSG_BN_STEP2(kt0 + 2, 2 % K::PD2, 0)
+    SSG_BN_STEP2(kt0 + 3, 3 % K::PD2, 1) SSG_BN_STEP2(kt0 + 4, 4 % K::PD2, 0) SSG_BN_STEP2(kt0 + 5, 5 % K::PD2, 1)
   }
 #undef SSG_BN_STEP2
   SSG_BN_STAMP(3)
