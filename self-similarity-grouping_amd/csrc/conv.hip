@@ -538,12 +538,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
 // logical chunk pc ^ g(row) into physical slot pc) and again when the fragments are read.
 #define SSG_LDSP(ptr_) ((__attribute__((address_space(3))) void*)(ptr_))
 
-template <int BN, bool ONEPROD = false>
-__global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
-  constexpr int BM = 128, WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
-  constexpr int WCOLS = BN / WN, NW = 2 * WCOLS;                     // 8 waves (2 x 4) for BN = 256, 4 waves (2 x 2) for BN = 128
-  constexpr int ABLK = BM / 16 / NW;                                 // 16-row A blocks per wave and stage: 1 or 2 (W: always 2)
-  constexpr int STAGE_BYTES = (BM + BN) * 64;                       // [A: 128 rows x 64 B][W: BN rows x 64 B]
+// BM x BN = 128 x 256 (8 waves, two workgroups per CU), 128 x 128 (4 waves) or 256 x 256 (16 waves, ONE workgroup per CU with the same
+// 16 waves: a third fewer global -> LDS bytes per MFMA than 128 x 256, which is what bounds these kernels).
+template <int BN, bool ONEPROD = false, int BM = 128>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 256 ? 4 : 3)) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
+  constexpr int WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
+  constexpr int WCOLS = BN / WN, NW = (BM / WM) * WCOLS;             // 8 waves (2 x 4) for 128 x 256, 4 waves (2 x 2) for 128 x 128, 16 (4 x 4) for 256 x 256
+  constexpr int ABLK = BM / 16 / NW, WBLK = BN / 16 / NW;            // 16-row A / W blocks per wave and stage: 1 or 2
+  constexpr int STAGE_BYTES = (BM + BN) * 64;                       // [A: BM rows x 64 B][W: BN rows x 64 B]
   __shared__ __attribute__((aligned(1024))) unsigned char st0[STAGE_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char st1[STAGE_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char st2[STAGE_BYTES];
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
   const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in), 0, p.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? p.in2_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
-  const unsigned wo0 = (unsigned)(((tn * BN + wave * 32 + drow) * p.Kpad + lc4) * 4), wo1 = wo0 + (unsigned)(16 * p.Kpad * 4);
+  const unsigned wo0 = (unsigned)(((tn * BN + wave * (16 * WBLK) + drow) * p.Kpad + lc4) * 4), wo1 = wo0 + (unsigned)(16 * p.Kpad * 4);
   const int ntap = p.KH * p.KW;
 #define SSG_DMA_A(J, ST, KT)                                                                                         \
   {                                                                                                                  \
@@ -596,8 +598,8 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
     const int r_ = tap_ / p.KW, s__ = tap_ - r_ * p.KW, cch_ = chunk_ * 32 + half_ + lc4;                             \
     SSG_DMA_A(0, ST, KT) if (ABLK == 2) SSG_DMA_A(1, ST, KT)                                                          \
     const unsigned kb_ = (unsigned)((KT) * CBK * 4);                                                                  \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048), 16, wo0 + kb_, 0, 0, 0);   \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * (1024 * WBLK)), 16, wo0 + kb_, 0, 0, 0);   \
+    if (WBLK == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, 0); \
   }
 
   // ---- fragment addressing: lane (row l32 of a 32-row MFMA tile, k half h); swizzle g = (row>>2)&3 depends on l32 only
@@ -634,7 +636,9 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
   // instructions per wave) and then publishes it.  The compiler's own tracking of the DMA -> LDS-array dependencies stays in
   // force for the fragment reads (separate __shared__ arrays per stage).
 #define SSG_PUBLISH()                                                                                              \
-  { if (ABLK == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); }
+  { if (ABLK + WBLK == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                           \
+    else if (ABLK + WBLK == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");                      \
+    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); }
   const int nk = p.Kpad / CBK;
   SSG_DMA(0, st0)
   { const int k1 = min(1, nk - 1); SSG_DMA(k1, st1) }
@@ -692,7 +696,9 @@ __global__ __launch_bounds__(BN == 256 ? 512 : 256, BN == 256 ? 4 : 3) void conv
   }
   // ---- epilogue: per (i, j) a 32-pixel x 32-channel patch through LDS (waves 0-3 in st0, 4-7 in st1), then row segments
   constexpr int EP = 36, CPR = 8, RPI = 8, ITS = 4;
-  float* patch = reinterpret_cast<float*>(wave < 4 ? st0 : st1) + (wave & 3) * (32 * EP);
+  constexpr int PPS = STAGE_BYTES / (32 * EP * 4) < 6 ? STAGE_BYTES / (32 * EP * 4) : 6;   // patches per stage array (4608 B each): 3, 5 or 6
+  static_assert(PPS * 32 * EP * 4 <= STAGE_BYTES && 3 * PPS >= NW, "epilogue patches fit in the stage arrays");
+  float* patch = reinterpret_cast<float*>(wave < PPS ? st0 : (wave < 2 * PPS ? st1 : st2)) + (wave % PPS) * (32 * EP);
   const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
   const float* __restrict__ resp = p.res;
   float* __restrict__ outp = p.out;
@@ -956,6 +962,15 @@ static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
   static int dma = -1;
   if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }
   if ((dma & 1) && (p.epi == 0 || p.epi == 3) && (int64_t)p.Cout * p.Kpad * 4 < 0x7fffffffLL) {   // (weights go through a 2 GiB buffer resource)
+    // 256 x 256 tiles (16 waves, one workgroup per CU): a third fewer global -> LDS bytes per MFMA; taken when they fill the chip
+    // (SSG_CONV_TALL_MINTILES = least number of such tiles, 0 = never)
+    static int tall = -1;
+    if (tall < 0) { const char* e = getenv("SSG_CONV_TALL_MINTILES"); tall = e ? atoi(e) : 200; }
+    const int tiles_tall = ((p.M + 255) / 256) * (p.Cout / 256);
+    if (tall > 0 && p.products == 3 && p.epi == 0 && !p.res && !p.in2 && tiles_tall >= tall) {   // measured: -2.5 % (3x3) / -6 % (1x1) on layer3 shapes; with a residual epilogue +3 %
+      hipLaunchKernelGGL((conv_dma_kernel<256, false, 256>), dim3(tiles_tall), dim3(1024), 0, stream, p);
+      return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<256x256>");
+    }
     const int tiles = ((p.M + 127) / 128) * (p.Cout / 256);
     if (p.products == 1) hipLaunchKernelGGL((conv_dma_kernel<256, true>), dim3(tiles), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL(conv_dma_kernel<256>, dim3(tiles), dim3(512), 0, stream, p);
