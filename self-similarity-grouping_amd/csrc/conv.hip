@@ -559,7 +559,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   const int drow = lane >> 2, pc = lane & 3;                        // row inside a 16-row block, physical 16-byte slot
   const int lc4 = (pc ^ ((drow >> 2) & 3)) * 4;                     // logical chunk (in fp32-sized units) this lane fetches
   const int nkA = p.in2 ? p.nk1 * 2 : 0x7fffffff;                    // p.nk1 counts 32-wide tiles on the dual path
-  int ab0, ah0, aw0, ab1 = -1, ah1 = 0, aw1 = 0;
+  int ab0, ah0, aw0, ab1 = -1, ah1 = 0, aw1 = 0, abase0 = 0, abase1 = 0;     // abase: byte offset of tap (0, 0), channel lc4 of this lane's pixel (may be negative)
   unsigned a2b0 = 0x80000000u, a2b1 = 0x80000000u;
 #define SSG_ROW(J)                                                                                                   \
   {                                                                                                                  \
@@ -568,6 +568,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
       const int b = m / (p.OH * p.OW), rem = m - b * (p.OH * p.OW);                                                  \
       const int oh = rem / p.OW, ow = rem - oh * p.OW;                                                               \
       ab##J = b; ah##J = oh * p.stride - p.pad; aw##J = ow * p.stride - p.pad;                                       \
+      abase##J = (((b * p.H + ah##J) * p.W + aw##J) * p.Cin + lc4) * 4;                                               \
       if (p.in2) a2b##J = (unsigned)((((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cin2 + lc4) * 4);      \
     } else { ab##J = -1; ah##J = 0; aw##J = 0; }                                                                     \
   }
@@ -578,28 +579,33 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   const __amdgpu_buffer_rsrc_t in2_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in2 ? p.in2 : p.in), 0, p.in2 ? p.in2_bytes : 0u, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (unsigned)((int64_t)p.Cout * p.Kpad * 4), 0x00020000);
   const unsigned wo0 = (unsigned)(((tn * BN + wave * (16 * WBLK) + drow) * p.Kpad + lc4) * 4), wo1 = wo0 + (unsigned)(16 * p.Kpad * 4);
-  const int ntap = p.KH * p.KW;
-#define SSG_DMA_A(J, ST, KT)                                                                                         \
+  // DMA cursor: the next k-tile to fetch is dn = ((chunk dch) * KH*KW + tap (dr, ds)) * 2 + half; it only ever moves forward by one
+  // (clamped at the last tile), so the tap decode is a few scalar increments instead of two integer divisions per tile and wave,
+  // and a lane's address is its tap-(0,0) offset + one uniform delta (out-of-range taps: the offset is replaced, not clamped).
+  const int nk = p.Kpad / CBK;
+  int dn = 0, dr = 0, ds = 0, dch = 0;
+#define SSG_DMA_A(J, ST)                                                                                             \
   {                                                                                                                  \
-    if ((KT) < nkA) {                                                                                                \
-      const int ih = ah##J + r_, iw = aw##J + s__;                                                                    \
-      const bool ok = ab##J >= 0 && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                                       \
-      const int ihc = min(max(ih, 0), p.H - 1), iwc = min(max(iw, 0), p.W - 1), bc = max(ab##J, 0);                   \
-      const unsigned aoff = (unsigned)((((bc * p.H + ihc) * p.W + iwc) * p.Cin + cch_) * 4) + (ok ? 0u : 0x80000000u); \
+    if (dn < nkA) {                                                                                                  \
+      const bool ok = ab##J >= 0 && (unsigned)(ah##J + dr) < (unsigned)p.H && (unsigned)(aw##J + ds) < (unsigned)p.W;  \
+      const unsigned aoff = ok ? (unsigned)(abase##J + ddelta_) : 0x80000000u;                                        \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, 0);   \
     } else {                                                                                                          \
-      const unsigned aoff = a2b##J + (unsigned)(((KT) - nkA) * CBK * 4);                                               \
+      const unsigned aoff = a2b##J + (unsigned)((dn - nkA) * CBK * 4);                                                 \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(in2_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, 0);  \
     }                                                                                                                 \
   }
-#define SSG_DMA(KT, ST)                                                                                              \
+#define SSG_DMA_NEXT(ST)                                                                                             \
   {                                                                                                                  \
-    const int kt32 = (KT) >> 1, half_ = ((KT) & 1) * 16, chunk_ = kt32 / ntap, tap_ = kt32 - chunk_ * ntap;          \
-    const int r_ = tap_ / p.KW, s__ = tap_ - r_ * p.KW, cch_ = chunk_ * 32 + half_ + lc4;                             \
-    SSG_DMA_A(0, ST, KT) if (ABLK == 2) SSG_DMA_A(1, ST, KT)                                                          \
-    const unsigned kb_ = (unsigned)((KT) * CBK * 4);                                                                  \
+    const int ddelta_ = ((dr * p.W + ds) * p.Cin + dch * 32 + (dn & 1) * 16) * 4;                                     \
+    SSG_DMA_A(0, ST) if (ABLK == 2) SSG_DMA_A(1, ST)                                                                  \
+    const unsigned kb_ = (unsigned)(dn * CBK * 4);                                                                    \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * (1024 * WBLK)), 16, wo0 + kb_, 0, 0, 0);   \
     if (WBLK == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, 0); \
+    if (dn < nk - 1) {                       /* (the tail re-fetches the last tile: harmless, keeps the vmcnt accounting uniform) */ \
+      dn++;                                                                                                          \
+      if (!(dn & 1)) { ds++; if (ds == p.KW) { ds = 0; dr++; if (dr == p.KH) { dr = 0; dch++; } } }                   \
+    }                                                                                                                \
   }
 
   // ---- fragment addressing: lane (row l32 of a 32-row MFMA tile, k half h); swizzle g = (row>>2)&3 depends on l32 only
@@ -639,21 +645,20 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   { if (ABLK + WBLK == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                           \
     else if (ABLK + WBLK == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");                      \
     else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); }
-  const int nk = p.Kpad / CBK;
-  SSG_DMA(0, st0)
-  { const int k1 = min(1, nk - 1); SSG_DMA(k1, st1) }
+  SSG_DMA_NEXT(st0)
+  SSG_DMA_NEXT(st1)
   const int nfull = nk / 3 * 3;
   for (int kt = 0; kt < nfull; kt += 3) {   // tile t lives in stage array t % 3; no exits inside (they doubled the accumulators)
     SSG_PUBLISH();                        // tile kt landed in st0 for every wave; everybody is done reading st2 (tile kt-1)
-    { const int kn = min(kt + 2, nk - 1); SSG_DMA(kn, st2) }
+    SSG_DMA_NEXT(st2)
     __builtin_amdgcn_sched_barrier(0);    // keep the DMA issue ahead of the multiply
     SSG_MMA(st0)
     SSG_PUBLISH();
-    { const int kn = min(kt + 3, nk - 1); SSG_DMA(kn, st0) }
+    SSG_DMA_NEXT(st0)
     __builtin_amdgcn_sched_barrier(0);
     SSG_MMA(st1)
     SSG_PUBLISH();
-    { const int kn = min(kt + 4, nk - 1); SSG_DMA(kn, st1) }
+    SSG_DMA_NEXT(st1)
     __builtin_amdgcn_sched_barrier(0);
     SSG_MMA(st2)
   }
@@ -661,7 +666,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   if (nk - nfull == 2) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
   __syncthreads();                        // drains the (clamped, redundant) tail DMAs before the stages become epilogue patches
 #undef SSG_PUBLISH
-#undef SSG_DMA
+#undef SSG_DMA_NEXT
 #undef SSG_DMA_A
 #undef SSG_MMA
 #pragma unroll
