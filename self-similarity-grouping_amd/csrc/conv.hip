@@ -540,7 +540,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
 
 // BM x BN = 128 x 256 (8 waves, two workgroups per CU), 128 x 128 (4 waves) or 256 x 256 (16 waves, ONE workgroup per CU with the same
 // 16 waves: a third fewer global -> LDS bytes per MFMA than 128 x 256, which is what bounds these kernels).
-template <int BN, bool ONEPROD = false, int BM = 128>
+// DUAL: a second 1x1 input is concatenated along K (fused downsample branch); a compile-time switch, because the main loop is bound
+// by instruction issue (every branch, scalar division and v_readfirstlane per k-tile shows).
+template <int BN, bool ONEPROD = false, int BM = 128, bool DUAL = false>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 256 ? 4 : 3)) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
   constexpr int WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
   constexpr int WCOLS = BN / WN, NW = (BM / WM) * WCOLS;             // 8 waves (2 x 4) for 128 x 256, 4 waves (2 x 2) for 128 x 128, 16 (4 x 4) for 256 x 256
@@ -552,13 +554,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   const int tiles_n = p.Cout / BN, tiles_m = (p.M + BM - 1) / BM;
   const int tile = conv_xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS-DMA destinations go to M0)
   const int wm = wave / WCOLS, wn = wave % WCOLS, l32 = lane & 31, h = lane >> 5;
 
   // ---- DMA addressing: this wave fills A rows [16*ABLK*w, +16*ABLK) and W rows [32w, 32w+32) of every stage
   const int drow = lane >> 2, pc = lane & 3;                        // row inside a 16-row block, physical 16-byte slot
   const int lc4 = (pc ^ ((drow >> 2) & 3)) * 4;                     // logical chunk (in fp32-sized units) this lane fetches
-  const int nkA = p.in2 ? p.nk1 * 2 : 0x7fffffff;                    // p.nk1 counts 32-wide tiles on the dual path
+  const int nkA = DUAL ? p.nk1 * 2 : 0x7fffffff;                     // p.nk1 counts 32-wide tiles on the dual path
   int ab0, ah0, aw0, ab1 = -1, ah1 = 0, aw1 = 0, abase0 = 0, abase1 = 0;     // abase: byte offset of tap (0, 0), channel lc4 of this lane's pixel (may be negative)
   unsigned a2b0 = 0x80000000u, a2b1 = 0x80000000u;
 #define SSG_ROW(J)                                                                                                   \
@@ -569,7 +571,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
       const int oh = rem / p.OW, ow = rem - oh * p.OW;                                                               \
       ab##J = b; ah##J = oh * p.stride - p.pad; aw##J = ow * p.stride - p.pad;                                       \
       abase##J = (((b * p.H + ah##J) * p.W + aw##J) * p.Cin + lc4) * 4;                                               \
-      if (p.in2) a2b##J = (unsigned)((((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cin2 + lc4) * 4);      \
+      if (DUAL) a2b##J = (unsigned)((((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cin2 + lc4) * 4);       \
     } else { ab##J = -1; ah##J = 0; aw##J = 0; }                                                                     \
   }
   SSG_ROW(0)
@@ -586,7 +588,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   int dn = 0, dr = 0, ds = 0, dch = 0;
 #define SSG_DMA_A(J, ST)                                                                                             \
   {                                                                                                                  \
-    if (dn < nkA) {                                                                                                  \
+    if (!DUAL || dn < nkA) {                                                                                          \
       const bool ok = ab##J >= 0 && (unsigned)(ah##J + dr) < (unsigned)p.H && (unsigned)(aw##J + ds) < (unsigned)p.W;  \
       const unsigned aoff = ok ? (unsigned)(abase##J + ddelta_) : 0x80000000u;                                        \
       __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, 0);   \
@@ -602,9 +604,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
     const unsigned kb_ = (unsigned)(dn * CBK * 4);                                                                    \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * (1024 * WBLK)), 16, wo0 + kb_, 0, 0, 0);   \
     if (WBLK == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, 0); \
-    if (dn < nk - 1) {                       /* (the tail re-fetches the last tile: harmless, keeps the vmcnt accounting uniform) */ \
-      dn++;                                                                                                          \
-      if (!(dn & 1)) { ds++; if (ds == p.KW) { ds = 0; dr++; if (dr == p.KH) { dr = 0; dch++; } } }                   \
+    {                                        /* branch-free advance; the tail re-fetches the last tile (harmless, keeps the vmcnt accounting uniform) */ \
+      const int adv_ = dn < nk - 1 ? 1 : 0;                                                                          \
+      dn += adv_;                                                                                                    \
+      ds += adv_ & ~dn & 1;                                                                                          \
+      const int w1_ = ds == p.KW ? 1 : 0; ds = w1_ ? 0 : ds; dr += w1_;                                               \
+      const int w2_ = dr == p.KH ? 1 : 0; dr = w2_ ? 0 : dr; dch += w2_;                                              \
     }                                                                                                                \
   }
 
@@ -936,7 +941,7 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
       if constexpr (BM == 128 && BN == 128) {   // long reductions on 128x128 tiles: LDS-DMA kernel (SSG_CONV_DMA bit 1)
         static int dma = -1;
         if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }   // bit 1 measured neutral (21.42 vs 21.46 k img/s): off by default
-        if ((dma & 2) && p.epi == 0) {
+        if ((dma & 2) && p.epi == 0 && !p.in2) {
           const int tiles = ((p.M + 127) / 128) * (p.Cout / 128);
           hipLaunchKernelGGL(conv_dma_kernel<128>, dim3(tiles), dim3(256), 0, stream, p);
           return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<128>");
@@ -973,11 +978,12 @@ static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
     if (tall < 0) { const char* e = getenv("SSG_CONV_TALL_MINTILES"); tall = e ? atoi(e) : 200; }
     const int tiles_tall = ((p.M + 255) / 256) * (p.Cout / 256);
     if (tall > 0 && p.products == 3 && p.epi == 0 && !p.res && !p.in2 && tiles_tall >= tall) {   // measured: -2.5 % (3x3) / -6 % (1x1) on layer3 shapes; with a residual epilogue +3 %
-      hipLaunchKernelGGL((conv_dma_kernel<256, false, 256>), dim3(tiles_tall), dim3(1024), 0, stream, p);
+      hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false>), dim3(tiles_tall), dim3(1024), 0, stream, p);
       return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<256x256>");
     }
     const int tiles = ((p.M + 127) / 128) * (p.Cout / 256);
     if (p.products == 1) hipLaunchKernelGGL((conv_dma_kernel<256, true>), dim3(tiles), dim3(512), 0, stream, p);
+    else if (p.in2) hipLaunchKernelGGL((conv_dma_kernel<256, false, 128, true>), dim3(tiles), dim3(512), 0, stream, p);
     else hipLaunchKernelGGL(conv_dma_kernel<256>, dim3(tiles), dim3(512), 0, stream, p);
     return ssg_check_hip(hipGetLastError(), "conv_dma_kernel");
   }
