@@ -1188,7 +1188,7 @@ static int source_rowmin_filtered_impl(const float* tgt, const float* src, int n
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
   if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
   const bool split = scale_t > 0.f && scale_s > 0.f;
-  if (split && one_product && (Ns_pad % 128) == 0) {
+  if (split && one_product && (Ns_pad % 128) == 0 && (d % sbound::BK) == 0) {
     // bound pass as a plain fp16 GEMM on half copies of the scaled operands (source_bound.hip): 2 bytes per element, 1 product
     uintptr_t a = (uintptr_t)(tilemin + (int64_t)nrows * ntiles); a = (a + 15) & ~(uintptr_t)15;
     _Float16* x16 = (_Float16*)a; _Float16* y16 = x16 + (int64_t)nrows * d;

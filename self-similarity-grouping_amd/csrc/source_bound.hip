@@ -20,7 +20,11 @@ namespace sbound {
 typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, PITCH = 80;        // bytes per LDS row: 64 of data + 16 of padding
+#ifndef SSG_SB_BK
+#define SSG_SB_BK 32
+#endif
+constexpr int BM = 128, BN = 128, BK = SSG_SB_BK, PITCH = BK * 2 + 16;   // bytes per LDS row: BK halves + 16 of padding (pitch / 16 odd)
+constexpr int CPR = BK * 2 / 16, NU = BM * CPR / 256;         // 16-byte chunks per row, chunks per thread and operand
 constexpr int TILE_BYTES = BM * PITCH;                          // one operand tile of one stage
 
 __global__ __launch_bounds__(256) void f32_to_f16_scaled_kernel(const float* __restrict__ in, _Float16* __restrict__ out, int64_t n4, float scale) {
@@ -32,8 +36,8 @@ __global__ __launch_bounds__(256) void f32_to_f16_scaled_kernel(const float* __r
   }
 }
 
-// X [M, K] (targets), Y [Npad, K] (sources) half, K % 32 == 0, Npad % 128 == 0.  tilemin [M, Npad/8].
-__global__ __launch_bounds__(256, 4) void source_bound_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Y, int M, int Npad, int K,
+// X [M, K] (targets), Y [Npad, K] (sources) half, K % BK == 0, Npad % 128 == 0.  tilemin [M, Npad/8].
+__global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void source_bound_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Y, int M, int Npad, int K,
                                                               const float* __restrict__ rowterm, const float* __restrict__ colterm, float acc_scale,
                                                               float* __restrict__ tilemin, int tmin_ld) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];
@@ -54,11 +58,11 @@ __global__ __launch_bounds__(256, 4) void source_bound_kernel(const _Float16* __
   }
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
-  // staging: each operand tile of a stage is 128 rows x 64 bytes = 512 chunks of 16 bytes: 2 per thread and operand
-  const uint4* gx[2]; const uint4* gy[2]; int lo[2];
+  // staging: each operand tile of a stage is 128 rows x BK halves = 128 * CPR chunks of 16 bytes: NU per thread and operand
+  const uint4* gx[NU]; const uint4* gy[NU]; int lo[NU];
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int c = tid + 256 * u, row = c >> 2, ch = c & 3;
+  for (int u = 0; u < NU; u++) {
+    const int c = tid + 256 * u, row = c / CPR, ch = c % CPR;
     gx[u] = reinterpret_cast<const uint4*>(X + (int64_t)min(tm * BM + row, M - 1) * K) + ch;
     gy[u] = reinterpret_cast<const uint4*>(Y + (int64_t)(tn * BN + row) * K) + ch;
     lo[u] = row * PITCH + ch * 16;
@@ -72,17 +76,20 @@ __global__ __launch_bounds__(256, 4) void source_bound_kernel(const _Float16* __
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
   const int nk = K / BK;
-  uint4 px0 = gx[0][0], px1 = gx[1][0], py0 = gy[0][0], py1 = gy[1][0];
-  *reinterpret_cast<uint4*>(lds + lo[0]) = px0; *reinterpret_cast<uint4*>(lds + lo[1]) = px1;
-  *reinterpret_cast<uint4*>(lds + TILE_BYTES + lo[0]) = py0; *reinterpret_cast<uint4*>(lds + TILE_BYTES + lo[1]) = py1;
+  uint4 px[NU], py[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) { px[u] = gx[u][0]; py[u] = gy[u][0]; }
+#pragma unroll
+  for (int u = 0; u < NU; u++) { *reinterpret_cast<uint4*>(lds + lo[u]) = px[u]; *reinterpret_cast<uint4*>(lds + TILE_BYTES + lo[u]) = py[u]; }
   __syncthreads();
   for (int ks = 0; ks < nk; ks++) {
-    const int nx = min(ks + 1, nk - 1) * (BK * 2 / 16);       // next stage's chunk offset (clamped: the last prefetch is repeated, unused)
-    px0 = gx[0][nx]; px1 = gx[1][nx]; py0 = gy[0][nx]; py1 = gy[1][nx];
+    const int nx = min(ks + 1, nk - 1) * CPR;                 // next stage's chunk offset (clamped: the last prefetch is repeated, unused)
+#pragma unroll
+    for (int u = 0; u < NU; u++) { px[u] = gx[u][nx]; py[u] = gy[u][nx]; }
     const unsigned char* xs = lds + (ks & 1) * (2 * TILE_BYTES);
     const unsigned char* ys = xs + TILE_BYTES;
 #pragma unroll
-    for (int s = 0; s < 2; s++) {             // two 16-wide k steps per stage
+    for (int s = 0; s < BK / 16; s++) {       // 16-wide k steps of a stage
       v8h xf[2], yf[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) xf[i] = *reinterpret_cast<const v8h*>(xs + (wm * 64 + i * 32 + l32) * PITCH + s * 32 + h * 16);
@@ -95,8 +102,8 @@ __global__ __launch_bounds__(256, 4) void source_bound_kernel(const _Float16* __
     }
     if (ks + 1 < nk) {
       unsigned char* nb = lds + ((ks + 1) & 1) * (2 * TILE_BYTES);
-      *reinterpret_cast<uint4*>(nb + lo[0]) = px0; *reinterpret_cast<uint4*>(nb + lo[1]) = px1;
-      *reinterpret_cast<uint4*>(nb + TILE_BYTES + lo[0]) = py0; *reinterpret_cast<uint4*>(nb + TILE_BYTES + lo[1]) = py1;
+#pragma unroll
+      for (int u = 0; u < NU; u++) { *reinterpret_cast<uint4*>(nb + lo[u]) = px[u]; *reinterpret_cast<uint4*>(nb + TILE_BYTES + lo[u]) = py[u]; }
     }
     __syncthreads();
   }
