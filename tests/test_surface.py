@@ -173,3 +173,25 @@ def test_triplet_pairwise_block_vs_torch():
         off = ~torch.eye(n, dtype=torch.bool); off[1, 3] = off[3, 1] = False
         assert (got[off] - ref[off]).abs().max() < 2e-5 * ref.max()
         assert float(got.min()) >= 1e-6 - 1e-12          # sqrt(1e-12): the clamp floor, never NaN
+
+
+# ------------------------------------------------------------------ fused embedding kernels: shape gating (host functions, CPU)
+def test_fused_kernel_shape_gates():
+    """ssg_stem_pool_supported / ssg_bottleneck_supported decide between the fused kernels and the launch-per-layer path; the
+    Python embedder relies on them (resnet._fmap / _bottleneck), so unsupported shapes must say 0 instead of being mis-run."""
+    from ssg_amd import _lib
+    L = _lib.lib()
+    assert L.ssg_stem_pool_supported(256, 128) == 1 and L.ssg_stem_pool_supported(384, 128) == 1
+    assert L.ssg_stem_pool_supported(256, 64) == 0 and L.ssg_stem_pool_supported(254, 128) == 0 and L.ssg_stem_pool_supported(4, 128) == 0
+    ok = {(64, 32, 256, 256, 64), (64, 32, 64, 256, 64), (24, 32, 256, 256, 64), (32, 16, 512, 512, 128), (96, 16, 512, 512, 128)}
+    for shape in ok:
+        assert L.ssg_bottleneck_supported(*shape) == 1, shape
+    bad = [(26, 32, 256, 256, 64), (64, 16, 256, 256, 64), (64, 32, 128, 256, 64), (28, 16, 512, 512, 128), (32, 16, 256, 512, 128),
+           (16, 8, 1024, 1024, 256), (8, 4, 2048, 2048, 512), (0, 32, 256, 256, 64), (64, 32, 256, 256, 128)]
+    for shape in bad:
+        assert L.ssg_bottleneck_supported(*shape) == 0, shape
+    # the entry points refuse what the gates refuse (before touching any pointer)
+    for fn, args in ((L.ssg_bottleneck_nhwc_x, (None,) * 11 + (1, 16, 8, 1024, 256, None, None)),
+                     (L.ssg_bottleneck_ds_nhwc_x, (None,) * 11 + (1, 64, 32, 256, 256, 64, None, None)),
+                     (L.ssg_stem_pool_nchw_x, (None, 0, None, None, None, None, 1, 256, 64, None, None))):
+        assert fn(*args) != 0 and b"unsupported" in L.ssg_last_error()
