@@ -1,4 +1,5 @@
-// bottleneck.hip -- one identity bottleneck block of the ResNet-50 backbone in ONE kernel (split-half path).
+// bottleneck.hip -- one bottleneck block of the ResNet-50 backbone in ONE kernel (split-half path): the three blocks of layer1
+// and the three identity blocks of layer2.
 //
 // reid/models/base.py:57-90 (torchvision Bottleneck without a downsample branch), eval mode, BatchNorm folded:
 //   out = relu( conv3_1x1( relu( conv2_3x3( relu( conv1_1x1(x) ) ) ) ) + x )
@@ -21,8 +22,12 @@
 // downsample 1x1 convolution rides in conv3's reduction (K = MID + CIN, weights concatenated, as ssg_conv1x1_dual_nhwc_x does)
 // and replaces the residual; its pixel operand (this wave's 32 pixels x CIN channels) is loaded straight into MFMA fragments.
 //
-// 4 waves, 2 workgroups per CU (<= 80 KB of LDS each).  All operand tiles are staged global -> registers -> LDS with the loads
-// several k-tiles ahead (register rings), one barrier per k-tile:
+// Layer1 (C = 256, MID = 64, 32-pixel rows, TH = 4): 4 waves, 2 workgroups per CU (<= 80 KB of LDS each) -- one's loads run under
+// the other's multiplies.  Layer2 (C = 512, MID = 128, 16-pixel rows, TH = 8): the 128-channel halo intermediate alone is 85 KB,
+// so ONE 8-wave workgroup per CU (150 KB): phase 2 = 4 pixel tiles x 2 channel groups, phase 3 = a wave pair per pixel tile, the
+// epilogue patches take over the dead W3 stages; its phases are serial on a CU (measured 0.75 -> 0.62 ms per block).
+// All operand tiles are staged global -> registers -> LDS with the loads several k-tiles ahead (register rings), one barrier per
+// stage:
 //   phase 1  y1[(TH+2)*IW, MID] = relu(x W1^T)   k-tiles of 16 channels: x rows (64 B each) + W1 rows; wave = 3 x 1 MFMA tiles
 //   phase 2  y2[TH*IW, MID]     = relu(conv3x3(y1))   k-tiles = (32-channel chunk, tap): W2 rows (128 B); wave = 32 pixels x MID
 //   phase 3  out[TH*IW, C]      = relu(y2 W3^T + x)   k-tiles of 16 channels: W3 rows; wave = its own 32 pixels x all C channels
@@ -69,7 +74,8 @@ struct Cfg {
   static constexpr int LDS = cmax(cmax(2 * BUF1, W2_OFF + 2 * BUF2), W3_OFF + 2 * BUF3);
   static constexpr int DS = CIN != C;                  // downsample variant: conv3's reduction is [y2 | x]
   static constexpr int NK1 = CIN / 16, NK2 = (MID / 32) * 9 / KT2, NK3 = (MID + (DS ? CIN : 0)) / 16;
-  static constexpr int PD1 = NK1 < 8 ? NK1 : 8, PD2 = KT2 == 1 ? 6 : 3;               // (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)               // k-tiles of global loads in flight ahead of the multiply
+  // stages of global loads in flight ahead of the multiply (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)
+  static constexpr int PD1 = NK1 < 8 ? NK1 : 8, PD2 = KT2 == 1 ? 6 : 3;
   static_assert(((MID / 32) * 9) % KT2 == 0 && NK2 % PD2 == 0, "phase-2 stages and ring");
   static_assert((NW == 4 || NW == 8) && NPIX == 128 && NPIX1 % 32 == 0 && MID % RPP == 0 && C % RPP == 0 && MID % (NW * 8) == 0, "128 output pixels, whole staging passes");
   static_assert(2 * BUF1 <= ZERO_OFF, "the zero row is written while phase 1 runs");
