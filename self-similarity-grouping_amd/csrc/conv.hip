@@ -977,7 +977,9 @@ static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("SSG_CONV_TALL_MINTILES"); tall = e ? atoi(e) : 200; }
     const int tiles_tall = ((p.M + 255) / 256) * (p.Cout / 256);
-    if (tall > 0 && p.products == 3 && p.epi == 0 && !p.res && !p.in2 && tiles_tall >= tall) {   // measured: -2.5 % (3x3) / -6 % (1x1) on layer3 shapes; with a residual epilogue +3 %
+    static int tall_res = -1;                // SSG_CONV_TALL_RES=1: also for convolutions with a residual epilogue (tuning knob)
+    if (tall_res < 0) { const char* e = getenv("SSG_CONV_TALL_RES"); tall_res = e ? atoi(e) : 0; }
+    if (tall > 0 && p.products == 3 && p.epi == 0 && (!p.res || tall_res) && !p.in2 && tiles_tall >= tall) {   // measured: -2.5 % (3x3) / -6 % (1x1) on layer3 shapes; with a residual epilogue +3 %
       hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false>), dim3(tiles_tall), dim3(1024), 0, stream, p);
       return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<256x256>");
     }
