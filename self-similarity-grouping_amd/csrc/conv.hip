@@ -977,6 +977,12 @@ static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
     static int tall = -1;
     if (tall < 0) { const char* e = getenv("SSG_CONV_TALL_MINTILES"); tall = e ? atoi(e) : 200; }
     const int tiles_tall = ((p.M + 255) / 256) * (p.Cout / 256);
+    static int tall_dual = -1;               // SSG_CONV_TALL_DUAL=1: also for the fused conv3 | downsample GEMMs (tuning knob)
+    if (tall_dual < 0) { const char* e = getenv("SSG_CONV_TALL_DUAL"); tall_dual = e ? atoi(e) : 0; }
+    if (tall > 0 && p.products == 3 && p.epi == 0 && p.in2 && tall_dual && tiles_tall >= tall) {
+      hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, true>), dim3(tiles_tall), dim3(1024), 0, stream, p);
+      return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<256x256, dual>");
+    }
     static int tall_res = -1;                // SSG_CONV_TALL_RES=1: also for convolutions with a residual epilogue (tuning knob)
     if (tall_res < 0) { const char* e = getenv("SSG_CONV_TALL_RES"); tall_res = e ? atoi(e) : 0; }
     if (tall > 0 && p.products == 3 && p.epi == 0 && (!p.res || tall_res) && !p.in2 && tiles_tall >= tall) {   // measured: -2.5 % (3x3) / -6 % (1x1) on layer3 shapes; with a residual epilogue +3 %
