@@ -137,24 +137,23 @@ def main():
     args = ap.parse_args()
 
     import ssg_amd
-    from ssg_amd import _lib, cluster, dist as sdist, rerank
+    from ssg_amd import _lib, cluster, dist as sdist, evaluators, rerank
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)                               # before the process group: RCCL binds its communicator to the current device
     rank, world, group = sdist.init_from_env()
     if world != args.gpus:
         raise SystemExit("launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d, --gpus %d)" % (args.gpus, world, args.gpus))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     timer = KernelTimer(_lib.lib())
     _lib._lib = timer
 
-    # ---- inputs resident in HBM before the timed region
+    # ---- inputs resident in HBM before the timed region.  Every rank holds the whole synthetic image set (11.4 GB; same seed), the
+    # product API (`extract_embeddings(..., group=)`) shards the batches over the ranks and all-gathers the embeddings
     model = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1, pretrained=False).cuda(local).eval()
     precision = model.precision
-    t_lo, t_hi = sdist.shard_bounds(args.N, rank, world)
-    s_lo, s_hi = sdist.shard_bounds(args.Ns, rank, world)
-    g = torch.Generator(device=dev).manual_seed(1 + rank)
-    tgt_imgs = torch.randn(t_hi - t_lo, 3, 256, 128, generator=g, device=dev)
-    src_imgs = torch.randn(s_hi - s_lo, 3, 256, 128, generator=g, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    tgt_imgs = torch.randn(args.N, 3, 256, 128, generator=g, device=dev)
+    src_imgs = torch.randn(args.Ns, 3, 256, 128, generator=g, device=dev)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import synth
     gens = {"hard": synth.hard_clustered, "separable": synth.clustered}
@@ -164,21 +163,30 @@ def main():
     row0, row1 = sdist.shard_bounds(args.N, rank, world)      # ragged row blocks (N need not divide by the number of GPUs)
     nrows = row1 - row0
 
-    def embed(imgs):
-        out = []
-        for bi, i in enumerate(range(0, imgs.shape[0], args.batch)):
-            timer.sample = (bi % 4 == 0)                 # per-launch HIP events on every 4th batch only
-            if timer.on and timer.sample:
-                timer.sampled_images += min(args.batch, imgs.shape[0] - i)
-            out.append(model.embed_with_flip(imgs[i:i + args.batch]))
-        timer.sample = True
-        return torch.cat(out, 0)
+    class TimedLoader(evaluators.TensorBatchLoader):
+        """the product's resident-tensor loader; per-launch HIP events are switched on for every 4th batch only"""
+
+        def shard(self, r, w):
+            s_ = super().shard(r, w)
+            return TimedLoader(s_.images, s_.batch_size, s_.fnames, s_.pids, s_.first, s_.count)
+
+        def __iter__(self):
+            for bi, batch in enumerate(super().__iter__()):
+                timer.sample = (bi % 4 == 0)
+                if timer.on and timer.sample:
+                    timer.sampled_images += batch[0].shape[0]
+                yield batch
+            timer.sample = True
+
+    tgt_loader, src_loader = TimedLoader(tgt_imgs, args.batch), TimedLoader(src_imgs, args.batch)
+    imgs_rank = tgt_loader.shard(rank, world).num_items() + src_loader.shard(rank, world).num_items()
 
     def step():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         ev[0].record()
-        f_src = sdist.gather_varlen(embed(src_imgs), group)      # C1: all-gather of the embeddings over xGMI
-        f_tgt = sdist.gather_varlen(embed(tgt_imgs), group)
+        # SURVEY 8e-1/2: image batches sharded by rank, C1 = all-gather of the embeddings over xGMI -- the product function
+        f_src, _, _ = evaluators.extract_embeddings(model, src_loader, group=group)
+        f_tgt, _, _ = evaluators.extract_embeddings(model, tgt_loader, group=group)
         ev[1].record()
         assert f_tgt.shape == (args.N, 2048) and f_src.shape == (args.Ns, 2048)
         h = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
@@ -267,7 +275,6 @@ def main():
     n_conv, ms_conv = (sum(c[0] for c in convs), sum(c[1] for c in convs)) if convs else (1, float("nan"))
     n_conv_per_fwd = round(n_conv * args.batch / max(2 * timer.sampled_images, 1)) if convs else 0
     launches_by_abi = {k: {"launches": tot[k][0], "ms": round(tot[k][1], 3)} for k in CONV_ABI if k in tot}
-    imgs_rank = (t_hi - t_lo) + (s_hi - s_lo)
     conv_tf = timer.sampled_images * FLOP_PER_IMAGE / (ms_conv * 1e-3) / 1e12     # launches and images of the sampled batches
     split = precision == "split"
     # split-half path: every fp32 multiply-add is three fp16-MFMA multiply-adds (xh*wh + xh*wl + xl*wh), so the

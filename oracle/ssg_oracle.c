@@ -211,13 +211,18 @@ static void aheapsort_half(const uint16_t* v, int64_t* tosort, int64_t n) {
 }
 static int msb64(uint64_t n) { int k = 0; while (n >>= 1) k++; return k; }
 #define SWAPI(a, b) do { int64_t t_ = (a); (a) = (b); (b) = t_; } while (0)
+/* small_thr: ranges with pr - pl > small_thr are partitioned.  numpy's source says SMALL_QUICKSORT = 16, the numpy 2.2.6 wheel
+ * in this image behaves like 15 (17 elements are still partitioned; probed, and pinned by tests/test_oracle_golden.py on the
+ * installed numpy): the tie order of reid/rerank.py:70 therefore depends on the numpy build, see DESIGN.md "Ties". */
+static int g_small_thr = 15;
+void ora_set_small_threshold(int t) { g_small_thr = t; }
 static void aquicksort_half(const uint16_t* v, int64_t* tosort, int64_t num) {
   int64_t *pl = tosort, *pr = tosort + num - 1, *stack[128], **sptr = stack, *pm, *pi, *pj, *pk, vi;
   int depth[128], *psdepth = depth, cdepth = msb64((uint64_t)num) * 2;
   uint16_t vp;
   for (;;) {
     if (cdepth < 0) { aheapsort_half(v, pl, pr - pl + 1); goto stack_pop; }
-    while ((pr - pl) > 15) {   /* numpy 2.2.6 behaviour: 17 elements are still partitioned (probed) */
+    while ((pr - pl) > g_small_thr) {   /* numpy 2.2.6 behaviour (15): 17 elements are still partitioned (probed) */
       pm = pl + ((pr - pl) >> 1);
       if (h_less(v[*pm], v[*pl])) SWAPI(*pm, *pl);
       if (h_less(v[*pr], v[*pm])) SWAPI(*pr, *pm);

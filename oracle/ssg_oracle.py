@@ -82,11 +82,19 @@ def pairwise_sum(a):
     return np.float32(lib().ora_pairwise_sum_f32(_p(a, _f32p), ctypes.c_int64(a.size)))
 
 
-def argsort_half(v):
-    """numpy default (introsort) argsort of a 1-D half array, restated."""
+def argsort_half(v, small=None):
+    """numpy default (introsort) argsort of a 1-D half array, restated.  small: partition threshold (ranges with pr - pl > small
+    are partitioned); None = 15, the behaviour of the numpy 2.2.6 build the goldens were generated with (numpy's source says
+    16).  The probe test in tests/test_oracle_golden.py tells which one the installed numpy follows."""
     v = _c(v, np.float16)
     out = np.empty(v.size, np.int64)
-    lib().ora_argsort_half(_p(v.view(np.uint16), _u16p), ctypes.c_int64(v.size), _p(out, _i64p))
+    if small is not None:
+        lib().ora_set_small_threshold(ctypes.c_int(int(small)))
+    try:
+        lib().ora_argsort_half(_p(v.view(np.uint16), _u16p), ctypes.c_int64(v.size), _p(out, _i64p))
+    finally:
+        if small is not None:
+            lib().ora_set_small_threshold(ctypes.c_int(15))
     return out
 
 

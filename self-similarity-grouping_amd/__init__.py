@@ -21,7 +21,8 @@ def __getattr__(name):   # lazy: torch import only when the compute surface is t
     if name in ("compute_dist", "generate_selflabel", "select_labeled", "generate_dataset"):
         from . import selftraining
         return getattr(selftraining, name)
-    if name in ("extract_features", "extract_embeddings", "extract_cnn_feature", "fliplr", "pairwise_distance", "pairwise_distance_device"):
+    if name in ("extract_features", "extract_embeddings", "extract_cnn_feature", "fliplr", "pairwise_distance", "pairwise_distance_device",
+                "TensorBatchLoader"):
         from . import evaluators
         return getattr(evaluators, name)
     if name in ("re_ranking_plain", "re_ranking_plain_device"):

@@ -33,12 +33,33 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def _all_gather_into(out, t, group):
-    """one flat all-gather (RCCL: a single ring/direct transfer into the final buffer; gloo: same call in the CPU tests)"""
+_FLAT_OK = {}       # backend name -> does it implement all_gather_into_tensor (probed once per backend, never per call)
+
+
+def _flat_gather_supported(group):
+    """Decided ONCE per backend on a 1-element tensor: a per-call try/except would let a rank-local failure (OOM, an async RCCL
+    error) send one rank into the list-form collective while its peers sit in the flat one -- mismatched collectives hang and
+    hide the original error.  Every rank runs the same probe at the same point (the first gather of the group), so they agree."""
     import torch.distributed as dist
-    try:
+    be = str(dist.get_backend(group))
+    if be not in _FLAT_OK:
+        dev = torch.device("cuda", torch.cuda.current_device()) if be == "nccl" else torch.device("cpu")
+        ws = dist.get_world_size(group)
+        try:
+            dist.all_gather_into_tensor(torch.empty(ws, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), group=group)
+            _FLAT_OK[be] = True
+        except (RuntimeError, NotImplementedError):
+            _FLAT_OK[be] = False
+    return _FLAT_OK[be]
+
+
+def _all_gather_into(out, t, group):
+    """one flat all-gather (RCCL: a single ring/direct transfer into the final buffer; gloo: same call in the CPU tests).
+    Real errors propagate: the variant was chosen when the group was first used."""
+    import torch.distributed as dist
+    if _flat_gather_supported(group):
         dist.all_gather_into_tensor(out, t, group=group)
-    except (RuntimeError, NotImplementedError):      # backend without the flat variant: list form + copy
+    else:                                              # backend without the flat variant: list form into views of `out`
         ws = dist.get_world_size(group)
         parts = list(out.view((ws,) + tuple(t.shape)).unbind(0))
         dist.all_gather(parts, t, group=group)
@@ -76,22 +97,50 @@ def gather_rows(t, group, n_total=None):
     return torch.cat([buf[:rem].reshape((rem * mx,) + tail), buf[rem:, :base].reshape(((ws - rem) * base,) + tail)], dim=0)
 
 
-def gather_varlen(t, group):
-    """all-gather row blocks of different lengths [n_r, ...] -> [sum n_r, ...] (rank order)."""
+def gather_counts(n, group, device=None):
+    """row count of every rank as a python list: ONE flat all-gather of an int64 + one host read"""
+    if group is None:
+        return [int(n)]
+    import torch.distributed as dist
+    ws = dist.get_world_size(group)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if str(dist.get_backend(group)) == "nccl" else torch.device("cpu")
+    out = torch.empty(ws, dtype=torch.int64, device=device)
+    _all_gather_into(out, torch.tensor([int(n)], dtype=torch.int64, device=device), group)
+    return [int(c) for c in out.tolist()]
+
+
+def gather_ragged(t, counts, group):
+    """all-gather row blocks whose lengths every rank already knows (`counts`, rank order) -> [sum counts, ...]: ONE flat
+    all-gather of blocks padded to the longest, no size exchange, no host synchronisation."""
     if group is None:
         return t
     import torch.distributed as dist
-    ws = dist.get_world_size(group)
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(ws)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes + [1])
-    pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    pad[: t.shape[0]] = t
-    parts = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:s] for p, s in zip(parts, sizes)], dim=0)
+    ws, rk = dist.get_world_size(group), dist.get_rank(group)
+    if len(counts) != ws or int(counts[rk]) != t.shape[0]:
+        raise ValueError("gather_ragged: rank %d holds %d rows, counts say %r" % (rk, t.shape[0], list(counts)))
+    tail = tuple(t.shape[1:])
+    mx = max(max(counts), 1)
+    t = t.contiguous()
+    if t.shape[0] != mx:
+        pad = torch.zeros((mx,) + tail, dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        t = pad
+    buf = torch.empty((ws * mx,) + tail, dtype=t.dtype, device=t.device)
+    _all_gather_into(buf, t, group)
+    if all(c == mx for c in counts):
+        return buf
+    buf = buf.view((ws, mx) + tail)
+    return torch.cat([buf[r, : counts[r]] for r in range(ws)], dim=0)
+
+
+def gather_varlen(t, group):
+    """all-gather row blocks of lengths only their owners know [n_r, ...] -> [sum n_r, ...] (rank order): one flat gather of
+    the counts (one host read) + one flat gather of the padded blocks.  Tables whose block sizes follow from `shard_bounds`
+    use `gather_rows` instead (no size exchange at all)."""
+    if group is None:
+        return t
+    return gather_ragged(t, gather_counts(t.shape[0], group, t.device), group)
 
 
 def all_reduce_sum(t, group):

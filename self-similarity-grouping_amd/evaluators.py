@@ -44,26 +44,106 @@ def _check_model(model):
     return m
 
 
-def extract_embeddings(model, data_loader, for_eval=False, print_freq=0):
+class TensorBatchLoader(object):
+    """Minimal extraction loader over an image tensor that is already resident (CPU or HBM): yields
+    `(imgs [b,3,H,W], fnames, pids, camids)` in order, like the `DataLoader(Preprocessor(...), shuffle=False)` of
+    selftraining.py:49-53.  `shard(rank, world)` returns the loader of this rank's contiguous block of batches."""
+
+    def __init__(self, images, batch_size=128, fnames=None, pids=None, first=0, count=None):
+        self.images, self.batch_size = images, int(batch_size)
+        self.first = int(first)
+        self.count = int(images.shape[0] - first if count is None else count)
+        self.fnames, self.pids = fnames, pids
+
+    def __len__(self):
+        return (self.count + self.batch_size - 1) // self.batch_size
+
+    def num_items(self):
+        return self.count
+
+    def shard(self, rank, world):
+        from .dist import shard_bounds
+        lo, hi = shard_bounds(len(self), rank, world)
+        i0 = min(lo * self.batch_size, self.count); i1 = min(hi * self.batch_size, self.count)
+        return TensorBatchLoader(self.images, self.batch_size, self.fnames, self.pids, self.first + i0, i1 - i0)
+
+    def __iter__(self):
+        for b0 in range(self.first, self.first + self.count, self.batch_size):
+            b1 = min(b0 + self.batch_size, self.first + self.count)
+            names = self.fnames[b0:b1] if self.fnames is not None else ["%08d" % i for i in range(b0, b1)]
+            ids = self.pids[b0:b1] if self.pids is not None else [0] * (b1 - b0)
+            yield self.images[b0:b1], names, ids, [0] * (b1 - b0)
+
+
+def _rank_batches(data_loader, group):
+    """this rank's share of an extraction loader: the contiguous `shard_bounds` block of its batches (the
+    reference splits every batch over the GPUs with nn.DataParallel, selftraining.py:135).  Loaders with a `shard(rank, world)`
+    method (GpuBatchLoader, TensorBatchLoader) only ever touch their own images; any other iterable is walked in full and the
+    foreign batches are skipped (their CPU-side decode is then wasted: give such loaders a `shard`)."""
+    if group is None:
+        return data_loader
+    import torch.distributed as dist
+    from .dist import shard_bounds
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if hasattr(data_loader, "shard"):
+        return data_loader.shard(rank, world)
+    lo, hi = shard_bounds(len(data_loader), rank, world)
+
+    def mine():
+        for i, batch in enumerate(data_loader):
+            if i >= hi:
+                break
+            if i >= lo:
+                yield batch
+    return mine()
+
+
+def extract_embeddings(model, data_loader, for_eval=False, print_freq=0, group=None, gather=True):
     """Device-resident extraction: returns (feats, fnames, pids) with feats
-    [(S+1), N, 2048] (for_eval=False, split model) or [N, D] CUDA float32, in loader order."""
+    [(S+1), N, 2048] (for_eval=False, split model) or [N, D] CUDA float32, in loader order.
+
+    group: torch.distributed group (one process per GPU).  The loader's batches are sharded contiguously over the ranks, every
+    rank embeds its own share and the embeddings are all-gathered (C1 of SURVEY.md 8e: ONE flat all-gather of the feature
+    blocks over RCCL/xGMI + a tiny one for the block lengths; the file names / pids travel as one `all_gather_object`), so
+    every rank returns the full set in loader order -- bit-identical to the unsharded call, because an image's features do not
+    depend on which other images share its launch.  gather=False keeps the local share (feats of this rank's images only)."""
     m = _check_model(model).eval()
     chunks, fnames, pids = [], [], []
     t0 = time.time()
-    for i, batch in enumerate(data_loader):
+    mine = _rank_batches(data_loader, group)
+    nb = len(mine) if hasattr(mine, "__len__") else len(data_loader)
+    for i, batch in enumerate(mine):
         imgs, names, ids = batch[0], batch[1], batch[2]
         chunks.append(m.embed_with_flip(torch.as_tensor(imgs), for_eval=for_eval))
         fnames.extend(list(names)); pids.extend(list(ids))
         if print_freq and (i + 1) % print_freq == 0:
-            print('Extract Features: [{}/{}]\tTime {:.3f}'.format(i + 1, len(data_loader), time.time() - t0))
-    feats = torch.cat(chunks, dim=1 if chunks[0].dim() == 3 else 0)
+            print('Extract Features: [{}/{}]\tTime {:.3f}'.format(i + 1, nb, time.time() - t0))
+    if chunks:
+        feats = torch.cat(chunks, dim=1 if chunks[0].dim() == 3 else 0)
+    else:       # more ranks than batches: an empty share of the right shape
+        nsets = (m.num_split + 1) if m.num_split > 1 else 1
+        feats = torch.empty((nsets, 0, 2048) if (nsets > 1 and not for_eval) else (0, nsets * 2048), dtype=torch.float32, device=m.device)
+    if group is None or not gather:
+        return feats, fnames, pids
+    import torch.distributed as dist
+    from .dist import gather_counts, gather_ragged
+    three = feats.dim() == 3
+    rows = feats.permute(1, 0, 2).contiguous() if three else feats          # image-major rows
+    counts = gather_counts(rows.shape[0], group, rows.device)
+    rows = gather_ragged(rows, counts, group)
+    feats = rows.permute(1, 0, 2).contiguous() if three else rows
+    meta = [None] * dist.get_world_size(group)
+    dist.all_gather_object(meta, (fnames, pids), group=group)
+    fnames = [f for part in meta for f in part[0]]
+    pids = [p for part in meta for p in part[1]]
     return feats, fnames, pids
 
 
-def extract_features(model, data_loader, print_freq=20, for_eval=True, metric=None):
-    """Drop-in for reid/evaluators.py:18-60."""
+def extract_features(model, data_loader, print_freq=20, for_eval=True, metric=None, group=None):
+    """Drop-in for reid/evaluators.py:18-60.  group: see extract_embeddings (sharded over the GPUs of the node, full
+    dictionaries on every rank)."""
     m = _check_model(model)
-    feats, fnames, pids = extract_embeddings(m, data_loader, for_eval=for_eval, print_freq=print_freq)
+    feats, fnames, pids = extract_embeddings(m, data_loader, for_eval=for_eval, print_freq=print_freq, group=group)
     features, labels = OrderedDict(), OrderedDict()
     cpu = feats.cpu()
     if not bool(torch.isfinite(cpu).all()):

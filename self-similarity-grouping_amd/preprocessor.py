@@ -114,12 +114,25 @@ class GpuBatchLoader(object):
         self.items = dataset if isinstance(dataset, Preprocessor) else Preprocessor(dataset, root)
         self.height, self.width, self.batch_size, self.mean, self.std, self.device = height, width, batch_size, mean, std, device
 
+        self.first, self.count = 0, len(self.items)
+
     def __len__(self):
-        return (len(self.items) + self.batch_size - 1) // self.batch_size
+        return (self.count + self.batch_size - 1) // self.batch_size
+
+    def shard(self, rank, world):
+        """loader of this rank's contiguous block of batches (`ssg_amd.dist.shard_bounds` over the batches): what
+        `extract_features(..., group=)` iterates, so that a rank only decodes the images it embeds"""
+        import copy
+        from .dist import shard_bounds
+        lo, hi = shard_bounds(len(self), rank, world)
+        sub = copy.copy(self)
+        i0 = min(lo * self.batch_size, self.count); i1 = min(hi * self.batch_size, self.count)
+        sub.first, sub.count = self.first + i0, i1 - i0
+        return sub
 
     def __iter__(self):
-        n = len(self.items)
-        for b0 in range(0, n, self.batch_size):
+        n = self.first + self.count
+        for b0 in range(self.first, n, self.batch_size):
             recs = [self.items[i] for i in range(b0, min(n, b0 + self.batch_size))]
             dev = torch.device("cuda", torch.cuda.current_device()) if self.device is None else torch.device(self.device)
             out = torch.empty((len(recs), 3, self.height, self.width), dtype=torch.float32, device=dev)

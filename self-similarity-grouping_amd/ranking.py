@@ -66,7 +66,8 @@ def per_query_all(distmat, query_ids=None, gallery_ids=None, query_cams=None, ga
     m, n = d.shape
     qid = _ids(query_ids, m, np.arange, dev); gid = _ids(gallery_ids, n, np.arange, dev)
     qcam = _ids(query_cams, m, lambda k: np.zeros(k), dev); gcam = _ids(gallery_cams, n, lambda k: np.ones(k), dev)
-    cap = int(min(2048, max(1, int(torch.bincount(gid.long()).max().item()))))      # no query can have more matches than the largest gallery identity
+    cap = int(min(2048, max(1, int(torch.unique(gid, return_counts=True)[1].max().item())))) if n else 1      # no query can have more matches than the largest
+    # gallery identity (unique counts, not bincount: raw Market-1501 lists carry the junk pid -1, ids may be large and sparse)
     first = torch.empty(m, dtype=torch.int32, device=dev); ap = torch.empty(m, dtype=torch.float64, device=dev)
     ovf = torch.zeros(1, dtype=torch.int32, device=dev)
     nmb = torch.zeros((m, cap), dtype=torch.int32, device=dev); nm = torch.zeros(m, dtype=torch.int32, device=dev)

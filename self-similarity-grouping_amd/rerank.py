@@ -45,18 +45,22 @@ class DistHandle:
         return self.M.device
 
     _pending = None
+    _error = None
 
     def validate(self):
-        """Raise what the pipeline could only detect on the device (read once, with the caller's host round trip)."""
-        if self._pending is None:
-            return self
-        vmax_h, flag_h = self._pending.tolist()
-        self._pending = None
-        if flag_h:
-            raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
-        if int(vmax_h) & 0x7FFF == 0:
-            raise ReRankNaNError("max(source_dist_vec) == 0: every target->source 1-exp(-d^2) rounds to 0 in float16; the reference "
-                                 "(reid/rerank.py:40) would return an all-NaN final_dist")
+        """Raise what the pipeline could only detect on the device.  The status words are read once (with the caller's host
+        round trip); a failure is kept on the handle and raised again by every later call, so a caller that catches the
+        error cannot go on to cluster the NaN matrix."""
+        if self._pending is not None:
+            vmax_h, flag_h = self._pending.tolist()
+            self._pending = None
+            if flag_h:
+                self._error = _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
+            elif int(vmax_h) & 0x7FFF == 0:
+                self._error = ReRankNaNError("max(source_dist_vec) == 0: every target->source 1-exp(-d^2) rounds to 0 in float16; the "
+                                             "reference (reid/rerank.py:40) would return an all-NaN final_dist")
+        if self._error is not None:
+            raise self._error
         return self
 
     def final_dist(self):

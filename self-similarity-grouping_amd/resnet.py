@@ -185,6 +185,7 @@ class ResNet:
         self.device = torch.device("cpu")
         self._sd = synthetic_state_dict(seed, depth, num_features)
         self._folded = None
+        self._twin = None
         self._weights = "synthetic"      # until load_state_dict puts real backbone weights in
         if checkpoint:
             self.load_state_dict(torch.load(checkpoint, map_location="cpu"), strict=False)
@@ -217,7 +218,7 @@ class ResNet:
                 if tuple(v.shape) != tuple(self._sd[k].shape):
                     raise RuntimeError("size mismatch for %s: %r vs %r" % (k, tuple(v.shape), tuple(self._sd[k].shape)))
                 self._sd[k] = v.detach().to("cpu").clone()
-        self._folded = None
+        self._invalidate()
         miss_base = [k for k in missing if k.startswith("base.") and not k.endswith("num_batches_tracked")]
         if miss_base:
             import warnings
@@ -236,14 +237,23 @@ class ResNet:
             raise NotImplementedError("ssg_amd.resnet.ResNet is an inference-only embedder")
         return self.eval()
 
+    def _invalidate(self):
+        """weights or device changed: drop the folded weights AND the cached fp32 fallback model (it keeps folded weights and a
+        device of its own; INTEGRATION.md's loop calls load_state_dict() every self-training iteration)"""
+        self._folded = None
+        self._twin = None
+
     def cuda(self, device=None):
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-        self._folded = None
+        self._invalidate()
         return self
 
     def to(self, device):
-        self.device = torch.device(device); self._folded = None
+        self.device = torch.device(device); self._invalidate()
         return self
+
+    def cpu(self):
+        return self.to("cpu")
 
     @property
     def module(self):   # nn.DataParallel(model).module compatibility (selftraining.py:135,230)

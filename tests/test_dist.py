@@ -146,3 +146,157 @@ def test_sharded_pipeline_matches_unsharded(world, N):
                     assert m == hashlib.sha256(np.ascontiguousarray(m0[lo:hi]).tobytes()).hexdigest(), (mode, s, r)
                 else:
                     assert np.array_equal(m, m0[lo:hi]), (mode, s, r)
+
+
+# ------------------------------------------------------------------ sharded feature extraction (images split by rank + C1 all-gather)
+class _FakeEmbedder:
+    """stands in for the HIP ResNet in the CPU plumbing test: a deterministic per-image function of the pixels"""
+    num_split = 2
+    device = torch.device("cpu")
+
+    def eval(self):
+        return self
+
+    def embed_with_flip(self, x, for_eval=False):
+        x = x.float()
+        base = torch.stack([x.mean(dim=(1, 2, 3)), x.amax(dim=(1, 2, 3)), x[:, 0].sum(dim=(1, 2))], dim=1)      # [B, 3]
+        feats = torch.stack([base.repeat(1, 683)[:, :2048] * (s + 1) for s in range(3)])                         # [3, B, 2048]
+        return feats.permute(1, 0, 2).reshape(x.shape[0], -1).contiguous() if for_eval else feats
+
+
+def _extract_cpu_worker(rank, world, port, q, n_img, batch):
+    import torch.distributed as dist
+    import ssg_amd  # noqa: F401
+    from ssg_amd import evaluators as ev
+    ev._check_model = lambda m: m
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    g = dist.group.WORLD
+    imgs = torch.randn(n_img, 3, 8, 4, generator=torch.Generator().manual_seed(3))
+    names = ["img%05d.jpg" % i for i in range(n_img)]
+    pids = [i % 7 for i in range(n_img)]
+    model = _FakeEmbedder()
+    ok = True
+    for for_eval in (False, True):
+        ref, rn, rp = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, batch, names, pids), for_eval=for_eval)
+        got, gn, gp = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, batch, names, pids), for_eval=for_eval, group=g)
+        ok = ok and torch.equal(ref, got) and rn == gn and rp == gp
+        # a loader without shard(): the generic skip-foreign-batches path
+        plain = list(ev.TensorBatchLoader(imgs, batch, names, pids))
+        got2, gn2, _ = ev.extract_embeddings(model, plain, for_eval=for_eval, group=g)
+        ok = ok and torch.equal(ref, got2) and rn == gn2
+        loc, ln, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, batch, names, pids), for_eval=for_eval, group=g, gather=False)
+        lo, hi = ev.TensorBatchLoader(imgs, batch).shard(rank, world).first, None
+        ok = ok and ln == names[lo:lo + len(ln)] and loc.shape[-2 if not for_eval else 0] == len(ln)
+    feats, labels = ev.extract_features(model, ev.TensorBatchLoader(imgs, batch, names, pids), print_freq=0, for_eval=False, group=g)
+    rfeats, rlabels = ev.extract_features(model, ev.TensorBatchLoader(imgs, batch, names, pids), print_freq=0, for_eval=False)
+    ok = ok and list(feats) == list(rfeats) == names and labels == rlabels
+    ok = ok and all(len(feats[n]) == 3 and all(torch.equal(a, b) for a, b in zip(feats[n], rfeats[n])) for n in names)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_img,batch", [(2, 37, 4), (3, 10, 4), (3, 5, 4)])
+def test_sharded_extraction_plumbing_gloo(world, n_img, batch):
+    """extract_embeddings / extract_features(group=): contiguous batch blocks per rank + all-gather == the unsharded call
+    (ragged last batch, fewer batches than ranks, loaders with and without shard())."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_extract_cpu_worker, args=(r, world, port, q, n_img, batch)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    [p.join(60) for p in procs]
+    assert res == [(r, True) for r in range(world)]
+
+
+def _extract_gpu_worker(rank, world, port, q, n_img, batch, backend):
+    import torch.distributed as dist
+    import ssg_amd
+    from ssg_amd import evaluators as ev
+    torch.cuda.set_device(0)                       # before the process group (RCCL binds the communicator to the current device)
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    g = dist.group.WORLD
+    imgs = torch.randn(n_img, 3, 256, 128, generator=torch.Generator().manual_seed(17))
+    model = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=1, pretrained=False).cuda().eval()
+    got, names, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, batch), for_eval=False, group=g)
+    q.put((rank, got.cpu().numpy(), names))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_extraction_matches_unsharded(world):
+    """The embedding half of the multi-GPU path (selftraining.py:135,196-209 under nn.DataParallel in the reference): images
+    sharded over `world` processes (gloo; they share the test box's single GPU), embeddings all-gathered -- bit-identical to the
+    single-process extraction, in loader order, on every rank."""
+    import ssg_amd
+    from ssg_amd import evaluators as ev
+    n_img, batch = 45, 4
+    imgs = torch.randn(n_img, 3, 256, 128, generator=torch.Generator().manual_seed(17))
+    model = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=1, pretrained=False).cuda().eval()
+    ref, rnames, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, batch), for_eval=False)
+    one, _, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, n_img), for_eval=False)
+    assert torch.equal(ref, one), "an image's features must not depend on its batch"
+    ref = ref.cpu().numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_extract_gpu_worker, args=(r, world, port, q, n_img, batch, "gloo")) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=900) for _ in range(world)]
+    [p.join(120) for p in procs]
+    assert sorted(r[0] for r in res) == list(range(world))
+    for r, got, names in res:
+        assert names == rnames and got.shape == ref.shape == (3, n_img, 2048)
+        assert np.array_equal(got, ref), "rank %d" % r
+
+
+def _nccl_world1_worker(port, q):
+    """the RCCL code path with one rank: every collective of the sharded pipeline executes on the nccl backend"""
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    import ssg_amd
+    from ssg_amd import compute_dist, generate_selflabel, evaluators as ev, dist as sd
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    g = dist.group.WORLD
+    assert str(dist.get_backend(g)) == "nccl"
+    out = {}
+    N, Ns, d = 1531, 640, 96
+    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(2)]
+    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(2)]
+    for mode, no_rerank in (("rerank", False), ("norerank", True)):
+        res = []
+        for grp in (g, None):
+            e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2, group=grp)
+            labels, clusters = generate_selflabel(e_list, r_list, 0, SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3), [])
+            hs = e_list if no_rerank else r_list
+            res.append([(float(c.eps), l, h.M.cpu().numpy().view(np.uint16)) for c, l, h in zip(clusters, labels, hs)])
+        out[mode] = all(a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) for a, b in zip(*res))
+    imgs = torch.randn(9, 3, 256, 128, generator=torch.Generator().manual_seed(17))
+    model = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=1, pretrained=False).cuda().eval()
+    a, na, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, 4), group=g)
+    b, nb, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, 4))
+    out["extract"] = bool(torch.equal(a, b)) and na == nb
+    t = torch.arange(12, dtype=torch.int32, device=dev).view(6, 2)
+    out["gathers"] = bool(torch.equal(sd.gather_rows(t, g, 6), t)) and bool(torch.equal(sd.gather_varlen(t, g), t)) and sd._FLAT_OK.get("nccl") is True
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_backend_world1_smoke():
+    """torch.distributed's `nccl` backend IS RCCL on ROCm; the test box has one GPU, so this is a one-rank communicator --
+    what it proves is that every collective of the sharded path (flat all-gathers of row tables / embeddings / ragged blocks,
+    the eps all-reduces, all_gather_object, barrier) executes on RCCL with device tensors, before an 8-GPU node ever sees it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=600)
+    p.join(120)
+    assert out == {"rerank": True, "norerank": True, "extract": True, "gathers": True}, out

@@ -93,6 +93,23 @@ def test_numpy_primitives(ora):
         assert np.sum(h) == np.float16(ora.pairwise_sum(h.astype(np.float32)))
 
 
+def test_installed_numpy_introsort_threshold(ora):
+    """The default rank_mode replays np.argsort's unstable introsort, whose tie order depends on the range size at which numpy
+    switches to insertion sort.  The kernel (csrc/topk_intro.hip SSG_INTRO_SMALL), the oracle and the goldens use 15
+    (`pr - pl > 15`: 17 elements are still partitioned), the behaviour of the numpy 2.2.6 build of this image; numpy's source
+    constant reads 16.  This probe finds 17-element tie patterns on which the two thresholds order differently and checks that the
+    INSTALLED numpy sides with 15 -- if it ever fails, rebuild with -DSSG_INTRO_SMALL=16 and regenerate the goldens."""
+    rng = np.random.default_rng(11)
+    probes = 0
+    for _ in range(4000):
+        h = (rng.integers(0, 4, 17) / 4.0).astype(np.float16)
+        a15, a16 = ora.argsort_half(h, small=15), ora.argsort_half(h, small=16)
+        if not np.array_equal(a15, a16):
+            probes += 1
+            assert np.array_equal(np.argsort(h), a15), "installed numpy %s partitions at a different range size than 15" % np.__version__
+    assert probes > 20
+
+
 def test_oracle_matches_scipy_cdist(ora):
     from scipy.spatial.distance import cdist
     rng = np.random.default_rng(3)
