@@ -316,6 +316,19 @@ int ssg_selftest_half_table(int which, uint16_t* out65536, ssg_stream_t stream);
 int ssg_selftest_half_binop(int which, const uint16_t* a, const uint16_t* b, int n, uint16_t* out, ssg_stream_t stream);
 int ssg_selftest_d2h(const double* a, int n, uint16_t* out, ssg_stream_t stream);
 
+/* ---- collectives of the sharded path: RCCL over xGMI, one rank per process / GPU ------------------------
+ * The reference spreads the extraction over GPUs with nn.DataParallel (selftraining.py:135) and has no multi-GPU N x N path.
+ * Every exchange of the sharded pipeline is an all-gather of equally sized blocks (embeddings, rank lists, sparse V / V_qe,
+ * source vector) or an int64 sum all-reduce (eps histogram).  The Python product issues them through torch.distributed
+ * (backend "nccl" = RCCL on ROCm); a host language without torch binds these four calls instead.
+ * ssg_comm_unique_id: 128 host bytes created by rank 0, passed by EVERY rank to ssg_comm_init (a collective; the communicator
+ * binds to the caller's current HIP device).  ssg_allgather: recv[r * bytes_per_rank ...] = rank r's block. */
+int ssg_comm_unique_id(void* id128_host);
+int ssg_comm_init(void** comm, int world, int rank, const void* id128_host);
+int ssg_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, ssg_stream_t stream);
+int ssg_allreduce_sum_i64(void* comm, int64_t* buf, size_t count, ssg_stream_t stream);
+int ssg_comm_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

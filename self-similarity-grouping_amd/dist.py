@@ -154,3 +154,52 @@ def barrier(group):
     if group is not None:
         import torch.distributed as dist
         dist.barrier(group=group)
+
+
+class AbiComm(object):
+    """RCCL communicator through the C ABI (include/ssg_hip.h: ssg_comm_init / ssg_allgather / ssg_allreduce_sum_i64 /
+    ssg_comm_destroy) -- what a host language without torch binds.  The Python product itself issues its collectives through
+    torch.distributed (backend "nccl" is the same RCCL); this wrapper exists so that the ABI's collective entry points are
+    exercised (tests/test_abi.py) and usable: `all_gather_rows` has the semantics of `gather_rows` for equal blocks.
+
+    id128: the 128 bytes of `AbiComm.unique_id()` created on rank 0 and shipped to every rank (file, socket, a
+    torch.distributed store ...)."""
+
+    def __init__(self, world, rank, id128):
+        import ctypes
+        from . import _lib
+        self._L = _lib.lib()
+        self.world, self.rank = int(world), int(rank)
+        h = ctypes.c_void_p()
+        buf = (ctypes.c_ubyte * 128).from_buffer_copy(bytes(id128))
+        _lib.check(self._L.ssg_comm_init(ctypes.byref(h), self.world, self.rank, buf), "ssg_comm_init")
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from . import _lib
+        buf = (ctypes.c_ubyte * 128)()
+        _lib.check(_lib.lib().ssg_comm_unique_id(buf), "ssg_comm_unique_id")
+        return bytes(buf)
+
+    def all_gather_rows(self, t):
+        """[n, ...] blocks of equal size on every rank -> [world * n, ...] in rank order (one ncclAllGather on the current stream)"""
+        from . import _lib
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        _lib.check(self._L.ssg_allgather(self._h, _lib.ptr(t), _lib.ptr(out), t.numel() * t.element_size(), _lib.stream()), "ssg_allgather")
+        return out
+
+    def all_reduce_sum_(self, t):
+        from . import _lib
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            raise ValueError("all_reduce_sum_: contiguous int64 tensors (eps histograms, counts)")
+        _lib.check(self._L.ssg_allreduce_sum_i64(self._h, _lib.ptr(t), t.numel(), _lib.stream()), "ssg_allreduce_sum_i64")
+        return t
+
+    def destroy(self):
+        from . import _lib
+        if self._h is not None:
+            _lib.check(self._L.ssg_comm_destroy(self._h), "ssg_comm_destroy")
+            self._h = None

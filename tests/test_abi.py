@@ -111,3 +111,31 @@ def test_split_half_host_formats():
     for (o, r, s, c) in ((0, 0, 0, 0), (1, 2, 1, 37), (0, 1, 2, 63), (1, 0, 0, 32)):
         k = ((c // 32) * kh * kw + r * kw + s) * 32 + c % 32
         assert pk[o, k] == w[o, r, s, c]
+
+
+def test_comm_entry_points_validate_without_gpu():
+    """the collective entry points of the ABI refuse bad arguments before touching RCCL"""
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    assert L.ssg_comm_unique_id(None) == -1
+    assert L.ssg_comm_init(ctypes.byref(h), 0, 0, (ctypes.c_ubyte * 128)()) == -1 and b"world" in L.ssg_last_error()
+    assert L.ssg_comm_init(ctypes.byref(h), 2, 2, (ctypes.c_ubyte * 128)()) == -1
+    assert L.ssg_allgather(None, None, None, 16, None) == -1
+    assert L.ssg_allreduce_sum_i64(None, None, 4, None) == -1
+    assert L.ssg_comm_destroy(None) == 0
+
+
+@pytest.mark.gpu
+def test_comm_entry_points_world1_on_rccl():
+    """ssg_comm_unique_id -> ssg_comm_init -> ssg_allgather / ssg_allreduce_sum_i64 -> ssg_comm_destroy on a one-rank RCCL
+    communicator (the test box has one GPU): the entry points a non-torch host binds run end to end on the device."""
+    import torch
+    from ssg_amd.dist import AbiComm
+    torch.cuda.set_device(0)
+    comm = AbiComm(1, 0, AbiComm.unique_id())
+    t = torch.arange(40, dtype=torch.float32, device="cuda").view(10, 4)
+    assert torch.equal(comm.all_gather_rows(t), t)
+    hh = torch.arange(7, dtype=torch.int64, device="cuda")
+    assert torch.equal(comm.all_reduce_sum_(hh.clone()), hh)
+    torch.cuda.synchronize()
+    comm.destroy()
