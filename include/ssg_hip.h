@@ -96,8 +96,11 @@ int ssg_topk_rank(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, i
  * introsort on an index array (npysort aquicksort_<half>: median-of-3 Hoare partition, insertion sort below 17 entries,
  * heapsort past the depth budget), so the column of equal keys depends on the whole partition sequence.  One workgroup per
  * row replays exactly the partitions that reach columns [0,K) (csrc/topk_intro.hip).  2 <= N <= 131072, K <= 64.
- * ws: ssg_topk_rank_introsort_ws_bytes(N, nrows) bytes (0 while a row fits in LDS, N <= ~36 k).  A caller that passes
- * ssg_topk_rank_introsort_arena_bytes(N, nrows) bytes anyway selects the global-arena variant for any N (parity tests). */
+ * Two launches: a workgroup per row runs the partitions of ranges longer than 2048 entries (SSG_INTRO_TAILN; 0 = one launch,
+ * the round-2 kernel) and hands the shorter ranges that still intersect [0, K) to a one-wave-per-row tail kernel through ws.
+ * ws: ssg_topk_rank_introsort_ws_bytes(N, nrows) bytes = the hand-over records (about 9 KB per row) plus, for rows that do not fit
+ * in LDS (N > ~36 k), the global arena.  A caller that passes ssg_topk_rank_introsort_arena_bytes(N, nrows) bytes selects the
+ * global-arena variant for any N (parity tests). */
 size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows);
 size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows);
 int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws, size_t ws_bytes,

@@ -542,8 +542,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
 // 16 waves: a third fewer global -> LDS bytes per MFMA than 128 x 256, which is what bounds these kernels).
 // DUAL: a second 1x1 input is concatenated along K (fused downsample branch); a compile-time switch, because the main loop is bound
 // by instruction issue (every branch, scalar division and v_readfirstlane per k-tile shows).
-template <int BN, bool ONEPROD = false, int BM = 128, bool DUAL = false>
+// NS: LDS stages (NS - 1 k-tiles in flight).  The 1x1 convolutions that stream their pixel operand from HBM (K = 512 ... 2048) sat at
+// 0.4 of the matrix peak AND 0.4 of the HBM rate with two 32 KB tiles in flight per CU: bytes in flight / memory latency was the
+// bound (64 KB / ~3 us = 21 GB/s per CU).  The 256 x 256 kernel (one workgroup per CU, 96 of 160 KB of LDS) takes a fourth stage.
+template <int BN, bool ONEPROD = false, int BM = 128, bool DUAL = false, int NS = 3>
 __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 256 ? 4 : 3)) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
+  static_assert(NS == 3 || NS == 4, "three or four stages");
   constexpr int WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
   constexpr int WCOLS = BN / WN, NW = (BM / WM) * WCOLS;             // 8 waves (2 x 4) for 128 x 256, 4 waves (2 x 2) for 128 x 128, 16 (4 x 4) for 256 x 256
   constexpr int ABLK = BM / 16 / NW, WBLK = BN / 16 / NW;            // 16-row A / W blocks per wave and stage: 1 or 2
@@ -551,6 +555,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   __shared__ __attribute__((aligned(1024))) unsigned char st0[STAGE_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char st1[STAGE_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char st2[STAGE_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char st3[NS == 4 ? STAGE_BYTES : 1024];
   const int tiles_n = p.Cout / BN, tiles_m = (p.M + BM - 1) / BM;
   const int tile = conv_xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
@@ -646,29 +651,56 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   // i.e. for the tile it issued a moment ago; the explicit pair below waits only for the older tile (each tile is 3 or 4 DMA
   // instructions per wave) and then publishes it.  The compiler's own tracking of the DMA -> LDS-array dependencies stays in
   // force for the fragment reads (separate __shared__ arrays per stage).
+  // (NS stages: NS - 1 tiles in flight, the wait leaves the NS - 2 newest tiles' DMAs outstanding)
 #define SSG_PUBLISH()                                                                                              \
-  { if (ABLK + WBLK == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                           \
-    else if (ABLK + WBLK == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");                      \
+  { constexpr int OUTST = (ABLK + WBLK) * (NS - 2);                                                                \
+    if (OUTST == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");                                  \
+    else if (OUTST == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");                             \
+    else if (OUTST == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                             \
+    else if (OUTST == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");                             \
     else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); }
+  static_assert((ABLK + WBLK) * (NS - 2) == 8 || (ABLK + WBLK) * (NS - 2) == 6 || (ABLK + WBLK) * (NS - 2) == 4 || (ABLK + WBLK) * (NS - 2) == 3 ||
+                (ABLK + WBLK) * (NS - 2) == 2, "vmcnt literal for this tile shape");
   SSG_DMA_NEXT(st0)
   SSG_DMA_NEXT(st1)
-  const int nfull = nk / 3 * 3;
-  for (int kt = 0; kt < nfull; kt += 3) {   // tile t lives in stage array t % 3; no exits inside (they doubled the accumulators)
-    SSG_PUBLISH();                        // tile kt landed in st0 for every wave; everybody is done reading st2 (tile kt-1)
-    SSG_DMA_NEXT(st2)
-    __builtin_amdgcn_sched_barrier(0);    // keep the DMA issue ahead of the multiply
-    SSG_MMA(st0)
-    SSG_PUBLISH();
-    SSG_DMA_NEXT(st0)
-    __builtin_amdgcn_sched_barrier(0);
-    SSG_MMA(st1)
-    SSG_PUBLISH();
-    SSG_DMA_NEXT(st1)
-    __builtin_amdgcn_sched_barrier(0);
-    SSG_MMA(st2)
+  if constexpr (NS == 4) SSG_DMA_NEXT(st2)
+  const int nfull = nk / NS * NS;
+  for (int kt = 0; kt < nfull; kt += NS) {   // tile t lives in stage array t % NS; no exits inside (they doubled the accumulators)
+    if constexpr (NS == 3) {
+      SSG_PUBLISH();                        // tile kt landed in st0 for every wave; everybody is done reading st2 (tile kt-1)
+      SSG_DMA_NEXT(st2)
+      __builtin_amdgcn_sched_barrier(0);    // keep the DMA issue ahead of the multiply
+      SSG_MMA(st0)
+      SSG_PUBLISH();
+      SSG_DMA_NEXT(st0)
+      __builtin_amdgcn_sched_barrier(0);
+      SSG_MMA(st1)
+      SSG_PUBLISH();
+      SSG_DMA_NEXT(st1)
+      __builtin_amdgcn_sched_barrier(0);
+      SSG_MMA(st2)
+    } else {
+      SSG_PUBLISH();                        // tile kt landed in st0 for every wave; everybody is done reading st3 (tile kt-1)
+      SSG_DMA_NEXT(st3)
+      __builtin_amdgcn_sched_barrier(0);
+      SSG_MMA(st0)
+      SSG_PUBLISH();
+      SSG_DMA_NEXT(st0)
+      __builtin_amdgcn_sched_barrier(0);
+      SSG_MMA(st1)
+      SSG_PUBLISH();
+      SSG_DMA_NEXT(st1)
+      __builtin_amdgcn_sched_barrier(0);
+      SSG_MMA(st2)
+      SSG_PUBLISH();
+      SSG_DMA_NEXT(st2)
+      __builtin_amdgcn_sched_barrier(0);
+      SSG_MMA(st3)
+    }
   }
   if (nk - nfull >= 1) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st0) }
-  if (nk - nfull == 2) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
+  if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
+  if constexpr (NS == 4) { if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st2) } }
   __syncthreads();                        // drains the (clamped, redundant) tail DMAs before the stages become epilogue patches
 #undef SSG_PUBLISH
 #undef SSG_DMA_NEXT
@@ -980,13 +1012,16 @@ static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
     static int tall_dual = -1;               // SSG_CONV_TALL_DUAL=1: also for the fused conv3 | downsample GEMMs (tuning knob)
     if (tall_dual < 0) { const char* e = getenv("SSG_CONV_TALL_DUAL"); tall_dual = e ? atoi(e) : 0; }
     if (tall > 0 && p.products == 3 && p.epi == 0 && p.in2 && tall_dual && tiles_tall >= tall) {
-      hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, true>), dim3(tiles_tall), dim3(1024), 0, stream, p);
+      hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, true, 4>), dim3(tiles_tall), dim3(1024), 0, stream, p);
       return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<256x256, dual>");
     }
     static int tall_res = -1;                // SSG_CONV_TALL_RES=1: also for convolutions with a residual epilogue (tuning knob)
     if (tall_res < 0) { const char* e = getenv("SSG_CONV_TALL_RES"); tall_res = e ? atoi(e) : 0; }
     if (tall > 0 && p.products == 3 && p.epi == 0 && (!p.res || tall_res) && !p.in2 && tiles_tall >= tall) {   // measured: -2.5 % (3x3) / -6 % (1x1) on layer3 shapes; with a residual epilogue +3 %
-      hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false>), dim3(tiles_tall), dim3(1024), 0, stream, p);
+      static int tall_ns = -1;               // SSG_CONV_TALL_STAGES=3: the three-stage pipeline of round 2 (tuning knob)
+      if (tall_ns < 0) { const char* e = getenv("SSG_CONV_TALL_STAGES"); tall_ns = e ? atoi(e) : 4; }
+      if (tall_ns == 4) hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false, 4>), dim3(tiles_tall), dim3(1024), 0, stream, p);
+      else hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false>), dim3(tiles_tall), dim3(1024), 0, stream, p);
       return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<256x256>");
     }
     const int tiles = ((p.M + 127) / 128) * (p.Cout / 256);

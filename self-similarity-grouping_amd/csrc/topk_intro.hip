@@ -28,6 +28,8 @@
 //     sequential restatement (oracle/ssg_oracle.c aquicksort_half) on the CPU;
 //   * ranges of <= 1024 entries are finished by wave 0 alone (no workgroup barriers).
 #include "ssg_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace ssg {
 namespace intro {
@@ -71,7 +73,18 @@ struct Ctl {
   int stack[STACK * 3];                  // (pl, pr, depth budget) of pushed ranges that still matter
   int sp;
   uint32_t xp;                           // raw half of the current pivot
+  int ntail;                             // split mode: ranges handed to the tail kernel (they stay on `tail`, same triples)
+  int tail[STACK * 3];
 };
+
+// Split mode (default): the workgroup kernel only runs the partitions of ranges longer than `tailn` entries and hands every
+// shorter range that still intersects [0, K) to the tail kernel, where ONE WAVE per row finishes them -- 8 to 25 rows per CU at a
+// time instead of one wave working while the seven others of the row's workgroup idle (a third of a row's time in round 2).
+// Hand-over record of a row in global memory: TailHdr, then the entries A[0 .. hi) (hi <= K + tailn).
+struct TailHdr { int n, hi, pad0, pad1; int rng[STACK * 3]; };
+constexpr int TAIL_HDR_WORDS = (int)(sizeof(TailHdr) / 4);
+static_assert(TAIL_HDR_WORDS % 4 == 0, "the entries behind the header start on a 16-byte boundary");
+constexpr int NOCHECK = 1 << 20;   // added to the depth budget of a handed-over range that must not be depth-tested when the tail kernel pops it
 
 struct LdsArena {
   uint32_t* p;
@@ -414,10 +427,13 @@ __device__ __forceinline__ Split split_ranges(int pl, int pr, int pi) {
 }
 
 // sorts exactly the ranges of the introsort recursion that intersect [0, K)
+// tailn > 0: split mode -- ranges of at most tailn entries are recorded in sh->tail (sh->ntail) instead of being finished here;
+// tailn == 0: everything is finished in this kernel (ranges of at most WAVE_N entries by wave 0 alone, the round-2 behaviour).
 template <int NT, class Arena>
-__device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int N, int K PROF_ARG) {
+__device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int N, int K, int tailn PROF_ARG) {
   const int tid = (int)threadIdx.x, lane = lane_id(), wav = tid >> 6;
-  int sp = 0;
+  const int wave_n = tailn > 0 ? tailn : WAVE_N;
+  int sp = 0, ntail = 0;
   int pl = 0, pr = N - 1, cd = 2 * (31 - __clz(N));
   bool have = true;
   for (;;) {
@@ -426,14 +442,38 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
       __syncthreads();
       --sp;
       pl = uni(sh->stack[3 * sp]); pr = uni(sh->stack[3 * sp + 1]); cd = uni(sh->stack[3 * sp + 2]);
-      if (cd < 0) {                       // popped past the depth budget: heapsort the whole range
+      if (cd < 0 && !(tailn > 0 && pr - pl + 1 <= tailn)) {   // popped past the depth budget: heapsort the whole range (short ones: in the tail kernel)
         if (tid == 0) heapsort(A, fmx, pl, pr - pl + 1);
         continue;
       }
     }
     have = false;
     bool needed = true;
-    while (pr - pl > SMALL && pr - pl + 1 > WAVE_N) {
+    if (tailn > 0) {
+      const bool spent = cd < 0;          // only a short popped range reaches this point with a spent budget
+      if (!spent) {
+        while (pr - pl > SMALL && pr - pl + 1 > tailn) {
+          const int pi = partition<false, NT>(A, sh, mk, fmx, pl, pr PROF_PASS);
+          --cd;
+          const Split s = split_ranges(pl, pr, pi);
+          if (s.ql < K && s.ql <= s.qr) {
+            if (tid == 0) { sh->stack[3 * sp] = s.ql; sh->stack[3 * sp + 1] = s.qr; sh->stack[3 * sp + 2] = cd; }
+            ++sp;
+          }
+          if (s.cl < K && s.cl <= s.cr) { pl = s.cl; pr = s.cr; }
+          else { needed = false; break; }
+        }
+      }
+      if (needed && pr > pl) {            // at most tailn entries left (or a short range past its depth budget): the tail kernel's
+        // numpy tests the depth budget only when a range is POPPED (top of aquicksort's outer loop), never while it keeps
+        // partitioning the child it continues with: a range that passed the test here carries NOCHECK, a popped short range
+        // whose budget is spent (cd < 0) carries its raw cd and is heapsorted by the tail kernel
+        if (tid == 0) { sh->tail[3 * ntail] = pl; sh->tail[3 * ntail + 1] = pr; sh->tail[3 * ntail + 2] = spent ? cd : cd + NOCHECK; }
+        ++ntail;
+      }
+      continue;
+    }
+    while (pr - pl > SMALL && pr - pl + 1 > wave_n) {
       const int pi = partition<false, NT>(A, sh, mk, fmx, pl, pr PROF_PASS);
       --cd;
       const Split s = split_ranges(pl, pr, pi);
@@ -465,7 +505,38 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
       sp = uni(sh->sp);
     }
   }
+  if (tid == 0) sh->ntail = ntail;
   __syncthreads();
+}
+
+// the tail kernel's loop: one wave finishes the ranges on sh->stack (sp of them) -- the wave-level half of sort_prefix
+template <int NT, class Arena>
+__device__ __forceinline__ void sort_tail(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int K, int sp PROF_ARG) {
+  const int lane = lane_id();
+  while (sp > 0) {
+    gsync<true>();
+    --sp;
+    int pl = uni(sh->stack[3 * sp]), pr = uni(sh->stack[3 * sp + 1]), cd = uni(sh->stack[3 * sp + 2]);
+    if (cd >= NOCHECK / 2) cd -= NOCHECK;   // handed over in the middle of its partition loop: no depth test (see sort_prefix)
+    else if (cd < 0) {                    // popped past the depth budget: heapsort the whole range
+      if (lane == 0) heapsort(A, fmx, pl, pr - pl + 1);
+      continue;
+    }
+    bool needed = true;
+    while (pr - pl > SMALL) {
+      const int pi = partition<true, NT>(A, sh, mk, fmx, pl, pr PROF_PASS);
+      --cd;
+      const Split s = split_ranges(pl, pr, pi);
+      if (s.ql < K && s.ql <= s.qr) {
+        if (lane == 0) { sh->stack[3 * sp] = s.ql; sh->stack[3 * sp + 1] = s.qr; sh->stack[3 * sp + 2] = cd; }
+        ++sp;
+      }
+      if (s.cl < K && s.cl <= s.cr) { pl = s.cl; pr = s.cr; }
+      else { needed = false; break; }
+    }
+    if (needed && pr > pl) insertion(A, fmx, pl, pr);
+  }
+  gsync<true>();
 }
 
 // LDS: Ctl | L[wcap] R[wcap] (u64) | P[wcap] (u32) | entries.  Entry of column j lives at word `first + j`, where
@@ -474,7 +545,7 @@ __device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks
 template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void topk_introsort_kernel(const hbits* __restrict__ D, const unsigned* __restrict__ rowmax, int N, int nrows,
                                                             int K, int wcap, uint32_t* __restrict__ arena, size_t arena_stride,
-                                                            int32_t* __restrict__ rank) {
+                                                            int32_t* __restrict__ rank, int tailn, uint32_t* __restrict__ tails, size_t tail_stride) {
   extern __shared__ __align__(16) unsigned char smem[];
   Ctl* sh = reinterpret_cast<Ctl*>(smem);
   Masks mk;
@@ -536,19 +607,70 @@ __global__ __launch_bounds__(NT) void topk_introsort_kernel(const hbits* __restr
     }
     __syncthreads();
     PROF(0);
+    auto finish = [&](const auto& A) {
+      if (tailn == 0) {
+        if (tid < K) rank[(int64_t)row * K + tid] = (int32_t)(A.get(tid) & IDX_MASK);
+        return;
+      }
+      // split mode: hand the short ranges and the entries they cover (at least the first K) to the tail kernel
+      const int nt = sh->ntail;
+      int hi = K;
+      for (int q = 0; q < nt; q++) hi = max(hi, sh->tail[3 * q + 1] + 1);
+      uint32_t* trow = tails + (size_t)row * tail_stride;
+      if (tid == 0) { trow[0] = (uint32_t)nt; trow[1] = (uint32_t)hi; }
+      for (int q = tid; q < 3 * nt; q += NT) trow[4 + q] = (uint32_t)sh->tail[q];
+      for (int j = tid; j < hi; j += NT) trow[TAIL_HDR_WORDS + j] = A.get(j);
+    };
     if (LDS) {
       LdsArena A{ent + first};
-      sort_prefix<NT>(A, sh, mk, fmx, N, K PROF_PASS);
+      sort_prefix<NT>(A, sh, mk, fmx, N, K, tailn PROF_PASS);
       PROF(9);
-      if (tid < K) rank[(int64_t)row * K + tid] = (int32_t)(A.get(tid) & IDX_MASK);
+      finish(A);
     } else {
       GlobalArena A{dst + first};
-      sort_prefix<NT>(A, sh, mk, fmx, N, K PROF_PASS);
-      if (tid < K) rank[(int64_t)row * K + tid] = (int32_t)(A.get(tid) & IDX_MASK);
+      sort_prefix<NT>(A, sh, mk, fmx, N, K, tailn PROF_PASS);
+      finish(A);
     }
     __syncthreads();
 #ifdef SSG_INTRO_PROF
     if (tid == 0) {
+#pragma unroll
+      for (int i_ = 0; i_ < 16; i_++) if (pacc_.a[i_]) atomicAdd(&g_prof[i_], pacc_.a[i_]);
+    }
+#endif
+  }
+}
+
+// One wave per row: the ranges the workgroup kernel handed over (at most tailn entries each, all inside [0, K + tailn)) are
+// partitioned / insertion-sorted / heapsorted exactly as wave 0 of the unsplit kernel would, on an LDS copy of the row's head.
+__global__ __launch_bounds__(64) void topk_introsort_tail_kernel(const uint32_t* __restrict__ tails, size_t tail_stride, const unsigned* __restrict__ rowmax,
+                                                                 int nrows, int K, int wcap, int32_t* __restrict__ rank) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Ctl* sh = reinterpret_cast<Ctl*>(smem);
+  Masks mk;
+  mk.L = reinterpret_cast<uint64_t*>(smem + ((sizeof(Ctl) + 15) & ~(size_t)15));
+  mk.R = mk.L + wcap;
+  mk.P = reinterpret_cast<uint32_t*>(mk.R + wcap);
+  uint32_t* ent = mk.P + wcap;
+  const int lane = lane_id();
+  for (int row = (int)blockIdx.x; row < nrows; row += (int)gridDim.x) {
+#ifdef SSG_INTRO_PROF
+    ProfAcc pacc_;
+#pragma unroll
+    for (int i_ = 0; i_ < 16; i_++) pacc_.a[i_] = 0;
+#endif
+    const uint32_t* trow = tails + (size_t)row * tail_stride;
+    const int nt = uni((int)trow[0]), hi = uni((int)trow[1]);
+    const float fmx = h2f((hbits)rowmax[row]);
+    for (int j = lane * 4; j < hi; j += 256) *reinterpret_cast<uint4*>(ent + j) = *reinterpret_cast<const uint4*>(trow + TAIL_HDR_WORDS + j);
+    for (int q = lane; q < 3 * nt; q += 64) sh->stack[q] = (int)trow[4 + q];
+    gsync<true>();
+    LdsArena A{ent};
+    sort_tail<64>(A, sh, mk, fmx, K, nt PROF_PASS);
+    if (lane < K) rank[(int64_t)row * K + lane] = (int32_t)(A.get(lane) & IDX_MASK);
+    gsync<true>();
+#ifdef SSG_INTRO_PROF
+    if (lane == 0) {
 #pragma unroll
       for (int i_ = 0; i_ < 16; i_++) if (pacc_.a[i_]) atomicAdd(&g_prof[i_], pacc_.a[i_]);
     }
@@ -563,12 +685,32 @@ __host__ inline size_t lds_fixed_bytes(int N) { return ((sizeof(Ctl) + 15) & ~(s
 __host__ inline bool fits_lds(int N) { return lds_fixed_bytes(N) + entry_words(N) * 4 <= LDS_LIMIT; }
 __host__ inline int arena_blocks(int nrows) { return nrows < 2048 ? nrows : 2048; }
 
+// split mode geometry: hand-over threshold (entries), record stride (32-bit words) and bytes of the hand-over records
+__host__ inline int tail_threshold() {
+  static int t = -1;
+  if (t < 0) { const char* e_ = getenv("SSG_INTRO_TAILN"); t = e_ ? atoi(e_) : 2048; if (t < 0) t = 0; if (t > 8192) t = 8192; }   // 0 = unsplit (round-2 kernel)
+  return t;
+}
+__host__ inline size_t tail_stride_words(int tailn) { return (size_t)TAIL_HDR_WORDS + (size_t)((64 + tailn + 3) & ~3); }
+__host__ inline size_t tail_bytes(int nrows) { const int t = tail_threshold(); return t > 0 ? (size_t)nrows * tail_stride_words(t) * 4 : 0; }
+
 template <bool LDS, int NT>
-__host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, uint32_t* arena, hipStream_t stream) {
+__host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, uint32_t* arena, uint32_t* tails, hipStream_t stream) {
   const size_t lds = lds_fixed_bytes(N) + (LDS ? entry_words(N) * 4 : 0);
+  const int tailn = tail_threshold();
   SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_introsort_kernel<LDS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((topk_introsort_kernel<LDS, NT>), dim3(LDS ? nrows : arena_blocks(nrows)), dim3(NT), lds, stream, D, rowmax, N, nrows, K,
-                     mask_words(N), arena, entry_words(N), rank);
+                     mask_words(N), arena, entry_words(N), rank, tailn, tails, tail_stride_words(tailn));
+  if (tailn > 0) {
+    SSG_LAUNCH_CHECK("topk_introsort_kernel");
+    const int head = 64 + tailn;                               // entries a row's tail can cover
+    const int wcap = mask_words(head);
+    const size_t tlds = ((sizeof(Ctl) + 15) & ~(size_t)15) + (size_t)wcap * (2 * sizeof(uint64_t) + sizeof(uint32_t)) + (size_t)((head + 3) & ~3) * 4;
+    if (tlds > 64 * 1024) SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_introsort_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds));
+    const int per_cu = (int)std::min<size_t>(32, LDS_LIMIT / tlds);
+    const int grid = std::min(nrows, 256 * (per_cu > 0 ? per_cu : 1));
+    hipLaunchKernelGGL(topk_introsort_tail_kernel, dim3(grid), dim3(64), tlds, stream, tails, tail_stride_words(tailn), rowmax, nrows, K, wcap, rank);
+  }
   return SSG_OK;
 }
 
@@ -577,12 +719,14 @@ __host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows,
 
 using namespace ssg;
 
+// workspace = [hand-over records of the tail kernel (split mode) | global arena (only when a row does not fit in LDS)]
 extern "C" size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows) {
   if (N <= 0 || nrows <= 0) return 0;
-  return (size_t)intro::arena_blocks(nrows) * intro::entry_words(N) * sizeof(uint32_t);
+  return intro::tail_bytes(nrows) + (size_t)intro::arena_blocks(nrows) * intro::entry_words(N) * sizeof(uint32_t);
 }
 extern "C" size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows) {
-  return (N > 0 && intro::fits_lds(N)) ? 0 : ssg_topk_rank_introsort_arena_bytes(N, nrows);
+  if (N <= 0 || nrows <= 0) return 0;
+  return intro::fits_lds(N) ? intro::tail_bytes(nrows) : ssg_topk_rank_introsort_arena_bytes(N, nrows);
 }
 
 extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws,
@@ -591,23 +735,26 @@ extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax
     ssg_set_error("ssg_topk_rank_introsort: need 0 < K <= min(64, N), 2 <= N <= 131072 (K=%d N=%d)", K, N);
     return SSG_ERR_INVALID;
   }
-  const bool arena = !intro::fits_lds(N) || (ws != nullptr && ws_bytes > 0 && ws_bytes >= ssg_topk_rank_introsort_arena_bytes(N, nrows));
+  const size_t tb = intro::tail_bytes(nrows), full = ssg_topk_rank_introsort_arena_bytes(N, nrows);
+  const bool arena = !intro::fits_lds(N) || (ws != nullptr && ws_bytes >= full);       // (a caller may force the arena path by passing its size)
+  const size_t need = arena ? full : tb;
+  if (need > 0 && (ws == nullptr || ws_bytes < need)) {
+    ssg_set_error("ssg_topk_rank_introsort: workspace of %zu bytes needed for N=%d, %d rows (got %zu): ssg_topk_rank_introsort_ws_bytes()", need, N, nrows, ws_bytes);
+    return SSG_ERR_INVALID;
+  }
+  uint32_t* tails = tb ? (uint32_t*)ws : nullptr;
+  uint32_t* ar = arena ? (uint32_t*)((unsigned char*)ws + tb) : nullptr;
   static int nt = -1;
   if (nt < 0) { const char* e_ = getenv("SSG_INTRO_NT"); nt = e_ ? atoi(e_) : 512; }
   int rc;
   if (!arena) {
-    rc = nt == 1024 ? intro::launch<true, 1024>(D, rowmax, N, nrows, K, rank, nullptr, stream)
-       : nt == 256 ? intro::launch<true, 256>(D, rowmax, N, nrows, K, rank, nullptr, stream)
-                   : intro::launch<true, 512>(D, rowmax, N, nrows, K, rank, nullptr, stream);
+    rc = nt == 1024 ? intro::launch<true, 1024>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream)
+       : nt == 256 ? intro::launch<true, 256>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream)
+                   : intro::launch<true, 512>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream);
   } else {
-    const size_t need = ssg_topk_rank_introsort_arena_bytes(N, nrows);
-    if (ws == nullptr || ws_bytes < need) {
-      ssg_set_error("ssg_topk_rank_introsort: workspace of %zu bytes needed for N=%d (got %zu)", need, N, ws_bytes);
-      return SSG_ERR_INVALID;
-    }
-    rc = nt == 1024 ? intro::launch<false, 1024>(D, rowmax, N, nrows, K, rank, (uint32_t*)ws, stream)
-       : nt == 256 ? intro::launch<false, 256>(D, rowmax, N, nrows, K, rank, (uint32_t*)ws, stream)
-                   : intro::launch<false, 512>(D, rowmax, N, nrows, K, rank, (uint32_t*)ws, stream);
+    rc = nt == 1024 ? intro::launch<false, 1024>(D, rowmax, N, nrows, K, rank, ar, tails, stream)
+       : nt == 256 ? intro::launch<false, 256>(D, rowmax, N, nrows, K, rank, ar, tails, stream)
+                   : intro::launch<false, 512>(D, rowmax, N, nrows, K, rank, ar, tails, stream);
   }
   if (rc) return rc;
   SSG_LAUNCH_CHECK("topk_introsort_kernel");

@@ -459,6 +459,51 @@ def test_conv_split_half_vs_fp64(cfg, L, dev):
     assert (outp - dec).abs().max().item() <= 2.0 ** -21 * scale
 
 
+@pytest.mark.parametrize("cfg", [
+    (400, 16, 8, 256, 256, 3, 1, 1, False),        # layer3 3x3: 256 x 256 tiles (four LDS stages), K = 2304: 144 k-tiles
+    (400, 16, 8, 1024, 256, 1, 1, 0, False),       # layer3 conv1: K = 1024 streamed from HBM
+    (420, 16, 8, 96, 256, 3, 1, 1, False),         # K = 864: 54 k-tiles, two left over after the four-stage rounds; ragged last tile (M = 53 760)
+    (400, 16, 8, 256, 1024, 1, 1, 0, True),        # conv3 + residual: 128 x 256 tiles (three stages) at this size
+])
+def test_conv_tile_shapes_agree_bitwise(cfg, L, dev):
+    """The tile shape is a launch-time choice (conv.hip launch_conv_wide: 256 x 256 tiles with four LDS stages when at least 200
+    of them exist, 128 x 256 / 128 x 128 tiles with three stages below that); every output element's reduction order is the same
+    in all of them, so a large batch (tall tiles) must equal the same images run in small batches (short tiles) bit for bit.  The
+    parity tests against the reference model use a handful of images and never reach the tall tiles."""
+    from ssg_amd._lib import check, ptr, stream
+    from ssg_amd.resnet import _h8l8, _weight_scale, pack_weight_khwc
+    B, H, W, Cin, Cout, k, stride, pad, use_res = cfg
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    wk = pack_weight_khwc(w.permute(0, 2, 3, 1))
+    sc = _weight_scale(wk)
+    ws = _h8l8(wk * sc).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    xs = torch.empty_like(x); check(L.ssg_h8l8_encode(ptr(x), ptr(xs), x.numel(), 1.0, stream()), "enc")
+    OH = (H + 2 * pad - k) // stride + 1; OW = (W + 2 * pad - k) // stride + 1
+    rs = None
+    if use_res:
+        r = torch.randn(B, OH, OW, Cout, generator=g).to(dev)
+        rs = torch.empty_like(r); check(L.ssg_h8l8_encode(ptr(r), ptr(rs), r.numel(), 1.0, stream()), "enc")
+
+    def run(lo, hi):
+        out = torch.empty(hi - lo, OH, OW, Cout, device=dev)
+        check(L.ssg_conv2d_nhwc_x(ptr(xs[lo:hi]), ptr(ws), ptr(bias), ptr(rs[lo:hi]) if use_res else None, ptr(out), hi - lo, H, W, Cin, Cout, k, k, stride, pad, 1, 3,
+                                  1.0 / sc, None, None, stream()), "convx")
+        return out
+    big = run(0, B)
+    small = torch.cat([run(lo, min(lo + 64, B)) for lo in range(0, B, 64)], 0)
+    assert torch.equal(big.view(torch.int32), small.view(torch.int32))
+    # and the values are right: fp64 convolution of a few images
+    dec = torch.empty_like(big[:2]); check(L.ssg_h8l8_decode(ptr(big[:2].contiguous()), ptr(dec), dec.numel(), 1.0, stream()), "dec")
+    ref = torch.nn.functional.conv2d(x[:2].cpu().permute(0, 3, 1, 2).double(), w.double(), bias.cpu().double(), stride, pad)
+    if use_res:
+        ref = ref + r[:2].cpu().permute(0, 3, 1, 2).double()
+    ref = torch.relu(ref)
+    assert (dec.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("precision", ["split", "f32"])
 def test_embedding_vs_reference_golden(golden, dev, precision):
     """HIP ResNet-50 embed (orig + flip, L2 norm) vs the real reference model's features.
