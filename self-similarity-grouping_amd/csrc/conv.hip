@@ -652,13 +652,18 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   // instructions per wave) and then publishes it.  The compiler's own tracking of the DMA -> LDS-array dependencies stays in
   // force for the fragment reads (separate __shared__ arrays per stage).
   // (NS stages: NS - 1 tiles in flight, the wait leaves the NS - 2 newest tiles' DMAs outstanding)
+  // lgkmcnt(0) belongs to the protocol: the barrier also tells the other waves "I am done READING the stage you overwrite next",
+  // and hipcc sinks the (register-only) MFMAs of the previous tile -- and with them the lgkmcnt waits for its fragment reads --
+  // below this asm statement.  Without the wait a wave passed the barrier with fragment reads still queued in the LDS pipeline,
+  // and under load another wave's DMA overwrote the stage first: a few wrong 16-byte chunks (hi or lo halves of a later k-tile) in
+  // about two output tiles per 1600 -- found in round 3 by the tile-shape equality test, present since the kernel was written.
 #define SSG_PUBLISH()                                                                                              \
   { constexpr int OUTST = (ABLK + WBLK) * (NS - 2);                                                                \
-    if (OUTST == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");                                  \
-    else if (OUTST == 6) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");                             \
-    else if (OUTST == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");                             \
-    else if (OUTST == 3) asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");                             \
-    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); }
+    if (OUTST == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                                  \
+    else if (OUTST == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");                             \
+    else if (OUTST == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");                             \
+    else if (OUTST == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");                             \
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
   static_assert((ABLK + WBLK) * (NS - 2) == 8 || (ABLK + WBLK) * (NS - 2) == 6 || (ABLK + WBLK) * (NS - 2) == 4 || (ABLK + WBLK) * (NS - 2) == 3 ||
                 (ABLK + WBLK) * (NS - 2) == 2, "vmcnt literal for this tile shape");
   SSG_DMA_NEXT(st0)
@@ -698,9 +703,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
       SSG_MMA(st3)
     }
   }
-  if (nk - nfull >= 1) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st0) }
-  if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
-  if constexpr (NS == 4) { if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st2) } }
+  if (nk - nfull >= 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st0) }
+  if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
+  if constexpr (NS == 4) { if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st2) } }
   __syncthreads();                        // drains the (clamped, redundant) tail DMAs before the stages become epilogue patches
 #undef SSG_PUBLISH
 #undef SSG_DMA_NEXT

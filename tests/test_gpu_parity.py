@@ -929,3 +929,28 @@ def test_eps_rule_paths_agree_with_numpy(case, dev, monkeypatch):
         monkeypatch.setenv("SSG_EPS_PATH", path)
         eps, cnt, top = cluster.eps_rule(M, rho)
         assert (eps, cnt, top) == (float(ref[0]), ref[1], ref[2]), (case, path)
+
+
+def test_conv_dma_kernel_is_deterministic(L, dev):
+    """Race screen for the LDS-DMA pipeline of conv_dma_kernel (counted vmcnt + raw s_barrier): the same launch repeated must give
+    the same bits, on the shape and tile (conv3 + residual, 128 x 256 tiles, two workgroups per CU) that exposed a missing
+    lgkmcnt(0) before the barrier in round 3 (two wrong output tiles in 1600 per launch)."""
+    from ssg_amd._lib import check, ptr, stream
+    from ssg_amd.resnet import _h8l8, _weight_scale, pack_weight_khwc
+    B, H, W, Cin, Cout = 400, 16, 8, 256, 1024
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5
+    wk = pack_weight_khwc(w.permute(0, 2, 3, 1)); sc = _weight_scale(wk); ws = _h8l8(wk * sc).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    xs = torch.empty_like(x); check(L.ssg_h8l8_encode(ptr(x), ptr(xs), x.numel(), 1.0, stream()), "enc")
+    zs = torch.zeros(B, H, W, Cout, device=dev)
+
+    def run(res):
+        out = torch.empty(B, H, W, Cout, device=dev)
+        check(L.ssg_conv2d_nhwc_x(ptr(xs), ptr(ws), ptr(bias), ptr(res), ptr(out), B, H, W, Cin, Cout, 1, 1, 1, 0, 1, 3, 1.0 / sc, None, None, stream()), "convx")
+        return out
+    ref = run(None)
+    for rep in range(12):
+        assert torch.equal(run(zs).view(torch.int32), ref.view(torch.int32)), "launch %d with a zero residual differs from the launch without one" % rep
+        assert torch.equal(run(None).view(torch.int32), ref.view(torch.int32)), rep
