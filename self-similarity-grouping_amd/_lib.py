@@ -10,7 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "ssg_hip.h")
-SO_PATH = os.path.join(_HERE, "libssg_hip.so")
+SO_PATH = os.environ.get("SSG_LIB_PATH") or os.path.join(_HERE, "libssg_hip.so")     # SSG_LIB_PATH: A/B builds of the same ABI (development)
 
 _SCALARS = {
     "int": ctypes.c_int, "double": ctypes.c_double, "uint64_t": ctypes.c_uint64, "int64_t": ctypes.c_int64,

@@ -666,10 +666,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
   static_assert((ABLK + WBLK) * (NS - 2) == 8 || (ABLK + WBLK) * (NS - 2) == 6 || (ABLK + WBLK) * (NS - 2) == 4 || (ABLK + WBLK) * (NS - 2) == 3 ||
                 (ABLK + WBLK) * (NS - 2) == 2, "vmcnt literal for this tile shape");
+  // BPOS > 0 (three-product kernels): the publishing barrier sits INSIDE a tile's multiply -- after its first (BPOS = 1) or second
+  // (BPOS = 2) group of four MFMAs, when the hardware has consumed every fragment of the tile anyway, so lgkmcnt(0) costs nothing and the
+  // remaining MFMAs of the tile are still queued behind the barrier: the matrix pipe has work while the next tile's fragment reads are
+  // in flight (with the barrier in front of the whole multiply every wave of the CU read LDS at the same time and the pipes drained).
+  // All NS stages are in flight ahead of the first tile; the DMA of tile t + NS goes into the stage of tile t right after the barrier.
+#ifndef SSG_DMA_BPOS
+#define SSG_DMA_BPOS 2
+#endif
+  constexpr int BPOS = ONEPROD ? 0 : SSG_DMA_BPOS;
+  constexpr int TDMA = ABLK + WBLK;                                  // DMA instructions per wave and tile
+  const int nfull = nk / NS * NS;
+  if constexpr (BPOS == 0) {
   SSG_DMA_NEXT(st0)
   SSG_DMA_NEXT(st1)
   if constexpr (NS == 4) SSG_DMA_NEXT(st2)
-  const int nfull = nk / NS * NS;
   for (int kt = 0; kt < nfull; kt += NS) {   // tile t lives in stage array t % NS; no exits inside (they doubled the accumulators)
     if constexpr (NS == 3) {
       SSG_PUBLISH();                        // tile kt landed in st0 for every wave; everybody is done reading st2 (tile kt-1)
@@ -706,6 +717,55 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   if (nk - nfull >= 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st0) }
   if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
   if constexpr (NS == 4) { if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st2) } }
+  } else {
+    v8h fah[MT], fal[MT], fbh[NT], fbl[NT];
+#define SSG_READS(ST)                                                                                                \
+    { _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                               \
+        fah[i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offh); fal[i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offl); } \
+      _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                               \
+        fbh[j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offh); fbl[j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offl); } }
+#define SSG_G1 { _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)      \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[j], fal[i], acc[i][j], 0, 0, 0); }
+#define SSG_G2 { _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)      \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[j], fah[i], acc[i][j], 0, 0, 0); }
+#define SSG_G3 { _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)      \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[j], fah[i], acc[i][j], 0, 0, 0); }
+    // one tile: fragments, the first MFMA groups, publish (tile t + 1 landed for everybody, everybody done reading this stage),
+    // refill this stage with tile t + NS, the rest of the multiply
+#define SSG_STEP(ST)                                                                                                 \
+    { SSG_READS(ST)                                                                                                  \
+      SSG_G1                                                                                                         \
+      if constexpr (BPOS == 2) SSG_G2                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TDMA * (NS - 2)) : "memory");                  \
+      SSG_DMA_NEXT(ST)                                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      if constexpr (BPOS == 1) SSG_G2                                                                                \
+      SSG_G3 }
+#define SSG_LAST(ST) { SSG_READS(ST) SSG_G1 SSG_G2 SSG_G3 }
+    SSG_DMA_NEXT(st0)
+    SSG_DMA_NEXT(st1)
+    SSG_DMA_NEXT(st2)
+    if constexpr (NS == 4) SSG_DMA_NEXT(st3)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TDMA * (NS - 1)) : "memory");     // tile 0 landed for everybody
+    for (int kt = 0; kt < nfull; kt += NS) {
+      SSG_STEP(st0)
+      SSG_STEP(st1)
+      SSG_STEP(st2)
+      if constexpr (NS == 4) SSG_STEP(st3)
+    }
+    // left-over tiles (nk % NS): the last publish of the loop covered tile nfull; the refills of the last steps re-fetched the
+    // clamped last tile into stages nobody reads again
+    if (nk - nfull >= 1) SSG_LAST(st0)
+    if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_LAST(st1) }
+    if constexpr (NS == 4) { if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_LAST(st2) } }
+#undef SSG_READS
+#undef SSG_G1
+#undef SSG_G2
+#undef SSG_G3
+#undef SSG_STEP
+#undef SSG_LAST
+  }
   __syncthreads();                        // drains the (clamped, redundant) tail DMAs before the stages become epilogue patches
 #undef SSG_PUBLISH
 #undef SSG_DMA_NEXT
