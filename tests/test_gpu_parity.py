@@ -834,7 +834,7 @@ def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkey
     """ssg_stem_pool_nchw_x (image -> conv1 + bn + relu -> maxpool in one launch) and ssg_bottleneck[_ds]_nhwc_x (a whole layer1
     block in one launch) against the launch-per-layer path they replace: same k-steps, product order and epilogues, so the
     layer4 map must be bit-identical.  H = 104: ragged last strip of the stem, layer1 / layer2 heights 26 / 13 have no fused block
-    kernel (fall back per block); H = 96: short images, layer2 height 12 falls back, layer1 height 24 is fused."""
+    kernel (fall back per block); H = 96: short images, layer1 height 24 is fused, layer2 height 12 falls back (fused too with SSG_BNECK2=1)."""
     import ssg_amd
     from ssg_amd import _lib
     m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=5).cuda().eval()
@@ -842,7 +842,7 @@ def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkey
     L = _lib.lib()
     assert L.ssg_stem_pool_supported(H, 128) == 1 and L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64) == (1 if (H // 4) % 4 == 0 else 0)
     assert L.ssg_bottleneck_supported(H // 4, 32, 64, 256, 64) == L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64)
-    assert L.ssg_bottleneck_supported(32, 16, 512, 512, 128) == 1 and L.ssg_bottleneck_supported(28, 16, 512, 512, 128) == 0   # layer2 identity blocks: 8-row tiles
+    assert L.ssg_bottleneck_supported(32, 16, 512, 512, 128) == 1 and L.ssg_bottleneck_supported(26, 16, 512, 512, 128) == 0   # layer2 identity blocks: 8-row tiles (4-row tiles with SSG_BNECK2=1)
     assert L.ssg_bottleneck_supported(16, 8, 1024, 1024, 256) == 0        # layer3 / layer4: separate launches
     maps = {}
     for stem, bneck in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
