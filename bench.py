@@ -38,6 +38,47 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec
 FLOP_PER_IMAGE = 10.68e9      # 2 forwards x 2 x 2.669 GMAC (SURVEY.md 8a a4)
 
 
+def build_fingerprint():
+    """sha256 of the kernel sources the HIP library is built from (csrc/*.hip, *.h, include/ssg_hip.h): ties a PMC traffic summary
+    under profiles/ to the build it was taken on -- bench.py refuses a summary of another build instead of quoting stale bytes"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "self-similarity-grouping_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ssg_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class SyncCounter:
+    """counts the blocking device -> host reads (Tensor.item / tolist / cpu / numpy on a CUDA tensor) inside a `with` block: the host
+    round trips of the grouping leg (VERDICT r2 #7)"""
+
+    def __init__(self):
+        self.n = 0
+
+    def __enter__(self):
+        self._orig = {k: getattr(torch.Tensor, k) for k in ("item", "tolist", "cpu")}
+        me = self
+
+        def wrap(name):
+            fn = self._orig[name]
+
+            def counted(t, *a, **kw):
+                if t.is_cuda:
+                    me.n += 1
+                return fn(t, *a, **kw)
+            return counted
+        for k in self._orig:
+            setattr(torch.Tensor, k, wrap(k))
+        return self
+
+    def __exit__(self, *exc):
+        for k, fn in self._orig.items():
+            setattr(torch.Tensor, k, fn)
+
+
 class KernelTimer:
     """HIP-event timing of individual C-ABI launches on the stream they are launched on."""
 
@@ -101,6 +142,13 @@ def cpu_baseline(args, src, tgt, gpu_labels, gpu_eps):
     t_cl = time.time() - t0
     del final
     img_s = args.cpu_images / t_embed
+    # SURVEY.md 8d also asks for the reference's own CPU-runnable size, BASELINE configs[0]: N = 2 000 (no re-rank: pairwise L2 + eps + DBSCAN;
+    # and the full re-rank for comparison), measured
+    n2k = min(2000, tgt.shape[0]); ns2k = min(2000, src.shape[0])
+    t0 = time.time(); e2k, _ = ora.re_ranking(src[:ns2k], tgt[:n2k], no_rerank=True); ee, _, _ = ora.eps_rule(e2k, args.rho); ora.dbscan(e2k, ee, 4); t_2k_plain = time.time() - t0
+    t0 = time.time(); _, f2k = ora.re_ranking(src[:ns2k], tgt[:n2k], k1=20, k2=6, lambda_value=args.lambda_value); ee, _, _ = ora.eps_rule(f2k, args.rho); ora.dbscan(f2k, ee, 4)
+    t_2k_rr = time.time() - t0
+    del e2k, f2k
     full = n == args.N and ns == args.Ns
     scale = 1.0 if full else (args.N * (args.N + args.Ns)) / float(n * (n + ns))      # N*(N+Ns)*d cost model only when a smaller N was asked for
     est_iter = (args.N + args.Ns) / img_s + (t_rr + t_cl) * scale
@@ -111,7 +159,10 @@ def cpu_baseline(args, src, tgt, gpu_labels, gpu_eps):
                         "" if full else " (extrapolated to N=%d,Ns=%d by N*(N+Ns))" % (args.N, args.Ns), avail),
            "embed_images_per_s": round(img_s, 3), "rerank_s_measured": round(t_rr, 3), "eps_dbscan_s_measured": round(t_cl, 3),
            "rerank_dbscan_s_measured": round(t_rr + t_cl, 3), "rerank_dbscan_N": n, "rerank_dbscan_Ns": ns, "grouping_extrapolated": not full,
-           "threads_embed": best_t, "threads_grouping": best_o, "cores_visible": avail}
+           "threads_embed": best_t, "threads_grouping": best_o, "cores_visible": avail,
+           "n2000": {"what": "BASELINE configs[0] size on the same threads: N=%d, Ns=%d, d=2048 grouping only (the embedding of 2 000 + 2 000 images at the rate above: %.0f s)"
+                             % (n2k, ns2k, (n2k + ns2k) / img_s),
+                     "l2_eps_dbscan_s": round(t_2k_plain, 3), "rerank_eps_dbscan_s": round(t_2k_rr, 3)}}
     if full:
         out["labels_equal_gpu"] = bool(np.array_equal(lab, gpu_labels)) and float(eps) == float(gpu_eps)
     return out
@@ -265,6 +316,19 @@ def main():
                                           "noise": int((l_o < 0).sum()), "eps": e_o}
         del so, to
 
+    # host round trips of one grouping leg (re-rank + eps rule + DBSCAN), counted on an extra untimed pass
+    with SyncCounter() as sc:
+        h_ = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
+                                      row0=row0, nrows=nrows, group=group)
+        n_rr = sc.n
+        e_, _, _ = cluster.eps_rule(h_, args.rho)
+        n_eps = sc.n - n_rr
+        cluster.DBSCAN(eps=e_, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h_)
+        n_db = sc.n - n_rr - n_eps
+    del h_
+    host_syncs = {"rerank": n_rr, "eps_rule": n_eps, "dbscan": n_db, "per_split": n_rr + n_eps + n_db,
+                  "what": "blocking device->host reads (item/tolist/cpu) of one grouping leg: value ranges of the features + longest sparse row (re-rank), "
+                          "candidate count + eps (eps rule), labels + edge count (DBSCAN)"}
     if rank != 0:
         return
     n_img = args.N + args.Ns
@@ -292,8 +356,11 @@ def main():
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, collected on this
     # kernel set at the same batch size); null when the configuration differs from the profiled one
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_conv_traffic.json")))
-        if split and pm["batch"] == args.batch and pm["launches_per_forward"] == n_conv_per_fwd:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_conv_traffic.json")))
+        fresh = pm.get("build") == build_fingerprint()
+        if not fresh:
+            roof["traffic_note"] = "profiles/r03_pmc_conv_traffic.json was taken on another build (%s, this one is %s): not quoted" % (pm.get("build"), build_fingerprint())
+        if fresh and split and pm["batch"] == args.batch and pm["launches_per_forward"] == n_conv_per_fwd:
             per = (pm["fetch_bytes_per_forward"] + pm["write_bytes_per_forward"]) / pm["launches_per_forward"]
             roof["traffic"] = round(per)
             roof["traffic_note"] = ("HBM bytes per conv launch (average over the %d launches of a forward, batch %d) from %s; algorithmic %.0f"
@@ -373,7 +440,7 @@ def main():
         "embed_images_per_s": round(n_img / (t_embed * 1e-3), 1), "embed_ms": round(t_embed, 2),
         "rerank_dbscan_s_per_iter": round((t_rerank + t_cluster) * 1e-3, 5), "rerank_ms": round(t_rerank, 3), "eps_dbscan_ms": round(t_cluster, 3),
         "labels": {"clusters": int(labels.max() + 1), "noise": int((labels < 0).sum()), "eps": eps},
-        "rank_mode": rerank.default_rank_mode(),
+        "rank_mode": rerank.default_rank_mode(), "host_syncs": host_syncs, "build": build_fingerprint(),
         "roofline": roof, "roofline_kernels": hbm,
         "roofline_k5_k12": {"bound": "hbm", "achieved": round(k5_12, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k5_12 / PEAK_HBM_GBS, 4),
                             "algorithmic": "8*N^2 bytes per split over all K5..K12 kernel time (SURVEY.md 8d); K5 = the introsort replay "

@@ -603,6 +603,25 @@ def test_pairwise_distance_dropin(dev):
     assert got_self.shape == (70, 70) and (got_self - ref_self).abs().max() < 2e-5
 
 
+def test_pairwise_distance_vs_reference_golden(golden, dev):
+    """a11 against the REFERENCE's own output (tests/golden/pairwise.npz, generated by tools/make_golden.py from
+    reid/evaluators.py:63-85 as shipped, float32 torch on the CPU): query x gallery branch and features-only branch, unit-norm
+    200-d features and un-normalised 2048-d ones.  Tolerance: float32 GEMM accumulation order, 2e-5 relative to the largest distance."""
+    from collections import OrderedDict
+    import ssg_amd
+    g = golden("pairwise.npz")
+    for tag in ("u", "r"):
+        F = torch.from_numpy(g["feats_" + tag]); n = F.shape[0]; nq, g0 = int(g["nq_" + tag]), int(g["g0_" + tag])
+        feats = OrderedDict(("f%03d" % i, F[i]) for i in range(n))
+        query = [("f%03d" % i, 0, 0) for i in range(0, nq)]
+        gallery = [("f%03d" % i, 0, 0) for i in range(g0, n)]
+        qg = ssg_amd.pairwise_distance(feats, query, gallery).numpy()
+        full = ssg_amd.pairwise_distance(feats).numpy()
+        tol = 2e-5 * max(1.0, float(np.abs(g["self_" + tag]).max()))
+        assert qg.shape == g["qg_" + tag].shape and np.abs(qg - g["qg_" + tag]).max() < tol, tag
+        assert full.shape == g["self_" + tag].shape and np.abs(full - g["self_" + tag]).max() < tol, tag
+
+
 def test_x2_branch_matches_torch(dev):
     """resnet.py:112-117 feat -> feat_bn -> relu on the pooled feature (HIP GEMM with folded BN)."""
     import ssg_amd

@@ -231,6 +231,36 @@ def eval_fixture():
     return ok
 
 
+def pairwise_fixture():
+    """reid/evaluators.py:63-85 pairwise_distance (float32 torch on the CPU) called as shipped: the query x gallery branch
+    (:74-85, deprecated positional addmm_) and the features-only branch (:64-72) on unit-norm and on un-normalised features."""
+    import contextlib
+    import io
+    import warnings
+    from collections import OrderedDict
+    import torch
+    reid = import_reid()
+    import reid.evaluators as rev
+    rec = {}
+    for tag, n, d, unit, seed in (("u", 70, 200, True, 3), ("r", 45, 2048, False, 4)):
+        g = torch.Generator().manual_seed(seed)
+        feats = OrderedDict()
+        for i in range(n):
+            f = torch.randn(d, generator=g) * (1.0 if unit else 0.3)
+            feats["f%03d" % i] = f / f.norm() if unit else f
+        query = [("f%03d" % i, 0, 0) for i in range(0, n // 2)]
+        gallery = [("f%03d" % i, 0, 0) for i in range(n // 3, n)]
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+            warnings.simplefilter("ignore")
+            qg = rev.pairwise_distance(feats, query, gallery).numpy()
+            full = rev.pairwise_distance(feats).numpy()
+        rec.update({"feats_" + tag: torch.stack(list(feats.values())).numpy(), "nq_" + tag: np.int32(n // 2), "g0_" + tag: np.int32(n // 3),
+                    "qg_" + tag: qg, "self_" + tag: full})
+        print("pairwise %s: n=%d d=%d  qg %r self %r (reference outputs stored)" % (tag, n, d, qg.shape, full.shape))
+    np.savez_compressed(os.path.join(OUT, "pairwise.npz"), **rec)
+    return True
+
+
 def plain_fixture():
     """reid/rerank_plain.py re_ranking (kNN-set Jaccard variant): oracle restatement vs the reference."""
     import contextlib
@@ -389,6 +419,10 @@ def main():
         ok = preprocess_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
         sys.exit(0 if ok else 1)
+    if "--only-pairwise" in sys.argv:     # regenerate just tests/golden/pairwise.npz
+        ok = pairwise_fixture()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     if "--only-eval" in sys.argv:         # regenerate just tests/golden/eval_cases.npz
         ok = eval_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
@@ -509,6 +543,7 @@ def main():
     ok = init_fixture(mod) and ok
     ok = embed_fixture() and ok
     ok = eval_fixture() and ok
+    ok = pairwise_fixture() and ok
     ok = plain_fixture() and ok
     print("ALL OK" if ok else "ORACLE MISMATCH")
     sys.exit(0 if ok else 1)

@@ -55,7 +55,19 @@ def embed_rate(n_images, num_split, batch=512):
 def main():
     from conftest import clustered
     dev = torch.device("cuda", 0)
-    which = sys.argv[1:] or ["1", "2", "3", "4"]
+    which = sys.argv[1:] or ["0", "1", "2", "3", "4"]
+    if "0" in which:
+        # BASELINE configs[0]: N = 2 000 Track-I images (N(0,1) pixels) through the whole selftraining.py chain on the GPU: extract_features ->
+        # no-rerank pairwise L2 -> eps rule -> DBSCAN (the reference runs this configuration on the CPU; tests/test_gpu_chain.py checks it against the oracle)
+        import ssg_amd
+        g = torch.Generator(device=dev).manual_seed(1)
+        imgs = torch.randn(2000, 3, 256, 128, generator=g, device=dev)
+        m = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1, pretrained=False).cuda().eval()
+        ssg_amd.extract_embeddings(m, ssg_amd.TensorBatchLoader(imgs[:500], 500))
+        t0 = sync(); feats, _, _ = ssg_amd.extract_embeddings(m, ssg_amd.TensorBatchLoader(imgs, 1000)); t1 = sync()
+        print(json.dumps({"config": 0, "what": "N=2000 Track-I images: HIP embed -> pairwise L2 (half) -> eps -> DBSCAN, no re-rank", "embed_s": round(t1 - t0, 4),
+                          "embed_img_s": round(2000 / (t1 - t0), 1), **group(feats[:500].contiguous(), feats, 0.1, 1.6e-3, no_rerank=True)}), flush=True)
+        del imgs, feats, m
     if "1" in which or "2" in which:
         tgt = torch.from_numpy(clustered(16000, 2048, 1)).to(dev); src = torch.from_numpy(clustered(12936, 2048, 2, intra=0.7)).to(dev)
         es, rate = embed_rate(16000 + 12936, 1)
