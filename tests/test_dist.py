@@ -84,7 +84,7 @@ def _gpu_worker(rank, world, port, q, N, Ns, d):
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     g = dist.group.WORLD
     Ns, d = Ns, d
-    nsplit = 3 if N < 10000 else 1
+    nsplit = 3
     tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(nsplit)]
     srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(nsplit)]
     lo, hi = sd.shard_bounds(N, rank, world)
@@ -107,15 +107,15 @@ def _gpu_worker(rank, world, port, q, N, Ns, d):
 @pytest.mark.parametrize("world,N", [(2, 1536), (8, 1531), (8, 30003)])
 def test_sharded_pipeline_matches_unsharded(world, N):
     """compute_dist -> generate_selflabel, 3 feature splits, rows sharded over `world` processes (gloo; they share the
-    test box's single GPU) with ragged row blocks (1531 = 8*191 + 3; 30003 = BASELINE configs[3]'s MSMT17-size problem, one split
-    over 8 ranks, with a non-divisible N): eps, labels and every local block of the distance matrix bit-identical to the
+    test box's single GPU) with ragged row blocks (1531 = 8*191 + 3; 30003 = BASELINE configs[3]'s MSMT17-size problem, three
+    splits over 8 ranks, with a non-divisible N): eps, labels and every local block of the distance matrix bit-identical to the
     unsharded run.  (The 8-GPU RCCL leg itself is the driver's; this is the same code over gloo.)"""
     from types import SimpleNamespace
     from ssg_amd import compute_dist, generate_selflabel
     from ssg_amd.dist import shard_bounds
     Ns, d = (640, 96) if N < 10000 else (4000, 128)
     dev = torch.device("cuda", 0)
-    nsplit = 3 if N < 10000 else 1           # the MSMT-size case: one split, re-rank mode (keeps the 8 processes on one GPU short)
+    nsplit = 3                               # whole / upper / lower feature sets (BASELINE configs[3]); the MSMT-size case runs the re-rank mode only
     modes = (("rerank", False), ("norerank", True)) if N < 10000 else (("rerank", False),)
     tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(nsplit)]
     srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(nsplit)]
@@ -300,3 +300,60 @@ def test_nccl_backend_world1_smoke():
     out = q.get(timeout=600)
     p.join(120)
     assert out == {"rerank": True, "norerank": True, "extract": True, "gathers": True}, out
+
+
+def _footprint_worker(rank, world, port, q, N, Ns, d):
+    import hashlib
+    import torch.distributed as dist
+    from ssg_amd import rerank, cluster
+    from ssg_amd import dist as sd
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    g = dist.group.WORLD
+    tgt = torch.from_numpy(clustered(N, d, 31)).to(dev); src = torch.from_numpy(clustered(Ns, d, 32, intra=0.7)).to(dev)
+    lo, hi = sd.shard_bounds(N, rank, world)
+    torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    h = rerank.re_ranking_device(src, tgt, lambda_value=0.1, row0=lo, nrows=hi - lo, group=g, keep_euclid=False)
+    eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
+    lab = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    held = h.M.numel() * h.M.element_size()
+    q.put((rank, float(eps), int(cnt), hashlib.sha256(lab.tobytes()).hexdigest(), int(peak), int(held), tuple(h.M.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config4_sharded_footprint_and_result():
+    """BASELINE configs[4]: N = 128 000 row-block-sharded over 8 ranks (here: 8 processes on the test box's one GPU, gloo).  Asserted,
+    not assumed: a rank holds a 16 000 x 128 000 block of J' (4.1 GB) and, while the re-rank runs, the same block of D -- the peak
+    of a rank's allocations stays below 8.2 GB + the sparse tables and the ranking hand-over records (the dense
+    matrices are never gathered); eps, the element count and the labels equal the unsharded run's."""
+    import hashlib
+    from ssg_amd import rerank, cluster
+    from ssg_amd.dist import shard_bounds
+    N, Ns, d, world = 128000, 2000, 256, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_footprint_worker, args=(r, world, port, q, N, Ns, d)) for r in range(world)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=1500) for _ in range(world))
+    [p.join(120) for p in procs]
+    dev = torch.device("cuda", 0)
+    tgt = torch.from_numpy(clustered(N, d, 31)).to(dev); src = torch.from_numpy(clustered(Ns, d, 32, intra=0.7)).to(dev)
+    h = rerank.re_ranking_device(src, tgt, lambda_value=0.1, keep_euclid=False)
+    eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
+    lab = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h)
+    want = hashlib.sha256(lab.tobytes()).hexdigest()
+    block = 2.0 * (N // world) * N                     # bytes of one half row block
+    for r, e, c, hsh, peak, held, shape in res:
+        lo, hi = shard_bounds(N, r, world)
+        assert shape == (hi - lo, N) and held == 2 * (hi - lo) * N
+        assert (e, c, hsh) == (float(eps), int(cnt), want), "rank %d result differs from the unsharded run" % r
+        assert peak < 2 * block + 2.5e9, "rank %d peak allocation %.2f GB (two half row blocks are %.2f GB)" % (r, peak / 1e9, 2 * block / 1e9)
+    print("configs[4] sharded over 8 ranks: peak allocation per rank %.2f .. %.2f GB (D + J' row blocks: %.2f GB)" % (
+        min(x[4] for x in res) / 1e9, max(x[4] for x in res) / 1e9, 2 * block / 1e9))
