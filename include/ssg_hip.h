@@ -310,6 +310,22 @@ int ssg_rerank_init_jaccard(const float* D, const float* rowmax, const int32_t* 
 int ssg_preprocess_u8(const uint8_t* src, int B, int h, int w, int H, int W, const int32_t* xmin, const int32_t* xcnt, const int32_t* xk,
                       int xksize, const int32_t* ymin, const int32_t* ycnt, const int32_t* yk, int yksize, const float* mean3_host,
                       const float* std3_host, uint8_t* tmp, float* out, ssg_stream_t stream);
+/* Decode half of reid/utils/data/preprocessor.py:22-30 (`Image.open(fpath).convert('RGB')` = Pillow -> libjpeg-turbo, default
+ * parameters) for a batch of baseline / extended-sequential Huffman JPEG files, bit-exact: Huffman decode (one thread per restart
+ * segment), dequantisation + islow integer inverse DCT, fancy chroma upsampling (h2v1 / h2v2), YCbCr -> RGB.  The host parses the
+ * marker segments and builds the tables (ssg_amd/jpeg.py):
+ *   ecs   entropy-coded bytes of all files back to back, >= 32 zero bytes of padding behind them
+ *   segs  int64 [nseg][5] per restart segment: image, byte offset into ecs, byte length, first MCU, MCU count
+ *   imgs  int64 [nimg][32] per image: W, H, components (1 | 3), luma sampling h, v, MCUs per row, MCU rows, byte offset into out, then
+ *         8 words per component: first block in coef, blocks per row, block rows, byte offset into planes, plane pitch, quantisation
+ *         table index, DC table index, AC table index
+ *   look [ntab][256] uint16 ((length << 8) | symbol of every code of at most 8 bits, 0 otherwise), maxcode [ntab][18], valoff [ntab][17],
+ *   vals [ntab][256]: jdhuff.c's derived tables; qts [nqt][64] uint16 in natural order
+ *   coef  workspace int16 [total_blocks][64] (zeroed by the call), planes workspace uint8 (sum of 64 * blocks), max_blocks / max_pixels =
+ *         largest component (in blocks) / image (in pixels) of the batch; out: RGB bytes, H * W * 3 per image at its offset. */
+int ssg_jpeg_decode_batch(const uint8_t* ecs, const int64_t* segs, int nseg, const int64_t* imgs, int nimg, const uint16_t* look,
+                          const int32_t* maxcode, const int32_t* valoff, const uint8_t* vals, const uint16_t* qts, int16_t* coef,
+                          int64_t total_blocks, int max_blocks, uint8_t* planes, int max_pixels, uint8_t* out, ssg_stream_t stream);
 /* x = sqrt(max(x, lo)) in place: with ssg_pairwise_sqdist_f32 the pairwise block of the fine-tune phase's TripletLoss
  * (reid/loss/triplet.py:28-31: dist = (|x|^2 + |x|^2' - 2 x x').clamp(min=1e-12).sqrt()) */
 int ssg_clamp_sqrt_f32(float* x, int64_t n, float lo, ssg_stream_t stream);

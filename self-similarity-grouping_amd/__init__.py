@@ -34,6 +34,9 @@ def __getattr__(name):   # lazy: torch import only when the compute surface is t
     if name in ("Preprocessor", "GpuBatchLoader", "preprocess_batch"):
         from . import preprocessor
         return getattr(preprocessor, name)
+    if name == "decode_jpeg_batch":
+        from . import jpeg
+        return jpeg.decode_batch
     if name == "triplet_pairwise_dist":
         from . import triplet
         return triplet.pairwise_dist

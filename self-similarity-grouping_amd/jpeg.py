@@ -1,0 +1,231 @@
+"""JPEG decode on the GPU for the extraction loaders -- the decode half of reid/utils/data/preprocessor.py:22-30
+(`Image.open(fpath).convert('RGB')`, done by Pillow / libjpeg-turbo on the CPU in the reference's DataLoader workers).
+
+`decode_batch(files)` takes the raw bytes of a batch of image files and returns one uint8 CUDA tensor [H, W, 3] per file whose
+bytes equal `np.asarray(Image.open(...).convert('RGB'))`:
+
+* the host walks the marker segments of every file (quantisation / Huffman tables, frame and scan headers, restart interval,
+  the position of the entropy-coded data) -- a few hundred bytes of bookkeeping per file;
+* `ssg_jpeg_decode_batch` (csrc/jpeg.hip) does the work: Huffman decode, integer inverse DCT, fancy chroma upsampling,
+  YCbCr -> RGB, restated from libjpeg's published algorithms (bit-exact);
+* files outside the supported class (progressive, arithmetic coding, 12 bit, CMYK / Adobe RGB, sampling factors other than
+  1x1 / 2x1 / 2x2, PNG or anything else that is not a JPEG) are decoded by Pillow on the host exactly like the reference does,
+  and uploaded; `stats` counts them.
+"""
+import struct
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+IMG_WORDS, SEG_WORDS = 32, 5
+_ZZ = np.array([0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63])
+stats = {"gpu": 0, "pillow": 0}
+
+
+class NotBaseline(ValueError):
+    """the file is left to Pillow"""
+
+
+class _Header(object):
+    __slots__ = ("width", "height", "comps", "qt", "dc", "ac", "scan", "ri", "ecs_start", "ecs_end")
+
+
+def scan_header(buf):
+    """marker walk of one file -> _Header (raises NotBaseline for anything the GPU decoder does not take)"""
+    mv = memoryview(buf)
+    n = len(mv)
+    if n < 4 or mv[0] != 0xFF or mv[1] != 0xD8:
+        raise NotBaseline("not a JPEG")
+    h = _Header()
+    h.qt, h.dc, h.ac, h.ri, h.comps, h.scan = {}, {}, {}, 0, None, None
+    adobe = None
+    p = 2
+    while True:
+        while p < n and mv[p] != 0xFF:
+            p += 1
+        while p < n and mv[p] == 0xFF:
+            p += 1
+        if p >= n:
+            raise NotBaseline("no scan")
+        marker = mv[p]; p += 1
+        if marker == 0x01 or 0xD0 <= marker <= 0xD8:
+            continue
+        if marker == 0xD9 or p + 2 > n:
+            raise NotBaseline("no scan")
+        (length,) = struct.unpack_from(">H", mv, p)
+        body = bytes(mv[p + 2:p + length])
+        p += length
+        if marker == 0xDB:                                   # DQT
+            q = 0
+            while q < len(body):
+                prec, tid = body[q] >> 4, body[q] & 15
+                q += 1
+                if prec:
+                    vals = struct.unpack_from(">64H", body, q); q += 128
+                else:
+                    vals = body[q:q + 64]; q += 64
+                nat = np.zeros(64, np.uint16)
+                nat[_ZZ] = np.frombuffer(bytes(vals), np.uint8) if not prec else np.asarray(vals, np.uint16)
+                h.qt[tid] = nat
+        elif marker == 0xC4:                                 # DHT
+            q = 0
+            while q < len(body):
+                cls, tid = body[q] >> 4, body[q] & 15
+                counts = body[q + 1:q + 17]
+                total = sum(counts)
+                (h.ac if cls else h.dc)[tid] = (bytes(counts), bytes(body[q + 17:q + 17 + total]))
+                q += 17 + total
+        elif marker in (0xC0, 0xC1):                         # baseline / extended sequential, Huffman
+            if body[0] != 8:
+                raise NotBaseline("%d-bit samples" % body[0])
+            h.height, h.width = struct.unpack_from(">HH", body, 1)
+            h.comps = [(body[6 + 3 * i], body[7 + 3 * i] >> 4, body[7 + 3 * i] & 15, body[8 + 3 * i]) for i in range(body[5])]
+        elif 0xC2 <= marker <= 0xCF and marker not in (0xC4, 0xC8, 0xCC):
+            raise NotBaseline("SOF%d" % (marker - 0xC0))
+        elif marker == 0xDD:
+            (h.ri,) = struct.unpack_from(">H", body, 0)
+        elif marker == 0xEE and body[:5] == b"Adobe" and len(body) >= 12:
+            adobe = body[11]
+        elif marker == 0xDA:                                 # SOS: must be the single scan of a sequential file
+            if h.comps is None:
+                raise NotBaseline("scan before frame")
+            ns = body[0]
+            ids = [c[0] for c in h.comps]
+            try:
+                h.scan = [(ids.index(body[1 + 2 * i]), body[2 + 2 * i] >> 4, body[2 + 2 * i] & 15) for i in range(ns)]
+            except ValueError:
+                raise NotBaseline("scan component")
+            if ns != len(h.comps) or body[1 + 2 * ns] != 0 or body[2 + 2 * ns] != 63 or [s[0] for s in h.scan] != list(range(ns)):
+                raise NotBaseline("not one interleaved full scan")
+            h.ecs_start = p
+            break
+    ncomp = len(h.comps)
+    if ncomp == 3:
+        if adobe not in (None, 1) or h.comps[1][1:3] != (1, 1) or h.comps[2][1:3] != (1, 1) or h.comps[0][1:3] not in ((1, 1), (2, 1), (2, 2)):
+            raise NotBaseline("colour transform / sampling factors")
+    elif ncomp == 1:
+        h.comps = [(h.comps[0][0], 1, 1, h.comps[0][3])]
+    else:
+        raise NotBaseline("%d components" % ncomp)
+    if h.width == 0 or h.height == 0 or any(c[3] not in h.qt for c in h.comps) or any(s[1] not in h.dc or s[2] not in h.ac for s in h.scan):
+        raise NotBaseline("missing table")
+    # end of the entropy-coded data: the first marker that is neither a stuffed zero nor RSTn
+    b = bytes(mv[h.ecs_start:])
+    q = 0
+    while True:
+        q = b.find(b"\xff", q)
+        if q < 0 or q + 1 >= len(b):
+            q = len(b)
+            break
+        if b[q + 1] == 0 or 0xD0 <= b[q + 1] <= 0xD7:
+            q += 2
+            continue
+        break
+    h.ecs_end = h.ecs_start + q
+    return h
+
+
+def _derived(counts, symbols):
+    """jdhuff.c jpeg_make_d_derived_tbl -> (look[256] uint16, maxcode[18] int32, valoff[17] int32, vals[256] uint8)"""
+    look = np.zeros(256, np.uint16); maxcode = np.full(18, -1, np.int32); valoff = np.zeros(17, np.int32); vals = np.zeros(256, np.uint8)
+    vals[:len(symbols)] = np.frombuffer(symbols, np.uint8)
+    code, p = 0, 0
+    for length in range(1, 17):
+        cnt = counts[length - 1]
+        if cnt:
+            valoff[length] = p - code
+            if length <= 8:
+                for i in range(cnt):
+                    first = (code + i) << (8 - length)
+                    look[first:first + (1 << (8 - length))] = (length << 8) | symbols[p + i]
+            code += cnt; p += cnt
+            maxcode[length] = code - 1
+        code <<= 1
+    maxcode[17] = 0xFFFFF
+    return look, maxcode, valoff, vals
+
+
+def _pillow_rgb(data):
+    import io
+    from PIL import Image
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def decode_batch(files, device=None):
+    """list of file contents (bytes) -> list of uint8 CUDA tensors [H, W, 3] (RGB), one per file, in order"""
+    import re
+    L = _lib.lib()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = [None] * len(files)
+    hdrs = []
+    for i, data in enumerate(files):
+        try:
+            hdrs.append((i, scan_header(data)))
+        except NotBaseline:
+            out[i] = torch.from_numpy(np.array(_pillow_rgb(data))).to(device)
+            stats["pillow"] += 1
+    if not hdrs:
+        return out
+    huff, huff_ids, qts, qt_ids = [], {}, [], {}
+
+    def huff_id(spec):
+        if spec not in huff_ids:
+            huff_ids[spec] = len(huff); huff.append(_derived(spec[0], spec[1]))
+        return huff_ids[spec]
+
+    def qt_id(q):
+        key = q.tobytes()
+        if key not in qt_ids:
+            qt_ids[key] = len(qts); qts.append(q)
+        return qt_ids[key]
+    imgs = np.zeros((len(hdrs), IMG_WORDS), np.int64)
+    segs, chunks = [], []
+    ecs_off = blocks = plane_off = out_off = 0
+    max_blocks = max_pixels = 0
+    rst = re.compile(b"\xff[\xd0-\xd7]")
+    for k, (i, h) in enumerate(hdrs):
+        hs, vs = h.comps[0][1], h.comps[0][2]
+        mcux = (h.width + 8 * hs - 1) // (8 * hs); mcuy = (h.height + 8 * vs - 1) // (8 * vs)
+        imgs[k, :8] = (h.width, h.height, len(h.comps), hs, vs, mcux, mcuy, out_off)
+        for ci, (cid, ch, cv, tq) in enumerate(h.comps):
+            bw, bh = mcux * ch, mcuy * cv
+            _, td, ta = h.scan[ci]
+            imgs[k, 8 + 8 * ci:16 + 8 * ci] = (blocks, bw, bh, plane_off, bw * 8, qt_id(h.qt[tq]), huff_id(h.dc[td]), huff_id(h.ac[ta]))
+            blocks += bw * bh; plane_off += bw * bh * 64
+            max_blocks = max(max_blocks, bw * bh)
+        out_off += h.width * h.height * 3
+        max_pixels = max(max_pixels, h.width * h.height)
+        ecs = bytes(files[i][h.ecs_start:h.ecs_end])
+        nmcu = mcux * mcuy
+        ri = h.ri or nmcu
+        start, m0 = 0, 0
+        for mt in rst.finditer(ecs):
+            # (a 0xFF byte of the compressed data is always followed by 0x00, so 0xFF 0xDn can only be a restart marker)
+            segs.append((k, ecs_off + start, mt.start() - start, m0, min(ri, nmcu - m0)))
+            start = mt.end(); m0 += ri
+            if m0 >= nmcu:
+                break
+        if m0 < nmcu:
+            segs.append((k, ecs_off + start, len(ecs) - start, m0, min(ri, nmcu - m0)))
+        chunks.append(ecs)
+        ecs_off += len(ecs)
+    pool = np.frombuffer(b"".join(chunks) + bytes(64), np.uint8)
+    segs = np.asarray(segs, np.int64).reshape(-1, SEG_WORDS)
+    look = np.stack([t[0] for t in huff]); maxcode = np.stack([t[1] for t in huff]); valoff = np.stack([t[2] for t in huff]); vals = np.stack([t[3] for t in huff])
+    d = lambda a: torch.from_numpy(np.array(a)).to(device)
+    pool_d, segs_d, imgs_d = d(pool), d(segs), d(imgs)
+    look_d, maxcode_d, valoff_d, vals_d, qts_d = d(look), d(maxcode), d(valoff), d(vals), d(np.stack(qts))
+    coef = torch.empty(blocks * 64, dtype=torch.int16, device=device)
+    planes = torch.empty(max(plane_off, 1), dtype=torch.uint8, device=device)
+    rgb = torch.empty(out_off, dtype=torch.uint8, device=device)
+    check(L.ssg_jpeg_decode_batch(ptr(pool_d), ptr(segs_d), int(segs.shape[0]), ptr(imgs_d), len(hdrs), ptr(look_d), ptr(maxcode_d), ptr(valoff_d), ptr(vals_d),
+                                  ptr(qts_d), ptr(coef), blocks, max_blocks, ptr(planes), max_pixels, ptr(rgb), stream()), "ssg_jpeg_decode_batch")
+    for k, (i, h) in enumerate(hdrs):
+        o = int(imgs[k, 7])
+        out[i] = rgb[o:o + h.width * h.height * 3].view(h.height, h.width, 3)
+    stats["gpu"] += len(hdrs)
+    return out

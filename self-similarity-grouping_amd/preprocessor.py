@@ -84,10 +84,11 @@ class Preprocessor(object):
     """reid/utils/data/preprocessor.py:7-30 with the decode only: items are `(uint8 HWC RGB array, fname, pid, camid)`; the
     transform the reference applies per item runs batched on the GPU (`preprocess_batch` / `GpuBatchLoader`)."""
 
-    def __init__(self, dataset, root=None, transform=None):
+    def __init__(self, dataset, root=None, transform=None, raw=False):
         if transform is not None:
             raise ValueError("the transform (Resize + ToTensor + Normalize, selftraining.py:43-47) runs on the GPU: pass height/width to GpuBatchLoader")
         self.dataset, self.root, self.transform = dataset, root, None
+        self.raw = raw          # True: items carry the file's bytes (decoded on the GPU by GpuBatchLoader) instead of Pillow's decoded array
 
     def __len__(self):
         return len(self.dataset)
@@ -101,6 +102,9 @@ class Preprocessor(object):
         from PIL import Image
         fname, pid, camid = self.dataset[index]
         fpath = fname if self.root is None else osp.join(self.root, fname)
+        if self.raw:
+            with open(fpath, "rb") as f:
+                return f.read(), fname, pid, camid
         img = np.asarray(Image.open(fpath).convert('RGB'))
         return img, fname, pid, camid
 
@@ -110,8 +114,15 @@ class GpuBatchLoader(object):
     selftraining.py:49-53: yields `(imgs [B,3,H,W] float32 CUDA, fnames, pids, camids)` in dataset order.  Images of a
     batch that share a size go through one kernel launch pair (Market-1501: all 128x64)."""
 
-    def __init__(self, dataset, root=None, height=256, width=128, batch_size=128, mean=MEAN, std=STD, device=None):
-        self.items = dataset if isinstance(dataset, Preprocessor) else Preprocessor(dataset, root)
+    def __init__(self, dataset, root=None, height=256, width=128, batch_size=128, mean=MEAN, std=STD, device=None, decode="gpu"):
+        # decode='gpu': the files' bytes go to the device and are decoded there (ssg_amd.jpeg: baseline JPEG bit-exact with Pillow; anything
+        # else falls back to Pillow per file); decode='pillow': every file is decoded on the host like the reference does
+        if decode not in ("gpu", "pillow"):
+            raise ValueError("decode must be 'gpu' or 'pillow'")
+        self.decode = decode
+        self.items = dataset if isinstance(dataset, Preprocessor) else Preprocessor(dataset, root, raw=(decode == "gpu"))
+        if isinstance(dataset, Preprocessor):
+            self.decode = "gpu" if dataset.raw else "pillow"
         self.height, self.width, self.batch_size, self.mean, self.std, self.device = height, width, batch_size, mean, std, device
 
         self.first, self.count = 0, len(self.items)
@@ -136,11 +147,16 @@ class GpuBatchLoader(object):
             recs = [self.items[i] for i in range(b0, min(n, b0 + self.batch_size))]
             dev = torch.device("cuda", torch.cuda.current_device()) if self.device is None else torch.device(self.device)
             out = torch.empty((len(recs), 3, self.height, self.width), dtype=torch.float32, device=dev)
+            if self.decode == "gpu":
+                from .jpeg import decode_batch
+                pix = decode_batch([r[0] for r in recs], dev)          # uint8 CUDA [H, W, 3] per file
+            else:
+                pix = [r[0] for r in recs]
             by_size = {}
-            for j, r in enumerate(recs):
-                by_size.setdefault(r[0].shape[:2], []).append(j)
+            for j, a in enumerate(pix):
+                by_size.setdefault(tuple(a.shape[:2]), []).append(j)
             for _, js in by_size.items():
-                batch = np.stack([recs[j][0] for j in js])
+                batch = torch.stack([pix[j] for j in js]) if self.decode == "gpu" else np.stack([pix[j] for j in js])
                 res = preprocess_batch(batch, self.height, self.width, self.mean, self.std, dev)
                 out[torch.as_tensor(js, device=dev)] = res
             yield out, [r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs]

@@ -973,3 +973,57 @@ def test_conv_dma_kernel_is_deterministic(L, dev):
     for rep in range(12):
         assert torch.equal(run(zs).view(torch.int32), ref.view(torch.int32)), "launch %d with a zero residual differs from the launch without one" % rep
         assert torch.equal(run(None).view(torch.int32), ref.view(torch.int32)), rep
+
+
+# ------------------------------------------------------------------ JPEG decode on the GPU
+def test_jpeg_decode_vs_pillow_golden(golden, dev):
+    """csrc/jpeg.hip through ssg_amd.jpeg.decode_batch: the committed files (written and decoded by Pillow, the reference's codec:
+    preprocessor.py:28) come back with exactly Pillow's bytes -- 4:4:4 / 4:2:2 / 4:2:0, grayscale, restart intervals, optimised
+    Huffman tables, odd sizes -- decoded as ONE batch; the progressive file of the fixture takes the Pillow fallback."""
+    from ssg_amd import jpeg as pj
+    g = golden("jpeg_cases.npz")
+    n = int(g["count"])
+    files = [g["file_%02d" % i].tobytes() for i in range(n)] + [g["progressive_file"].tobytes()]
+    before = dict(pj.stats)
+    out = pj.decode_batch(files)
+    assert pj.stats["gpu"] - before["gpu"] == n and pj.stats["pillow"] - before["pillow"] == 1
+    for i in range(n):
+        assert out[i].dtype == torch.uint8 and out[i].is_cuda
+        assert np.array_equal(out[i].cpu().numpy(), g["rgb_%02d" % i]), i
+    assert np.array_equal(out[n].cpu().numpy(), g["progressive_rgb"])
+
+
+def test_jpeg_decode_generated_files_and_loader(dev, ora, tmp_path):
+    """Freshly generated files (Pillow as the checker at run time) in one batch of mixed sizes and layouts, and the extraction
+    loader end to end: GpuBatchLoader(decode='gpu') == GpuBatchLoader(decode='pillow') bit for bit on files on disk."""
+    import io
+    from PIL import Image
+    import ssg_amd
+    from ssg_amd import jpeg as pj
+    rng = np.random.default_rng(9)
+    files, refs = [], []
+    for k in range(40):
+        h, w = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.stack([xx * 255.0 / max(w - 1, 1), yy * 255.0 / max(h - 1, 1), (xx + yy) * 127.0 / max(h + w - 2, 1)], -1) + rng.normal(0, 25, (h, w, 3))
+        kw = dict(quality=int(rng.integers(25, 99)), subsampling=int(rng.integers(0, 3)), optimize=bool(rng.integers(0, 2)))
+        if rng.integers(0, 3) == 0:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 6))
+        buf = io.BytesIO(); Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(buf, "JPEG", **kw)
+        files.append(buf.getvalue()); refs.append(np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB")))
+    out = pj.decode_batch(files)
+    for k in range(40):
+        assert np.array_equal(out[k].cpu().numpy(), refs[k]), (k, refs[k].shape)
+    # the loader: Market-1501-like 128 x 64 files plus a few other sizes and one PNG (Pillow fallback inside the GPU path)
+    names = []
+    for k in range(11):
+        h, w = (128, 64) if k < 8 else (int(rng.integers(60, 200)), int(rng.integers(30, 100)))
+        a = np.clip(rng.normal(120, 50, (h, w, 3)), 0, 255).astype(np.uint8)
+        name = "img%02d.%s" % (k, "png" if k == 10 else "jpg")
+        Image.fromarray(a).save(str(tmp_path / name), quality=85) if k != 10 else Image.fromarray(a).save(str(tmp_path / name))
+        names.append((name, k % 3, 0))
+    got = list(ssg_amd.GpuBatchLoader(names, root=str(tmp_path), height=256, width=128, batch_size=4, decode="gpu"))
+    ref = list(ssg_amd.GpuBatchLoader(names, root=str(tmp_path), height=256, width=128, batch_size=4, decode="pillow"))
+    assert len(got) == len(ref) == 3
+    for (a, fa, pa, _), (b, fb, pb, _) in zip(got, ref):
+        assert fa == fb and pa == pb and torch.equal(a, b)

@@ -206,3 +206,64 @@ def test_parallel_partition_model_matches_introsort(ora):
         ref = np.argsort(key.view(np.float16))[:64]
         assert np.array_equal(ora.argsort_half(key.view(np.float16))[:64], ref)
         assert np.array_equal(argsort_topk(key, 64), ref)
+
+
+# ------------------------------------------------------------------ JPEG decode (the decode half of preprocessor.py:28)
+def _random_jpeg(rng, h, w, kind, **kw):
+    import io
+    from PIL import Image
+    if kind == 0:
+        a = rng.integers(0, 256, (h, w, 3))
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.stack([xx * 255.0 / max(w - 1, 1), yy * 255.0 / max(h - 1, 1), (xx + yy) * 127.0 / max(h + w - 2, 1)], -1) + rng.normal(0, 9, (h, w, 3))
+    buf = io.BytesIO(); Image.fromarray(np.clip(a, 0, 255).astype(np.uint8)).save(buf, "JPEG", **kw)
+    data = buf.getvalue()
+    return data, np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def test_jpeg_oracle_vs_golden_and_pillow(golden):
+    """oracle/jpeg_oracle.py (numpy restatement of libjpeg's default decompression) == the committed Pillow outputs, and == Pillow
+    itself on freshly generated files (sizes that are not MCU multiples, all three chroma layouts, restart intervals)."""
+    from oracle import jpeg_oracle
+    g = golden("jpeg_cases.npz")
+    for i in range(int(g["count"])):
+        assert np.array_equal(jpeg_oracle.decode(g["file_%02d" % i].tobytes()), g["rgb_%02d" % i]), i
+    with pytest.raises(jpeg_oracle.Unsupported):
+        jpeg_oracle.decode(g["progressive_file"].tobytes())
+    rng = np.random.default_rng(5)
+    for h, w in ((16, 16), (23, 41), (9, 70)):
+        for ss in (0, 1, 2):
+            for extra in ({}, {"restart_marker_blocks": 2}, {"optimize": True}):
+                data, ref = _random_jpeg(rng, h, w, int(rng.integers(0, 2)), quality=int(rng.integers(30, 96)), subsampling=ss, **extra)
+                assert np.array_equal(jpeg_oracle.decode(data), ref), (h, w, ss, extra)
+
+
+def test_jpeg_host_parser_matches_oracle(golden):
+    """ssg_amd/jpeg.py's marker walk (product host code, no GPU needed) agrees with the oracle's independent parser on geometry,
+    tables and the extent of the entropy-coded data; its derived Huffman tables decode every code of the file's DHT segments; files
+    outside the supported class are refused (they go to Pillow in the product)."""
+    from oracle import jpeg_oracle
+    from ssg_amd import jpeg as pj
+    g = golden("jpeg_cases.npz")
+    for i in range(int(g["count"])):
+        data = g["file_%02d" % i].tobytes()
+        h = pj.scan_header(data); o = jpeg_oracle.parse(data)
+        assert (h.width, h.height, h.ri) == (o["width"], o["height"], o["restart_interval"])
+        assert [tuple(c) for c in h.comps] == [tuple(c) for c in o["comps"]] and h.scan == o["scan"]
+        assert data[h.ecs_start:h.ecs_end] == o["ecs"]
+        for tid, q in h.qt.items():
+            assert np.array_equal(q.astype(np.int32), o["qt"][tid])
+        for spec in list(h.dc.values()) + list(h.ac.values()):
+            look, maxcode, valoff, vals = pj._derived(spec[0], spec[1])
+            code, p = 0, 0
+            for length in range(1, 17):
+                for _ in range(spec[0][length - 1]):
+                    if length <= 8:
+                        assert look[code << (8 - length)] == ((length << 8) | spec[1][p])
+                    assert code <= maxcode[length] and vals[code + valoff[length]] == spec[1][p]
+                    code += 1; p += 1
+                code <<= 1
+    for bad in (g["progressive_file"].tobytes(), b"\x89PNG\r\n\x1a\n" + bytes(32), b""):
+        with pytest.raises(pj.NotBaseline):
+            pj.scan_header(bad)

@@ -261,6 +261,54 @@ def pairwise_fixture():
     return True
 
 
+def jpeg_fixture():
+    """Decode half of the input side (reid/utils/data/preprocessor.py:28 `Image.open(fpath).convert('RGB')`): small JPEG files
+    written with Pillow (the reference's own codec: baseline Huffman, 4:4:4 / 4:2:2 / 4:2:0, grayscale, restart markers,
+    optimised Huffman tables, odd sizes, a Market-1501-sized 128 x 64 image) and the pixels Pillow decodes from them.  The
+    fixture stores file bytes + expected RGB arrays; oracle/jpeg_oracle.py must reproduce every one of them."""
+    import io
+    from PIL import Image
+    from oracle import jpeg_oracle
+    rng = np.random.default_rng(77)
+    rec, ok, n = {}, True, 0
+
+    def picture(h, w, kind):
+        if kind == 0:
+            a = rng.integers(0, 256, (h, w, 3))
+        elif kind == 1:
+            yy, xx = np.mgrid[0:h, 0:w]
+            a = np.stack([xx * 255.0 / max(w - 1, 1), yy * 255.0 / max(h - 1, 1), (xx + yy) * 127.0 / max(h + w - 2, 1)], -1) + rng.normal(0, 6, (h, w, 3))
+        else:
+            a = np.kron(rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8, 3)), np.ones((8, 8, 1)))[:h, :w] + rng.normal(0, 20, (h, w, 3))
+        return np.clip(a, 0, 255).astype(np.uint8)
+    cases = [(128, 64, 1, 75, 2, 0, False, False), (128, 64, 2, 90, 2, 0, False, False), (37, 53, 0, 60, 2, 0, False, False), (17, 9, 1, 85, 1, 0, False, False),
+             (64, 33, 2, 95, 0, 0, False, False), (31, 64, 1, 40, 2, 3, False, False), (100, 7, 2, 75, 1, 2, False, False), (5, 3, 0, 75, 2, 0, False, False),
+             (48, 40, 1, 80, 2, 0, True, False), (40, 24, 1, 85, 0, 0, False, True), (1, 1, 0, 75, 2, 0, False, False), (200, 100, 2, 70, 2, 5, True, False)]
+    for h, w, kind, q, ss, ri, opt, gray in cases:
+        a = picture(h, w, kind)
+        if gray:
+            a = a[:, :, 0]
+        kw = dict(quality=q, optimize=opt)
+        if not gray:
+            kw["subsampling"] = ss
+        if ri:
+            kw["restart_marker_blocks"] = ri
+        buf = io.BytesIO(); Image.fromarray(a).save(buf, "JPEG", **kw)
+        data = buf.getvalue()
+        ref = np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+        good = np.array_equal(jpeg_oracle.decode(data), ref)
+        ok = ok and good
+        rec["file_%02d" % n] = np.frombuffer(data, np.uint8); rec["rgb_%02d" % n] = ref
+        print("jpeg %02d: %dx%d q=%d subsampling=%d restart=%d optimize=%s gray=%s  %d bytes  oracle==Pillow: %s" % (n, h, w, q, ss, ri, opt, gray, len(data), good))
+        n += 1
+    # a progressive file: outside the GPU decoder's class (the product leaves it to Pillow); the expected pixels are still Pillow's
+    buf = io.BytesIO(); Image.fromarray(picture(40, 40, 1)).save(buf, "JPEG", quality=80, progressive=True)
+    rec["progressive_file"] = np.frombuffer(buf.getvalue(), np.uint8); rec["progressive_rgb"] = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))
+    rec["count"] = np.int32(n)
+    np.savez_compressed(os.path.join(OUT, "jpeg_cases.npz"), **rec)
+    return ok
+
+
 def plain_fixture():
     """reid/rerank_plain.py re_ranking (kNN-set Jaccard variant): oracle restatement vs the reference."""
     import contextlib
@@ -419,6 +467,10 @@ def main():
         ok = preprocess_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
         sys.exit(0 if ok else 1)
+    if "--only-jpeg" in sys.argv:         # regenerate just tests/golden/jpeg_cases.npz
+        ok = jpeg_fixture()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     if "--only-pairwise" in sys.argv:     # regenerate just tests/golden/pairwise.npz
         ok = pairwise_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
@@ -544,6 +596,7 @@ def main():
     ok = embed_fixture() and ok
     ok = eval_fixture() and ok
     ok = pairwise_fixture() and ok
+    ok = jpeg_fixture() and ok
     ok = plain_fixture() and ok
     print("ALL OK" if ok else "ORACLE MISMATCH")
     sys.exit(0 if ok else 1)
