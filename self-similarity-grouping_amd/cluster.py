@@ -91,7 +91,12 @@ def _eps_rule_sampled(L, h, rho, st):
     buf = torch.empty(n_cap, dtype=torch.int64, device=dev)
     cursor = torch.zeros(2, dtype=torch.int64, device=dev)
     check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
-    got, zeros, thr_bits = torch.cat([cursor, thr3[:1]]).tolist()       # host round trip 1
+    pend = h.take_pending() if hasattr(h, "take_pending") else None    # the re-rank's status words ride along with this read-back
+    vals = torch.cat([cursor, thr3[:1]] + ([pend.to(torch.int64)] if pend is not None else [])).tolist()       # host round trip 1
+    got, zeros, thr_bits = vals[:3]
+    if pend is not None:
+        h.resolve_pending(vals[3:5])
+        h.validate()
     thr = float(np.uint32(thr_bits & 0xFFFFFFFF).view(np.float32))
     overflow = int(got > n_cap)
     if h.group is not None:             # the accept / fall-back decision must be the same on every rank
@@ -133,11 +138,11 @@ def eps_rule(X, rho):
     L = _lib.lib()
     h = as_handle(X)
     dev, st = h.device, stream()
-    h.validate()
     if os.environ.get("SSG_EPS_PATH", "sampled") == "sampled" and float(rho) > 0 and h.N >= 64:
-        r = _eps_rule_sampled(L, h, float(rho), st)
+        r = _eps_rule_sampled(L, h, float(rho), st)      # (validates the handle with its first read-back)
         if r is not None:
             return r
+    h.validate()
     args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
     prefix, below, count, top = 0, 0, None, None
     key_max = None

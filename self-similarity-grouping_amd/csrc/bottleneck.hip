@@ -62,24 +62,32 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int C, int MID, int IW, int TH, int CIN = C, int NW = 4>
 struct Cfg {
   static constexpr int HROWS = TH + 2, NPIX1 = HROWS * IW, NPIX = TH * IW;
-  static constexpr int NTHR = NW * 64, RPP = NTHR / 4;  // 64-byte k-tile rows staged per pass of the workgroup
-  static constexpr int XROWS = (NPIX1 + RPP - 1) / RPP * RPP;      // x rows of a phase-1 stage, padded to whole passes (the padding loads return zeros)
+  static constexpr int NTHR = NW * 64, RPP = NTHR / 4;  // 64-byte k-tile rows staged per pass of the workgroup (phase 3)
+  // phase-1 k-tiles: 16 channels (64-byte row pieces) or, for the 8-wave layer2 kernel, 32 channels (whole 128-byte lines, half the
+  // load -> LDS -> barrier -> fragment round trips: a step costs ~1250 cycles in those round trips alone, whatever it multiplies)
+#ifndef SSG_BN_K1T
+#define SSG_BN_K1T 32
+#endif
+  static constexpr int K1T = NW == 8 ? SSG_BN_K1T : 16, KS1 = K1T / 16, CPR1 = 4 * KS1, RPP1 = NTHR / CPR1;
+  static constexpr int XROWS = (NPIX1 + RPP1 - 1) / RPP1 * RPP1;   // x rows of a phase-1 stage, padded to whole passes (the padding loads return zeros)
   static constexpr int P1 = 80;                        // LDS pitch of a 64-byte k-tile row (pitch/16 odd: conflict-free b128)
+  static constexpr int P1T = K1T * 4 + 16;             // ... of a phase-1 row (80 or 144 bytes)
   static constexpr int KT2 = NW == 8 ? 2 : 1;          // 32-channel (chunk, tap) k-tiles of conv2 per LDS stage: the 8-wave workgroup (alone on its CU) halves its barriers
   static constexpr int P2 = KT2 * 128 + 16;            // ... of a phase-2 stage row (KT2 x 128 bytes of a W2 row)
   static constexpr int PY = MID * 4 + 16;              // ... of a y1 / y2 pixel row (all MID channels, h8l8)
-  static constexpr int BUF1 = (XROWS + MID) * P1;      // phase-1 stage: x rows, then W1 rows
+  static constexpr int BUF1 = (XROWS + MID) * P1T;     // phase-1 stage: x rows, then W1 rows
   static constexpr int ZERO_OFF = NPIX1 * PY;          // one all-zero pixel row (conv2's left / right padding)
   static constexpr int W2_OFF = (ZERO_OFF + PY + 255) / 256 * 256, BUF2 = MID * P2;
   static constexpr int W3_OFF = (NPIX * PY + 255) / 256 * 256, BUF3 = C * P1;
   static constexpr int LDS = cmax(cmax(2 * BUF1, W2_OFF + 2 * BUF2), W3_OFF + 2 * BUF3);
   static constexpr int DS = CIN != C;                  // downsample variant: conv3's reduction is [y2 | x]
-  static constexpr int NK1 = CIN / 16, NK2 = (MID / 32) * 9 / KT2, NK3 = (MID + (DS ? CIN : 0)) / 16;
+  static constexpr int NK1 = CIN / K1T, NK2 = (MID / 32) * 9 / KT2, NK3 = (MID + (DS ? CIN : 0)) / 16;
   // stages of global loads in flight ahead of the multiply (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)
-  static constexpr int PD1 = NK1 < 8 ? NK1 : 8, PD2 = KT2 == 1 ? 6 : 3;
+  static constexpr int PD1MAX = K1T == 64 ? 2 : (K1T == 32 ? 4 : 8);
+  static constexpr int PD1 = NK1 < PD1MAX ? NK1 : PD1MAX, PD2 = KT2 == 1 ? 6 : 3;
   static_assert(((MID / 32) * 9) % KT2 == 0 && NK2 % PD2 == 0, "phase-2 stages and ring");
-  static_assert((NW == 4 || NW == 8) && NPIX == 128 && NPIX1 % 32 == 0 && MID % RPP == 0 && C % RPP == 0 && MID % (NW * 8) == 0, "128 output pixels, whole staging passes");
-  static_assert(2 * BUF1 <= ZERO_OFF, "the zero row is written while phase 1 runs");
+  static_assert((NW == 4 || NW == 8) && NPIX == 128 && NPIX1 % 32 == 0 && MID % RPP == 0 && MID % RPP1 == 0 && C % RPP == 0 && MID % (NW * 8) == 0, "128 output pixels, whole staging passes");
+  static constexpr bool ZERO_EARLY = 2 * BUF1 <= ZERO_OFF;   // the zero row is written while phase 1 runs -- unless the (32-channel) stages cover it
   static_assert(LDS <= (NW == 4 ? 80 : 160) * 1024, "4 waves: two workgroups per CU; 8 waves: one");
   static_assert(NW == 4 || NW * 32 * 36 * 4 <= 2 * BUF3, "8 waves: the epilogue patches take over the W3 stages");
 };
@@ -122,34 +130,35 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
   }
   const int img = T / tiles_img, ty0 = (T - img * tiles_img) * TH;
   SSG_BN_STAMP(0)
-  if (tid < K::PY / 16) *reinterpret_cast<uint4*>(smem + K::ZERO_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+  if (K::ZERO_EARLY && tid < K::PY / 16) *reinterpret_cast<uint4*>(smem + K::ZERO_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
 
   // =========================== phase 1: y1 = relu(conv1(x)) on the TH+2 halo rows ===========================
-  constexpr int RPP = K::RPP, AU = K::XROWS / RPP, WU = MID / RPP;   // 16-byte pieces per thread and k-tile: x rows, W1 rows
-  const int ck = tid & 3, r0 = tid >> 2;
+  constexpr int RPP = K::RPP, RPP1 = K::RPP1, AU = K::XROWS / RPP1, WU = MID / RPP1;   // 16-byte pieces per thread and k-tile: x rows, W1 rows
+  const int ck = tid & 3, r0 = tid >> 2;               // phase 3 staging (64-byte rows)
+  const int ck1 = tid % K::CPR1, r1 = tid / K::CPR1;   // phase 1 staging (64- or 128-byte rows)
   const float* ximg = p.x + (int64_t)img * p.H * IW * CIN;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (unsigned)(p.H * IW * CIN * 4), 0x00020000);
   unsigned aoff[AU];
 #pragma unroll
   for (int u = 0; u < AU; u++) {
-    const int hp = r0 + RPP * u, pix = (ty0 - 1) * IW + hp;  // rows above / below the image (and the padding rows of the stage): out-of-range offset -> the load returns zeros
-    aoff[u] = (hp < K::NPIX1 && pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * CIN + ck * 4) * 4) : 0x80000000u;
+    const int hp = r1 + RPP1 * u, pix = (ty0 - 1) * IW + hp;  // rows above / below the image (and the padding rows of the stage): out-of-range offset -> the load returns zeros
+    aoff[u] = (hp < K::NPIX1 && pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * CIN + ck1 * 4) * 4) : 0x80000000u;
   }
-  const float* w1p = p.w1 + (int64_t)r0 * CIN + ck * 4;
+  const float* w1p = p.w1 + (int64_t)r1 * CIN + ck1 * 4;
   v4f sa[K::PD1][AU], sw[K::PD1][WU];
 #define SSG_BN_LOAD1(T_, S_)                                                                                         \
   {                                                                                                                  \
     _Pragma("unroll") for (int u = 0; u < AU; u++) {                                                                  \
-      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[u], (T_) * 64, 0);                            \
+      const v4u raw = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, aoff[u], (T_) * (K::K1T * 4), 0);                  \
       sa[S_][u] = __builtin_bit_cast(v4f, raw);                                                                     \
     }                                                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < WU; u++) sw[S_][u] = *reinterpret_cast<const v4f*>(w1p + (int64_t)(RPP * u) * CIN + (T_) * 16); \
+    _Pragma("unroll") for (int u = 0; u < WU; u++) sw[S_][u] = *reinterpret_cast<const v4f*>(w1p + (int64_t)(RPP1 * u) * CIN + (T_) * K::K1T); \
   }
 #define SSG_BN_STORE1(BUF_, S_)                                                                                      \
   {                                                                                                                  \
     unsigned char* sb_ = smem + (BUF_) * K::BUF1;                                                                    \
-    _Pragma("unroll") for (int u = 0; u < AU; u++) *reinterpret_cast<v4f*>(sb_ + (r0 + RPP * u) * K::P1 + ck * 16) = sa[S_][u]; \
-    _Pragma("unroll") for (int u = 0; u < WU; u++) *reinterpret_cast<v4f*>(sb_ + (K::XROWS + r0 + RPP * u) * K::P1 + ck * 16) = sw[S_][u]; \
+    _Pragma("unroll") for (int u = 0; u < AU; u++) *reinterpret_cast<v4f*>(sb_ + (r1 + RPP1 * u) * K::P1T + ck1 * 16) = sa[S_][u]; \
+    _Pragma("unroll") for (int u = 0; u < WU; u++) *reinterpret_cast<v4f*>(sb_ + (K::XROWS + r1 + RPP1 * u) * K::P1T + ck1 * 16) = sw[S_][u]; \
   }
   // MFMA tiles of phase 1: (NPIX1/32) pixel tiles x (MID/32) channel tiles over the waves
   constexpr int MT1 = K::NPIX1 / 32, NT1 = MID / 32;
@@ -168,12 +177,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
 #define SSG_BN_MMA1(BUF_)                                                                                            \
   {                                                                                                                  \
     const unsigned char* sb_ = smem + (BUF_) * K::BUF1;                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < K::KS1; ks++) {                                                          \
     v8h xh_[MTW1], xl_[MTW1], wh_[NTW1], wl_[NTW1];                                                                  \
     _Pragma("unroll") for (int i = 0; i < MTW1; i++) {                                                               \
-      const unsigned char* q_ = sb_ + ((i1b + i) * 32 + l32) * K::P1 + h * 32;                                       \
+      const unsigned char* q_ = sb_ + ((i1b + i) * 32 + l32) * K::P1T + ks * 64 + h * 32;                            \
       xh_[i] = *reinterpret_cast<const v8h*>(q_); xl_[i] = *reinterpret_cast<const v8h*>(q_ + 16); }                 \
     _Pragma("unroll") for (int j = 0; j < NTW1; j++) {                                                               \
-      const unsigned char* q_ = sb_ + (K::XROWS + (j1b + j) * 32 + l32) * K::P1 + h * 32;                            \
+      const unsigned char* q_ = sb_ + (K::XROWS + (j1b + j) * 32 + l32) * K::P1T + ks * 64 + h * 32;                 \
       wh_[j] = *reinterpret_cast<const v8h*>(q_); wl_[j] = *reinterpret_cast<const v8h*>(q_ + 16); }                 \
     _Pragma("unroll") for (int i = 0; i < MTW1; i++) _Pragma("unroll") for (int j = 0; j < NTW1; j++)                \
       acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xl_[i], acc1[i][j], 0, 0, 0);                      \
@@ -181,6 +191,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
       acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl_[j], xh_[i], acc1[i][j], 0, 0, 0);                      \
     _Pragma("unroll") for (int i = 0; i < MTW1; i++) _Pragma("unroll") for (int j = 0; j < NTW1; j++)                \
       acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh_[j], xh_[i], acc1[i][j], 0, 0, 0);                      \
+    }                                                                                                                \
   }
   // the register set of a tile is a LITERAL index (kt % PD1 of an unrolled loop variable leaves the rings in scratch memory)
 #define SSG_BN_STEP1(KT_, S_)                                                                                        \
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
         *reinterpret_cast<uint2*>(d) = hi; *reinterpret_cast<uint2*>(d + 16) = lo;
       }
   }
+  if (!K::ZERO_EARLY && tid < K::PY / 16) *reinterpret_cast<uint4*>(smem + K::ZERO_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);   // (phase 1 is over: its stages covered this row)
   SSG_BN_STORE2(0, 0)
   __syncthreads();
   SSG_BN_STAMP(2)

@@ -52,7 +52,20 @@ class DistHandle:
         round trip); a failure is kept on the handle and raised again by every later call, so a caller that catches the
         error cannot go on to cluster the NaN matrix."""
         if self._pending is not None:
-            vmax_h, flag_h = self._pending.tolist()
+            self.resolve_pending(self._pending.tolist())
+        if self._error is not None:
+            raise self._error
+        return self
+
+    def take_pending(self):
+        """the two device status words (or None when they were read already): a consumer that is about to read something else
+        back appends them to ITS read (cluster.eps_rule does) and hands the values to resolve_pending -- one host round trip less"""
+        return self._pending
+
+    def resolve_pending(self, values):
+        """values = the two status words as python numbers (read with the caller's host round trip)"""
+        if self._pending is not None:
+            vmax_h, flag_h = int(values[0]), int(values[1])
             self._pending = None
             if flag_h:
                 self._error = _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
