@@ -81,7 +81,12 @@ struct Cfg {
   static constexpr int W3_OFF = (NPIX * PY + 255) / 256 * 256, BUF3 = C * P1;
   static constexpr int LDS = cmax(cmax(2 * BUF1, W2_OFF + 2 * BUF2), W3_OFF + 2 * BUF3);
   static constexpr int DS = CIN != C;                  // downsample variant: conv3's reduction is [y2 | x]
-  static constexpr int NK1 = CIN / K1T, NK2 = (MID / 32) * 9 / KT2, NK3 = (MID + (DS ? CIN : 0)) / 16;
+#ifdef SSG_BN_ABL_NK1                                  // ablation builds (tools/micro/bneck_prof.hip): a shortened conv1 reduction, wrong results
+  static constexpr int NK1 = SSG_BN_ABL_NK1;
+#else
+  static constexpr int NK1 = CIN / K1T;
+#endif
+  static constexpr int NK2 = (MID / 32) * 9 / KT2, NK3 = (MID + (DS ? CIN : 0)) / 16;
   // stages of global loads in flight ahead of the multiply (PD1 = 4 measures the same: phase 1 is bound by HBM bandwidth, not latency)
   static constexpr int PD1MAX = K1T == 64 ? 2 : (K1T == 32 ? 4 : 8);
   static constexpr int PD1 = NK1 < PD1MAX ? NK1 : PD1MAX, PD2 = KT2 == 1 ? 6 : 3;
