@@ -527,6 +527,28 @@ def test_embedding_vs_reference_golden(golden, dev, precision):
             assert cat.shape == (2, (S + 1) * 2048)
 
 
+def test_embed_with_flip_on_two_streams_equals_one_stream(dev):
+    """`embed_with_flip` runs the original and the flipped forward on two HIP streams (resnet.py, flip_streams): the result must be
+    bit-identical to the one-stream order, also over back-to-back calls of different batches and sizes (tensors allocated on a side
+    stream's pool are consumed on the caller's stream, then recycled by the next call) and on a non-default caller stream."""
+    import ssg_amd
+    m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=2, pretrained=False).cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    batches = [torch.randn(b, 3, 256, 128, generator=g).cuda() for b in (5, 16, 3, 16, 9, 1)]
+    m.flip_streams = False
+    want = [m.embed_with_flip(x).clone() for x in batches]
+    m.flip_streams = True
+    got = [m.embed_with_flip(x) for x in batches]              # no synchronisation in between
+    caller = torch.cuda.Stream()
+    caller.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(caller):
+        got2 = [m.embed_with_flip(x * 1.0) for x in batches]   # inputs produced on the caller's stream right before the call
+    torch.cuda.synchronize()
+    for w, a, b in zip(want, got, got2):
+        assert torch.equal(w, a) and torch.equal(w, b)
+    assert not m._overflowed()
+
+
 def test_extract_features_dropin(golden, dev):
     """reid/evaluators.py:18 call surface: dict fname -> list of S+1 CPU vectors, dict fname -> pid."""
     import ssg_amd
