@@ -62,10 +62,18 @@ class TensorBatchLoader(object):
         return self.count
 
     def shard(self, rank, world):
+        """this rank's contiguous block of IMAGES (`shard_bounds` over the items, not over the batches: 13 batches over 8 ranks would
+        leave three ranks with half the work), re-batched locally -- an image's features do not depend on its batch"""
         from .dist import shard_bounds
-        lo, hi = shard_bounds(len(self), rank, world)
-        i0 = min(lo * self.batch_size, self.count); i1 = min(hi * self.batch_size, self.count)
+        i0, i1 = shard_bounds(self.count, rank, world)
         return TensorBatchLoader(self.images, self.batch_size, self.fnames, self.pids, self.first + i0, i1 - i0)
+
+    def listing(self):
+        """(fnames, pids) of every item in loader order, without touching the images"""
+        r = range(self.first, self.first + self.count)
+        names = list(self.fnames[self.first:self.first + self.count]) if self.fnames is not None else ["%08d" % i for i in r]
+        ids = list(self.pids[self.first:self.first + self.count]) if self.pids is not None else [0] * self.count
+        return names, ids
 
     def __iter__(self):
         for b0 in range(self.first, self.first + self.count, self.batch_size):
@@ -104,7 +112,8 @@ def extract_embeddings(model, data_loader, for_eval=False, print_freq=0, group=N
 
     group: torch.distributed group (one process per GPU).  The loader's batches are sharded contiguously over the ranks, every
     rank embeds its own share and the embeddings are all-gathered (C1 of SURVEY.md 8e: ONE flat all-gather of the feature
-    blocks over RCCL/xGMI + a tiny one for the block lengths; the file names / pids travel as one `all_gather_object`), so
+    blocks over RCCL/xGMI; block lengths and file names / pids follow from the loader description every rank holds -- loaders
+    without `shard` / `listing` exchange them with a small all-gather and one `all_gather_object`), so
     every rank returns the full set in loader order -- bit-identical to the unsharded call, because an image's features do not
     depend on which other images share its launch.  gather=False keeps the local share (feats of this rank's images only)."""
     m = _check_model(model).eval()
@@ -129,13 +138,24 @@ def extract_embeddings(model, data_loader, for_eval=False, print_freq=0, group=N
     from .dist import gather_counts, gather_ragged
     three = feats.dim() == 3
     rows = feats.permute(1, 0, 2).contiguous() if three else feats          # image-major rows
-    counts = gather_counts(rows.shape[0], group, rows.device)
+    world = dist.get_world_size(group)
+    known = hasattr(data_loader, "shard") and hasattr(data_loader, "num_items") and hasattr(data_loader, "listing")
+    if known:
+        # every rank holds the same loader description: block lengths and names follow from it, no exchange and no host round trip
+        counts = [int(data_loader.shard(r, world).num_items()) for r in range(world)]
+        if counts[dist.get_rank(group)] != rows.shape[0]:
+            raise RuntimeError("extract_embeddings: this rank embedded %d images, its shard of the loader has %d" % (rows.shape[0], counts[dist.get_rank(group)]))
+    else:
+        counts = gather_counts(rows.shape[0], group, rows.device)
     rows = gather_ragged(rows, counts, group)
     feats = rows.permute(1, 0, 2).contiguous() if three else rows
-    meta = [None] * dist.get_world_size(group)
-    dist.all_gather_object(meta, (fnames, pids), group=group)
-    fnames = [f for part in meta for f in part[0]]
-    pids = [p for part in meta for p in part[1]]
+    if known:
+        fnames, pids = data_loader.listing()
+    else:
+        meta = [None] * world
+        dist.all_gather_object(meta, (fnames, pids), group=group)
+        fnames = [f for part in meta for f in part[0]]
+        pids = [p for part in meta for p in part[1]]
     return feats, fnames, pids
 
 

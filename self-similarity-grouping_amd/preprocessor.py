@@ -131,15 +131,22 @@ class GpuBatchLoader(object):
         return (self.count + self.batch_size - 1) // self.batch_size
 
     def shard(self, rank, world):
-        """loader of this rank's contiguous block of batches (`ssg_amd.dist.shard_bounds` over the batches): what
+        """loader of this rank's contiguous block of images (`ssg_amd.dist.shard_bounds` over the items): what
         `extract_features(..., group=)` iterates, so that a rank only decodes the images it embeds"""
         import copy
         from .dist import shard_bounds
-        lo, hi = shard_bounds(len(self), rank, world)
+        i0, i1 = shard_bounds(self.count, rank, world)      # by images, not by batches: balanced to one image, re-batched locally
         sub = copy.copy(self)
-        i0 = min(lo * self.batch_size, self.count); i1 = min(hi * self.batch_size, self.count)
         sub.first, sub.count = self.first + i0, i1 - i0
         return sub
+
+    def num_items(self):
+        return self.count
+
+    def listing(self):
+        """(fnames, pids) of every item in loader order, from the dataset records alone (no file is opened)"""
+        recs = [self.items.dataset[i] for i in range(self.first, self.first + self.count)]
+        return [r[0] for r in recs], [r[1] for r in recs]
 
     def __iter__(self):
         n = self.first + self.count
