@@ -190,8 +190,10 @@ def main():
     import ssg_amd
     from ssg_amd import _lib, cluster, dist as sdist, evaluators, rerank
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SSG_BENCH_SHARE_GPU") == "1":           # dry run of the N > 1 code path on a one-GPU box: every rank on cuda:0, gloo collectives
+        local = 0
     torch.cuda.set_device(local)                               # before the process group: RCCL binds its communicator to the current device
-    rank, world, group = sdist.init_from_env()
+    rank, world, group = sdist.init_from_env(backend="gloo" if os.environ.get("SSG_BENCH_SHARE_GPU") == "1" else None)
     if world != args.gpus:
         raise SystemExit("launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d, --gpus %d)" % (args.gpus, world, args.gpus))
     dev = torch.device("cuda", local)
@@ -434,7 +436,7 @@ def main():
                                                      "f32 (embed, fp32 MFMA)") + " / exact int64 via int8 MFMA digits + f64 + f16 (distance, re-rank: half semantics, bit-exact)",
         "data": "synthetic: N(0,1) 256x128 images + seeded Kaiming ResNet-50 weights for the embed leg; clustered unit-norm 2048-d embeddings "
                 "for the grouping leg (track '%s', tools/synth.py: %s) -- random-init backbone features are degenerate: reid/rerank.py:40 NaN path"
-                % (args.track_g, "identity sizes 1..24, unequal spreads, 30%% confusable centres -> noise, border points, merged clusters"
+                % (args.track_g, "identity sizes 1..24, unequal spreads, 30 % confusable centres -> noise, border points, merged clusters"
                    if args.track_g == "hard" else "16 per identity, trivially separable (SURVEY.md 8d)"),
         "config": {"workload": "BASELINE configs[1]+[2]: N=%d target + Ns=%d source images -> ResNet-50 2048-d embed (orig+flip) -> "
                                "k-reciprocal re-rank (k1=20,k2=6,lambda=%.1f) -> eps rule (rho=%.1e) -> DBSCAN(min_samples=4), 1 feature split"
