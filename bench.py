@@ -84,7 +84,7 @@ class KernelTimer:
 
     def __init__(self, L):
         self.L, self.ev, self.on = L, {}, False
-        self.sample, self.sampled_images = True, 0      # embed batches are sampled 1 in 4 (the events cost 2.7 % when on every launch)
+        self.sample, self.sampled_images = True, 0      # embed batches are sampled 1 in 8 (the events cost 2.7 % when on every launch, and a sampled batch runs its two forwards on one stream)
 
     def __getattr__(self, k):
         fn = getattr(self.L, k)
@@ -217,7 +217,7 @@ def main():
     nrows = row1 - row0
 
     class TimedLoader(evaluators.TensorBatchLoader):
-        """the product's resident-tensor loader; per-launch HIP events are switched on for every 4th batch only"""
+        """the product's resident-tensor loader; per-launch HIP events are switched on for every 8th batch only"""
 
         def shard(self, r, w):
             s_ = super().shard(r, w)
@@ -225,7 +225,7 @@ def main():
 
         def __iter__(self):
             for bi, batch in enumerate(super().__iter__()):
-                timer.sample = (bi % 4 == 0)
+                timer.sample = (bi % 8 == 0)
                 # sampled batches run their two forwards one after the other on one stream, so that an event pair brackets ONE launch
                 # running alone (the roofline figure); the other batches use the product default, two streams (launches overlap)
                 model.flip_streams = not (timer.on and timer.sample)
@@ -356,7 +356,7 @@ def main():
                        "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2, 53 convs x 2 orientations per image)"),
             "achieved": round(conv_tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(conv_tf / peak, 4),
             "traffic": None, "launches": n_conv, "avg_launch_ms": round(ms_conv / max(n_conv, 1), 4), "launches_by_abi": launches_by_abi,
-            "algorithmic": "10.68 GFLOP per image (2 forwards x 5.34 GFLOP); HIP events around every convolution-carrying launch of every 4th batch: %d of the "
+            "algorithmic": "10.68 GFLOP per image (2 forwards x 5.34 GFLOP); HIP events around every convolution-carrying launch of every 8th batch (those batches run their two forwards on one stream): %d of the "
                            "%d images embedded in the timed steps" % (timer.sampled_images, imgs_rank * args.steps)}
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, collected on this
     # kernel set at the same batch size); null when the configuration differs from the profiled one
