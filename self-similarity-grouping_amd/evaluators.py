@@ -10,6 +10,7 @@ stay on the GPU until the dictionary is built, so there is one D2H copy per call
 one per batch.  `extract_embeddings` is the device-resident variant used by the fused
 grouping path (no dict, no D2H).
 """
+import os
 import time
 from collections import OrderedDict
 
@@ -121,12 +122,19 @@ def extract_embeddings(model, data_loader, for_eval=False, print_freq=0, group=N
     t0 = time.time()
     mine = _rank_batches(data_loader, group)
     nb = len(mine) if hasattr(mine, "__len__") else len(data_loader)
+    # the split-half range flag (|activation| >= 65520, resnet.ResNet._overflowed) is sticky on the device: loaders that can be walked
+    # again read it ONCE after the last batch instead of once per batch (a host round trip that drains the launch queue every time);
+    # one-shot iterables keep the per-batch check
+    again = hasattr(mine, "__len__") and hasattr(m, "_overflowed") and os.environ.get("SSG_EXTRACT_CHECK_EACH", "0") != "1"
     for i, batch in enumerate(mine):
         imgs, names, ids = batch[0], batch[1], batch[2]
-        chunks.append(m.embed_with_flip(torch.as_tensor(imgs), for_eval=for_eval))
+        chunks.append(m.embed_with_flip(torch.as_tensor(imgs), for_eval=for_eval, check_overflow=False) if again
+                      else m.embed_with_flip(torch.as_tensor(imgs), for_eval=for_eval))
         fnames.extend(list(names)); pids.extend(list(ids))
         if print_freq and (i + 1) % print_freq == 0:
             print('Extract Features: [{}/{}]\tTime {:.3f}'.format(i + 1, nb, time.time() - t0))
+    if again and m._overflowed():          # (the fp32 twin warns when it is first built)
+        chunks = [m._f32_twin().embed_with_flip(torch.as_tensor(batch[0]), for_eval=for_eval) for batch in mine]
     if chunks:
         feats = torch.cat(chunks, dim=1 if chunks[0].dim() == 3 else 0)
     else:       # more ranks than batches: an empty share of the right shape

@@ -471,9 +471,11 @@ class ResNet:
 
     forward = __call__
 
-    def embed_with_flip(self, x, for_eval=False):
+    def embed_with_flip(self, x, for_eval=False, check_overflow=True):
         """Fused reid/evaluators.py:28-35: features of x and fliplr(x) summed and L2-normalised.
-        Returns [(S+1), B, 2048] (per-set norm) or, for_eval / single set, [B, (S+1)*2048]."""
+        Returns [(S+1), B, 2048] (per-set norm) or, for_eval / single set, [B, (S+1)*2048].
+        check_overflow=False leaves the split-half range flag unread (no host round trip): the caller reads it once after its last
+        batch with `_overflowed()` and recomputes on the fp32 path if it is set (`evaluators.extract_embeddings` does)."""
         L = _lib.lib()
         x = x.to(self.device, torch.float32)          # one H2D copy for both orientations
         if self.flip_streams and self.precision == "split" and os.environ.get("SSG_FLIP_STREAMS", "1") != "0":
@@ -494,7 +496,7 @@ class ResNet:
         else:
             a = self.pooled(*self._fmap(x, flip=False))
             b = self.pooled(*self._fmap(x, flip=True))
-        if self._overflowed():
+        if check_overflow and self._overflowed():
             return self._f32_twin().embed_with_flip(x, for_eval)
         nsets, B, C = a.shape
         if for_eval or nsets == 1:

@@ -923,6 +923,14 @@ def test_split_half_overflow_falls_back_to_f32(dev):
     x1, _ = ms(imgs, False); y1, _ = m32(imgs, False)
     assert torch.equal(x1, y1)
     assert torch.equal(ms.feature_map(imgs), m32.feature_map(imgs))
+    # extraction reads the flag once after its last batch and recomputes the whole extraction on the fp32 path
+    from ssg_amd import evaluators as ev
+    ms2 = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, pretrained=False, seed=1, precision="split").cuda().eval()
+    both = torch.cat([imgs * 1e-4, imgs])                     # first batch in range, second one overflows
+    with pytest.warns(UserWarning, match="half range"):
+        fe, _, _ = ev.extract_embeddings(ms2, ev.TensorBatchLoader(both, 2))
+    fw, _, _ = ev.extract_embeddings(m32, ev.TensorBatchLoader(both, 2))
+    assert bool(torch.isfinite(fe).all()) and torch.equal(fe, fw)
     # in-range batches keep using the split path afterwards (flag cleared)
     small = torch.randn(2, 3, 256, 128, generator=torch.Generator().manual_seed(4))
     a = ms.embed_with_flip(small); b = m32.embed_with_flip(small)
