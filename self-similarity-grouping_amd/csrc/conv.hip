@@ -1302,9 +1302,17 @@ static int source_rowmin_filtered_impl(const float* tgt, const float* src, int n
     _Float16* x16 = (_Float16*)a; _Float16* y16 = x16 + (int64_t)nrows * d;
     hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, tgt, x16, (int64_t)nrows * d / 4, scale_t);
     hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, src, y16, (int64_t)Ns_pad * d / 4, scale_s);
-    const int tiles = ((nrows + sbound::BM - 1) / sbound::BM) * (Ns_pad / sbound::BN);
-    hipLaunchKernelGGL(sbound::source_bound_kernel, dim3(tiles), dim3(256), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
-                       1.f / (scale_t * scale_s), tilemin, ntiles);
+    static int sb_dma = -1;                 // SSG_SB_DMA=0: the register-staged 128 x 128 kernel
+    if (sb_dma < 0) { const char* e = getenv("SSG_SB_DMA"); sb_dma = e ? atoi(e) : 1; }
+    if (sb_dma && (int64_t)nrows * d * 2 < 0x7fffffffLL && (int64_t)Ns_pad * d * 2 < 0x7fffffffLL) {     // (operands go through 2 GiB buffer resources)
+      const int tiles = ((nrows + sbound::TB - 1) / sbound::TB) * ((Ns_pad + sbound::TB - 1) / sbound::TB);
+      hipLaunchKernelGGL(sbound::source_bound_dma_kernel, dim3(tiles), dim3(512), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
+                         1.f / (scale_t * scale_s), tilemin, ntiles);
+    } else {
+      const int tiles = ((nrows + sbound::BM - 1) / sbound::BM) * (Ns_pad / sbound::BN);
+      hipLaunchKernelGGL(sbound::source_bound_kernel, dim3(tiles), dim3(256), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
+                         1.f / (scale_t * scale_s), tilemin, ntiles);
+    }
     hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
     SSG_LAUNCH_CHECK("source_bound / source_refine kernels");
     return SSG_OK;

@@ -131,5 +131,126 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void source_bound_kernel(con
   }
 }
 
+// ---- 256 x 256 tiles, LDS-DMA stages, 128 x 64 wave tiles ---------------------------------------------------------------------
+// A one-product fp16 GEMM on 64 x 64 wave tiles reads one 16-byte fragment per lane and MFMA: at the matrix peak that alone is the
+// CU's whole LDS bandwidth (1 KB per 32 cycles and wave, 4 SIMDs), before the staging writes -- the kernel above measured "fragment
+// reads ~ MFMA time".  Here a wave owns 128 targets x 64 sources (6 fragments per 8 MFMAs), the operand tiles go global -> LDS
+// directly (buffer_load ... lds: no staging registers, no ds_write; rows of 64 bytes = BK 32 halves, 16-byte chunks XOR-swizzled with
+// (row >> 2) & 3 on the global side and in the fragment reads, as conv.hip's conv_dma_kernel does), four 32 KB stages with three
+// k-tiles in flight, and the fragments of k-tile t + 1 are fetched into a second register set right after the barrier that publishes
+// them, under the second half of tile t's MFMAs.  8 waves (2 per SIMD), 128 accumulator registers.
+#define SSG_SB_LDSP(ptr_) ((__attribute__((address_space(3))) void*)(ptr_))
+constexpr int TB = 256;
+__global__ __launch_bounds__(512, 1) void source_bound_dma_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Y, int M, int Npad, int K,
+                                                                  const float* __restrict__ rowterm, const float* __restrict__ colterm, float acc_scale,
+                                                                  float* __restrict__ tilemin, int tmin_ld) {
+  constexpr int NS = 4, XB = TB * 64, STAGE = 2 * XB, TDMA = 4, MT = 4, NT = 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char st0[STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char st1[STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char st2[STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char st3[STAGE];
+  const int tiles_n = (Npad + TB - 1) / TB, tiles_m = (M + TB - 1) / TB;
+  constexpr int TG = 2;                                    // target panels (1 MB each at d = 2048) that sweep the source panels together
+  int tm, tn;
+  {
+    const int nwg = tiles_m * tiles_n, b = (int)blockIdx.x;
+    const int q = nwg / 8, r = nwg % 8, x = b % 8, sidx = b / 8;
+    const int L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + sidx;
+    const int tpg = TG * tiles_n, grp = L / tpg, rem = L - grp * tpg;
+    const int gcur = min(TG, tiles_m - grp * TG);
+    tn = rem / gcur; tm = grp * TG + rem % gcur;
+  }
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
+  // DMA: this wave fills rows [32 wave, 32 wave + 32) of the X part and of the Y part of every stage (two 16-row blocks each)
+  const int drow = lane >> 2, pc = lane & 3, lc = pc ^ ((drow >> 2) & 3);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(X), 0, (unsigned)((int64_t)M * K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(Y), 0, (unsigned)((int64_t)Npad * K * 2), 0x00020000);
+  // (rows past the end of X / Y lie outside the buffer range and read as zeros)
+  const unsigned xo0 = (unsigned)(((int64_t)(tm * TB + wave * 32 + drow) * K) * 2 + lc * 16), xo1 = xo0 + (unsigned)(16 * K * 2);
+  const unsigned yo0 = (unsigned)(((int64_t)(tn * TB + wave * 32 + drow) * K) * 2 + lc * 16), yo1 = yo0 + (unsigned)(16 * K * 2);
+  const int nk = K / 32;
+  int dn = 0;
+#define SSG_SB_DMA(ST)                                                                                               \
+  {                                                                                                                  \
+    const unsigned kb_ = (unsigned)(dn * 64);                                                                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, SSG_SB_LDSP(ST + wave * 2048), 16, xo0 + kb_, 0, 0, 0);              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, SSG_SB_LDSP(ST + wave * 2048 + 1024), 16, xo1 + kb_, 0, 0, 0);       \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, SSG_SB_LDSP(ST + XB + wave * 2048), 16, yo0 + kb_, 0, 0, 0);         \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, SSG_SB_LDSP(ST + XB + wave * 2048 + 1024), 16, yo1 + kb_, 0, 0, 0);  \
+    dn += dn < nk - 1 ? 1 : 0;               /* the tail re-fetches the last tile (keeps the vmcnt accounting uniform) */ \
+  }
+  // fragments: lane (row l32 of a 32-row MFMA tile, k group h); k step s of a stage = logical 16-byte chunk 2 s + h
+  const int g = (l32 >> 2) & 3;
+  const int off0 = ((0 + h) ^ g) * 16, off1 = ((2 + h) ^ g) * 16;
+  const int xrow = (wm * 128 + l32) * 64, yrow = XB + (wn * 64 + l32) * 64;
+  v8h xf[2][2][MT], yf[2][2][NT];                           // [register set][k step][tile]
+#define SSG_SB_READS(ST, S)                                                                                          \
+  { _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                                 \
+      xf[S][0][i] = *reinterpret_cast<const v8h*>(ST + xrow + i * 2048 + off0); xf[S][1][i] = *reinterpret_cast<const v8h*>(ST + xrow + i * 2048 + off1); } \
+    _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                                 \
+      yf[S][0][j] = *reinterpret_cast<const v8h*>(ST + yrow + j * 2048 + off0); yf[S][1][j] = *reinterpret_cast<const v8h*>(ST + yrow + j * 2048 + off1); } }
+#define SSG_SB_MMA(S, KS) { _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++) \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(yf[S][KS][j], xf[S][KS][i], acc[i][j], 0, 0, 0); }
+  // k-tile t (fragments in set S): first k step, publish tile t + 1 (and: everybody is done reading this stage), refill this stage with
+  // tile t + NS, fetch tile t + 1's fragments into the other set, second k step
+#define SSG_SB_STEP(ST, STN, S)                                                                                      \
+  { SSG_SB_MMA(S, 0)                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TDMA * (NS - 2)) : "memory");                   \
+    SSG_SB_DMA(ST)                                                                                                   \
+    SSG_SB_READS(STN, 1 - (S))                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                               \
+    SSG_SB_MMA(S, 1) }
+  v16f acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; i++)
+#pragma unroll
+    for (int j = 0; j < NT; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  SSG_SB_DMA(st0)
+  SSG_SB_DMA(st1)
+  SSG_SB_DMA(st2)
+  SSG_SB_DMA(st3)
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TDMA * (NS - 1)) : "memory");     // k-tile 0 landed for everybody
+  SSG_SB_READS(st0, 0)
+  const int nfull = nk / NS * NS;
+  for (int kt = 0; kt < nfull; kt += NS) {
+    SSG_SB_STEP(st0, st1, 0)
+    SSG_SB_STEP(st1, st2, 1)
+    SSG_SB_STEP(st2, st3, 0)
+    SSG_SB_STEP(st3, st0, 1)
+  }
+  // left-over k-tiles (nk % NS): set 0 holds the fragments of tile nfull (published by the last barrier of the loop, or by the one above)
+  if (nk - nfull >= 1) { SSG_SB_MMA(0, 0) SSG_SB_MMA(0, 1) }
+  if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_SB_READS(st1, 0) SSG_SB_MMA(0, 0) SSG_SB_MMA(0, 1) }
+  if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_SB_READS(st2, 0) SSG_SB_MMA(0, 0) SSG_SB_MMA(0, 1) }
+#undef SSG_SB_STEP
+#undef SSG_SB_MMA
+#undef SSG_SB_READS
+#undef SSG_SB_DMA
+  // epilogue: as above (col = lane & 31 -> target, accumulator quad q of tile j = sources j * 32 + 8 q + 4 h + {0..3})
+#pragma unroll
+  for (int i = 0; i < MT; i++) {
+    const int m = tm * TB + wm * 128 + i * 32 + l32;
+    const float rt = rowterm[m < M ? m : 0];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const int n0 = tn * TB + wn * 64 + j * 32;
+      if (n0 >= Npad) continue;                              // (Npad is a multiple of 128, the tile of 256: the last source tile may be half empty)
+      float gq[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 ct = *reinterpret_cast<const float4*>(colterm + n0 + 8 * q + 4 * h);
+        const float mn = fminf(fminf((rt + ct.x) - 2.f * (acc[i][j][4 * q] * acc_scale), (rt + ct.y) - 2.f * (acc[i][j][4 * q + 1] * acc_scale)),
+                               fminf((rt + ct.z) - 2.f * (acc[i][j][4 * q + 2] * acc_scale), (rt + ct.w) - 2.f * (acc[i][j][4 * q + 3] * acc_scale)));
+        gq[q] = fminf(mn, __shfl_xor(mn, 32, 64));
+      }
+      if (h == 0 && m < M) *reinterpret_cast<float4*>(tilemin + (int64_t)m * tmin_ld + n0 / 8) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+    }
+  }
+}
+
 }  // namespace sbound
 }  // namespace ssg

@@ -246,14 +246,14 @@ def _extract_gpu_worker(rank, world, port, q, n_img, batch, backend):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("world", [2, 3])        # (8 processes each building their own ResNet-50 took 5 minutes of CPU; the 8-rank exchange pattern is covered by the pipeline test)
 def test_sharded_extraction_matches_unsharded(world):
     """The embedding half of the multi-GPU path (selftraining.py:135,196-209 under nn.DataParallel in the reference): images
     sharded over `world` processes (gloo; they share the test box's single GPU), embeddings all-gathered -- bit-identical to the
     single-process extraction, in loader order, on every rank."""
     import ssg_amd
     from ssg_amd import evaluators as ev
-    n_img, batch = 45, 4
+    n_img, batch = 46, 4                               # 46 = 16 + 15 + 15 over three ranks: ragged shares, ragged last batches
     imgs = torch.randn(n_img, 3, 256, 128, generator=torch.Generator().manual_seed(17))
     model = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=1, pretrained=False).cuda().eval()
     ref, rnames, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, batch), for_eval=False)

@@ -94,7 +94,7 @@ def test_sort_u64(L, dev):
 
 
 # ------------------------------------------------------------------ pairwise distance (K3/K4)
-@pytest.mark.parametrize("N,Ns,d", [(300, 77, 96), (129, 260, 40), (1024, 512, 256)])
+@pytest.mark.parametrize("N,Ns,d", [(300, 77, 96), (129, 260, 40), (1024, 512, 256), (700, 900, 2048), (515, 1300, 160)])
 def test_pairwise_vs_oracle(N, Ns, d, dev, ora):
     from ssg_amd import rerank
     tgt = clustered(N, d, 3); src = clustered(Ns, d, 4, intra=0.7)
