@@ -121,6 +121,13 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 // x*w = xh*wl + xl*wh + xh*wh (the order of conv.hip's split_mma_step), weights as the first MFMA operand:
 // C/D layout col = lane&31 -> pixel, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> channel
 
+// one LDS-DMA instruction: 64 lanes x 16 bytes, global (buffer resource, per-lane byte offset + uniform offset) -> LDS at `lds_addr` +
+// 16 * lane.  A function of its own: with the builtin called directly from the kernel template (per-lane offset from a local array) the
+// HOST pass of hipcc drops the kernel's launch stub without a diagnostic (undefined __device_stub__ at load time).
+__device__ __forceinline__ void bn_dma16(const __amdgpu_buffer_rsrc_t r, unsigned lds_addr, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr, 16, voff, soff, 0, 0);
+}
+
 template <int C, int MID, int IW, int TH, int CIN, int NW>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Params p) {
   using K = Cfg<C, MID, IW, TH, CIN, NW>;
@@ -143,6 +150,106 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
   const int ck1 = tid % K::CPR1, r1 = tid / K::CPR1;   // phase 1 staging (64- or 128-byte rows)
   const float* ximg = p.x + (int64_t)img * p.H * IW * CIN;
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ximg), 0, (unsigned)(p.H * IW * CIN * 4), 0x00020000);
+  // MFMA tiles of phase 1: (NPIX1/32) pixel tiles x (MID/32) channel tiles over the waves
+  constexpr int MT1 = K::NPIX1 / 32, NT1 = MID / 32;
+  // waves are split as WR x WC with WC = min(NT1, NW/2): each wave owns ceil(MT1/WR) pixel tiles x NT1/WC channel tiles (a pixel tile
+  // beyond MT1 multiplies the zero padding rows of the stage and is not written)
+  constexpr int WC1 = NT1 < NW / 2 ? NT1 : NW / 2, WR1 = NW / WC1, MTW1 = (MT1 + WR1 - 1) / WR1, NTW1 = NT1 / WC1;
+  static_assert(NT1 % WC1 == 0 && (WR1 * MTW1) * 32 <= K::XROWS, "phase-1 tiles divide over the waves");
+  const int i1b = (wave / WC1) * MTW1, j1b = (wave % WC1) * NTW1;
+  v16f acc1[MTW1][NTW1];
+#pragma unroll
+  for (int i = 0; i < MTW1; i++)
+#pragma unroll
+    for (int j = 0; j < NTW1; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc1[i][j][r] = 0.f;
+  // folded BatchNorm scale / bias of this wave's conv1 channels (needed after the loop: no L2 round trip there)
+  float4 cs1r[NTW1][4], b1r[NTW1][4];
+#pragma unroll
+  for (int j = 0; j < NTW1; j++)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      cs1r[j][q] = *reinterpret_cast<const float4*>(p.cs1 + (j1b + j) * 32 + 8 * q + 4 * h); b1r[j][q] = *reinterpret_cast<const float4*>(p.b1 + (j1b + j) * 32 + 8 * q + 4 * h);
+    }
+#ifndef SSG_BN_P1DMA
+#define SSG_BN_P1DMA 1
+#endif
+  if constexpr (NW == 8 && K::K1T == 32 && SSG_BN_P1DMA) {
+    // ---- 8-wave kernel: LDS-DMA stages + register double-buffered fragments.  One workgroup per CU: with register-staged stages every
+    // wave stores, waits at the barrier, reads its fragments and multiplies at the same time as the other seven -- per 32-channel k-tile
+    // 1350 cycles of LDS traffic and 1150 cycles of MFMA one after the other (measured 3000).  Here the x rows and W1 rows go
+    // global -> LDS directly (buffer_load ... lds; rows of 128 bytes, 16-byte chunks XOR-swizzled with (row >> 1) & 7 on the global side
+    // and in the fragment reads: conflict-free b128 reads), four 36 KB stages with three k-tiles in flight (the y1 / W2 regions are not
+    // live yet), and the fragments of k-tile t + 1 are read into a second register set right after the barrier that publishes them,
+    // under the second k-step of tile t.  Same products in the same order: bit-identical.
+    constexpr int NS = 4, XR = K::NPIX1, SROWS = XR + MID, STG = SROWS * 128, NBLK = SROWS / 8, TDMA = (NBLK + NW - 1) / NW;
+    static_assert(K::NK1 % NS == 0 && NS * STG <= K::LDS && SROWS % 8 == 0 && XR % 8 == 0 && MTW1 == 3 && NTW1 == 1, "phase-1 DMA stages");
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w1), 0, (unsigned)(MID * CIN * 4), 0x00020000);
+    unsigned go[TDMA];                                       // per DMA instruction of this wave: global byte offset of its lane's 16-byte chunk in k-tile 0
+    int gblk[TDMA];                                          // ... and its 8-row block of the stage (wave-uniform); blocks < XR / 8 hold x rows
+#pragma unroll
+    for (int u = 0; u < TDMA; u++) {
+      int blk = wv + NW * u;
+      if (blk >= NBLK) blk = wv;                             // (36 blocks over 8 waves: the last four waves fetch their first block twice -- keeps vmcnt uniform)
+      gblk[u] = blk;
+      const int r = blk * 8 + (lane >> 3), lc = (lane & 7) ^ ((r >> 1) & 7);
+      if (blk < XR / 8) {
+        const int pix = (ty0 - 1) * IW + r;                  // rows above / below the image: out-of-range offset -> zeros
+        go[u] = (pix >= 0 && pix < p.H * IW) ? (unsigned)((pix * CIN + lc * 4) * 4) : 0x80000000u;
+      } else {
+        go[u] = (unsigned)(((r - XR) * CIN + lc * 4) * 4);
+      }
+    }
+#define SSG_BN_DMA1(T_, ST_)                                                                                         \
+    { _Pragma("unroll") for (int u = 0; u < TDMA; u++)                                                               \
+        bn_dma16(gblk[u] < XR / 8 ? xrsrc : wrsrc, (unsigned)(uintptr_t)(smem + (ST_) * STG + gblk[u] * 1024), go[u], (T_) * 128); }
+    // fragments: lane (row l32 of a 32-row MFMA tile, channel group h of a 16-channel k-step): hi = logical chunk 4 ks + 2 h, lo = the next one
+    // (the sixth pixel tile of the second wave row does not exist: its fragment reads land in the W1 rows of the stage, its products are
+    // never written -- cheaper than a branch around every MFMA)
+    const int i1s = __builtin_amdgcn_readfirstlane(i1b);
+    int xo[MTW1], xs[MTW1];
+#pragma unroll
+    for (int i = 0; i < MTW1; i++) { const int r = (i1s + i) * 32 + l32; xo[i] = r * 128; xs[i] = (r >> 1) & 7; }
+    const int wr_ = XR + j1b * 32 + l32, wo = wr_ * 128, ws = (wr_ >> 1) & 7;
+    v8h fxh[2][2][MTW1], fxl[2][2][MTW1], fwh[2][2], fwl[2][2];       // [register set][k-step][tile]
+#define SSG_BN_READS1(ST_, S_)                                                                                       \
+    { const unsigned char* sb_ = smem + (ST_) * STG;                                                                 \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ks++) {                                                             \
+        _Pragma("unroll") for (int i = 0; i < MTW1; i++) {                                        \
+          fxh[S_][ks][i] = *reinterpret_cast<const v8h*>(sb_ + xo[i] + (((4 * ks + 2 * h) ^ xs[i]) * 16));           \
+          fxl[S_][ks][i] = *reinterpret_cast<const v8h*>(sb_ + xo[i] + (((4 * ks + 2 * h + 1) ^ xs[i]) * 16)); }     \
+        fwh[S_][ks] = *reinterpret_cast<const v8h*>(sb_ + wo + (((4 * ks + 2 * h) ^ ws) * 16));                       \
+        fwl[S_][ks] = *reinterpret_cast<const v8h*>(sb_ + wo + (((4 * ks + 2 * h + 1) ^ ws) * 16)); } }
+#define SSG_BN_MMAK(S_, KS_)                                                                                         \
+    { _Pragma("unroll") for (int i = 0; i < MTW1; i++) acc1[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[S_][KS_], fxl[S_][KS_][i], acc1[i][0], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < MTW1; i++) acc1[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwl[S_][KS_], fxh[S_][KS_][i], acc1[i][0], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < MTW1; i++) acc1[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fwh[S_][KS_], fxh[S_][KS_][i], acc1[i][0], 0, 0, 0); }
+    // k-tile t (fragments in set S): first k-step, publish tile t + 1 (and: everybody is done reading this stage), refill this stage with
+    // tile t + NS, read tile t + 1's fragments into the other set, second k-step
+#define SSG_BN_STEPD(KT_, ST_, STN_, S_)                                                                             \
+    { SSG_BN_MMAK(S_, 0)                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TDMA * (NS - 2)) : "memory");                  \
+      { const int tn_ = (KT_) + NS < K::NK1 ? (KT_) + NS : K::NK1 - 1;   /* the tail re-fetches the last tile: uniform vmcnt accounting */ \
+        SSG_BN_DMA1(tn_, ST_) }                                                                                      \
+      SSG_BN_READS1(STN_, 1 - (S_))                                                                                  \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      SSG_BN_MMAK(S_, 1) }
+    SSG_BN_DMA1(0, 0) SSG_BN_DMA1(1, 1) SSG_BN_DMA1(2, 2) SSG_BN_DMA1(3, 3)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TDMA * (NS - 1)) : "memory");       // k-tile 0 landed for everybody
+    SSG_BN_READS1(0, 0)
+#pragma unroll 1
+    for (int kt = 0; kt < K::NK1; kt += NS) {
+      SSG_BN_STEPD(kt, 0, 1, 0) SSG_BN_STEPD(kt + 1, 1, 2, 1) SSG_BN_STEPD(kt + 2, 2, 3, 0) SSG_BN_STEPD(kt + 3, 3, 0, 1)
+    }
+    __syncthreads();                       // drains the redundant tail DMAs: the stages are about to become y1 / the W2 stages
+#undef SSG_BN_STEPD
+#undef SSG_BN_MMAK
+#undef SSG_BN_READS1
+#undef SSG_BN_DMA1
+  } else {
   unsigned aoff[AU];
 #pragma unroll
   for (int u = 0; u < AU; u++) {
@@ -165,20 +272,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
     _Pragma("unroll") for (int u = 0; u < AU; u++) *reinterpret_cast<v4f*>(sb_ + (r1 + RPP1 * u) * K::P1T + ck1 * 16) = sa[S_][u]; \
     _Pragma("unroll") for (int u = 0; u < WU; u++) *reinterpret_cast<v4f*>(sb_ + (K::XROWS + r1 + RPP1 * u) * K::P1T + ck1 * 16) = sw[S_][u]; \
   }
-  // MFMA tiles of phase 1: (NPIX1/32) pixel tiles x (MID/32) channel tiles over the waves
-  constexpr int MT1 = K::NPIX1 / 32, NT1 = MID / 32;
-  // waves are split as WR x WC with WC = min(NT1, NW/2): each wave owns ceil(MT1/WR) pixel tiles x NT1/WC channel tiles (a pixel tile
-  // beyond MT1 multiplies the zero padding rows of the stage and is not written)
-  constexpr int WC1 = NT1 < NW / 2 ? NT1 : NW / 2, WR1 = NW / WC1, MTW1 = (MT1 + WR1 - 1) / WR1, NTW1 = NT1 / WC1;
-  static_assert(NT1 % WC1 == 0 && (WR1 * MTW1) * 32 <= K::XROWS, "phase-1 tiles divide over the waves");
-  const int i1b = (wave / WC1) * MTW1, j1b = (wave % WC1) * NTW1;
-  v16f acc1[MTW1][NTW1];
-#pragma unroll
-  for (int i = 0; i < MTW1; i++)
-#pragma unroll
-    for (int j = 0; j < NTW1; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc1[i][j][r] = 0.f;
 #define SSG_BN_MMA1(BUF_)                                                                                            \
   {                                                                                                                  \
     const unsigned char* sb_ = smem + (BUF_) * K::BUF1;                                                              \
@@ -210,14 +303,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
 #define SSG_BN_LOAD1_IF(S_) if constexpr ((S_) < K::PD1) SSG_BN_LOAD1(S_, S_)
   SSG_BN_LOAD1_IF(0) SSG_BN_LOAD1_IF(1) SSG_BN_LOAD1_IF(2) SSG_BN_LOAD1_IF(3) SSG_BN_LOAD1_IF(4) SSG_BN_LOAD1_IF(5) SSG_BN_LOAD1_IF(6) SSG_BN_LOAD1_IF(7)
 #undef SSG_BN_LOAD1_IF
-  // folded BatchNorm scale / bias of this wave's conv1 channels (needed after the loop: no L2 round trip there)
-  float4 cs1r[NTW1][4], b1r[NTW1][4];
-#pragma unroll
-  for (int j = 0; j < NTW1; j++)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      cs1r[j][q] = *reinterpret_cast<const float4*>(p.cs1 + (j1b + j) * 32 + 8 * q + 4 * h); b1r[j][q] = *reinterpret_cast<const float4*>(p.b1 + (j1b + j) * 32 + 8 * q + 4 * h);
-    }
   SSG_BN_STORE1(0, 0)
   __syncthreads();
 #define SSG_BN_STEP1_IF(KT_, S_) if constexpr ((S_) < K::PD1) SSG_BN_STEP1(KT_, S_)
@@ -228,6 +313,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
   }
 #undef SSG_BN_STEP1_IF
 #undef SSG_BN_STEP1
+  }
   SSG_BN_STAMP(1)
 #undef SSG_BN_LOAD1
 #undef SSG_BN_STORE1
