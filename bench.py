@@ -51,6 +51,24 @@ def build_fingerprint():
     return h.hexdigest()[:16]
 
 
+def pmc_traffic(path, build, batch, launches_per_forward):
+    """HBM bytes per convolution launch from the PMC summary `tools/pmc_embed.sh` wrote (FETCH_SIZE x 2 + WRITE_SIZE over one forward, divided
+    by its launches) -> (bytes or None, note).  None when there is no summary, when it was taken on another build of the kernels (the
+    fingerprint it carries differs) or on another launch set / batch size: a stale figure is not quoted."""
+    try:
+        pm = json.load(open(path))
+        if pm.get("build") != build:
+            return None, "%s was taken on another build (%s, this one is %s): not quoted" % (os.path.basename(path), pm.get("build"), build)
+        if pm["batch"] != batch or pm["launches_per_forward"] != launches_per_forward:
+            return None, "%s covers %d launches per forward at batch %d, this run has %d at batch %d: not quoted" % (
+                os.path.basename(path), pm["launches_per_forward"], pm["batch"], launches_per_forward, batch)
+        per = (pm["fetch_bytes_per_forward"] + pm["write_bytes_per_forward"]) / pm["launches_per_forward"]
+        return round(per), ("HBM bytes per conv launch (average over the %d launches of a forward, batch %d) from %s; algorithmic %.0f"
+                            % (pm["launches_per_forward"], pm["batch"], pm["source"], pm["algorithmic_bytes_per_forward"] / pm["launches_per_forward"]))
+    except (OSError, KeyError, ValueError, TypeError):
+        return None, None
+
+
 class SyncCounter:
     """counts the blocking device -> host reads (Tensor.item / tolist / cpu / numpy on a CUDA tensor) inside a `with` block: the host
     round trips of the grouping leg (VERDICT r2 #7)"""
@@ -360,18 +378,10 @@ def main():
                            "%d images embedded in the timed steps" % (timer.sampled_images, imgs_rank * args.steps)}
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, collected on this
     # kernel set at the same batch size); null when the configuration differs from the profiled one
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_conv_traffic.json")))
-        fresh = pm.get("build") == build_fingerprint()
-        if not fresh:
-            roof["traffic_note"] = "profiles/r03_pmc_conv_traffic.json was taken on another build (%s, this one is %s): not quoted" % (pm.get("build"), build_fingerprint())
-        if fresh and split and pm["batch"] == args.batch and pm["launches_per_forward"] == n_conv_per_fwd:
-            per = (pm["fetch_bytes_per_forward"] + pm["write_bytes_per_forward"]) / pm["launches_per_forward"]
-            roof["traffic"] = round(per)
-            roof["traffic_note"] = ("HBM bytes per conv launch (average over the %d launches of a forward, batch %d) from %s; algorithmic %.0f"
-                                    % (pm["launches_per_forward"], pm["batch"], pm["source"], pm["algorithmic_bytes_per_forward"] / pm["launches_per_forward"]))
-    except (OSError, KeyError, ValueError):
-        pass
+    if split:
+        roof["traffic"], note = pmc_traffic(os.path.join(ROOT, "profiles", "r03_pmc_conv_traffic.json"), build_fingerprint(), args.batch, n_conv_per_fwd)
+        if note:
+            roof["traffic_note"] = note
     if split:
         roof["peak_is"] = "fp16 dense MFMA peak %.1f / 3 products per fp32 multiply" % PEAK_FP16_MFMA_TF
         roof["executed_fp16_tflops"] = round(3.0 * conv_tf, 1)

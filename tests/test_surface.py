@@ -1,5 +1,7 @@
 """Small call-surface rows of SURVEY.md 8(a) that the big parity files do not exercise on their own:
 a3 extract_cnn_feature, a2 fliplr, a10 the generate_dataloader label join, the DeviceBackedArray handle rules."""
+import os
+
 import numpy as np
 import pytest
 
@@ -195,3 +197,29 @@ def test_fused_kernel_shape_gates():
                      (L.ssg_bottleneck_ds_nhwc_x, (None,) * 11 + (1, 64, 32, 256, 256, 64, None, None)),
                      (L.ssg_stem_pool_nchw_x, (None, 0, None, None, None, None, 1, 256, 64, None, None))):
         assert fn(*args) != 0 and b"unsupported" in L.ssg_last_error()
+
+
+def test_bench_quotes_pmc_traffic_only_for_its_own_build(tmp_path):
+    """bench.py's `roofline.traffic` comes from the PMC summary under profiles/; the summary carries the fingerprint of the kernel sources
+    it was measured on and is refused for any other build, launch set or batch size (a stale byte count must not be quoted)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("ssg_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    fp = bench.build_fingerprint()
+    assert len(fp) == 16 and fp == bench.build_fingerprint() and int(fp, 16) >= 0
+    rec = {"build": fp, "batch": 1000, "launches_per_forward": 37, "fetch_bytes_per_forward": 35.2e9, "write_bytes_per_forward": 18.8e9,
+           "algorithmic_bytes_per_forward": 41.9e9, "source": "unit test"}
+    path = tmp_path / "traffic.json"
+    path.write_text(json.dumps(rec))
+    got, note = bench.pmc_traffic(str(path), fp, 1000, 37)
+    assert got == round((35.2e9 + 18.8e9) / 37) and "37 launches" in note
+    assert bench.pmc_traffic(str(path), "0" * 16, 1000, 37)[0] is None and "another build" in bench.pmc_traffic(str(path), "0" * 16, 1000, 37)[1]
+    assert bench.pmc_traffic(str(path), fp, 512, 37)[0] is None and bench.pmc_traffic(str(path), fp, 1000, 35)[0] is None
+    assert bench.pmc_traffic(str(tmp_path / "missing.json"), fp, 1000, 37) == (None, None)
+    path.write_text("{not json")
+    assert bench.pmc_traffic(str(path), fp, 1000, 37) == (None, None)
+    # the committed summary belongs to the committed kernels
+    committed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_pmc_conv_traffic.json")
+    assert json.load(open(committed))["build"] == fp, "profiles/r03_pmc_conv_traffic.json is stale: re-run tools/pmc_embed.sh on the GPU box"
