@@ -100,7 +100,8 @@ int ssg_topk_rank(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, i
  * the round-2 kernel) and hands the shorter ranges that still intersect [0, K) to a one-wave-per-row tail kernel through ws.
  * ws: ssg_topk_rank_introsort_ws_bytes(N, nrows) bytes = the hand-over records (about 9 KB per row) plus, for rows that do not fit
  * in LDS (N > ~36 k), the global arena.  A caller that passes ssg_topk_rank_introsort_arena_bytes(N, nrows) bytes selects the
- * global-arena variant for any N (parity tests). */
+ * global-arena variant for any N (parity tests).  ws == NULL / fewer bytes than the hand-over records (the pre-round-3 calling
+ * convention for LDS-resident rows) is accepted: the replay then runs unsplit in one launch (slower); only the arena is mandatory. */
 size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows);
 size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows);
 int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws, size_t ws_bytes,
@@ -322,10 +323,14 @@ int ssg_preprocess_u8(const uint8_t* src, int B, int h, int w, int H, int W, con
  *   look [ntab][256] uint16 ((length << 8) | symbol of every code of at most 8 bits, 0 otherwise), maxcode [ntab][18], valoff [ntab][17],
  *   vals [ntab][256]: jdhuff.c's derived tables; qts [nqt][64] uint16 in natural order
  *   coef  workspace int16 [total_blocks][64] (zeroed by the call), planes workspace uint8 (sum of 64 * blocks), max_blocks / max_pixels =
- *         largest component (in blocks) / image (in pixels) of the batch; out: RGB bytes, H * W * 3 per image at its offset. */
+ *         largest component (in blocks) / image (in pixels) of the batch; out: RGB bytes, H * W * 3 per image at its offset.
+ *   status int32 [nimg] (zeroed by the call; round 4): non-zero = damaged entropy-coded data (bit 0: a zero run past coefficient 63,
+ *         bit 1: a segment ran out of data before its MCUs were decoded) -- the pixels of such a file are not libjpeg's; the caller
+ *         hands it to the reference's decoder (Pillow), which warns / raises like the reference. */
 int ssg_jpeg_decode_batch(const uint8_t* ecs, const int64_t* segs, int nseg, const int64_t* imgs, int nimg, const uint16_t* look,
                           const int32_t* maxcode, const int32_t* valoff, const uint8_t* vals, const uint16_t* qts, int16_t* coef,
-                          int64_t total_blocks, int max_blocks, uint8_t* planes, int max_pixels, uint8_t* out, ssg_stream_t stream);
+                          int64_t total_blocks, int max_blocks, uint8_t* planes, int max_pixels, uint8_t* out, int32_t* status,
+                          ssg_stream_t stream);
 /* x = sqrt(max(x, lo)) in place: with ssg_pairwise_sqdist_f32 the pairwise block of the fine-tune phase's TripletLoss
  * (reid/loss/triplet.py:28-31: dist = (|x|^2 + |x|^2' - 2 x x').clamp(min=1e-12).sqrt()) */
 int ssg_clamp_sqrt_f32(float* x, int64_t n, float lo, ssg_stream_t stream);

@@ -586,19 +586,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
 // 1 when ssg_bottleneck_nhwc_x / ssg_bottleneck_ds_nhwc_x has a kernel for this block shape (CIN == C: identity block):
 //   layer1 of ResNet-50 at 256x128 input: H x 32 x 256, MID 64 (identity blocks and the first block, CIN = 64), 4-row tiles;
 //   layer2 identity blocks: H x 16 x 512, MID 128, 8-row tiles (one 8-wave workgroup per CU: the 128-channel halo intermediate is 85 KB)
-static int launch_bottleneck2(const ssg::bneck::Params& p, hipStream_t stream);     // bottleneck2.hip
-// SSG_BNECK2=1: layer2 identity blocks on bottleneck2.hip (4-row tiles, two 4-wave workgroups per CU, conv2 / conv3 weights straight
-// into registers) instead of the 8-wave kernel above.  Measured in round 3 (B = 1000): 1.45 ms against 1.23 ms per block -- both
-// kernels sit at 8 waves per CU (250 VGPRs), and with one wave per SIMD and workgroup the load -> LDS -> barrier -> fragment chain of
-// conv1's 32 k-tiles is not hidden by a second workgroup either (phase accounting in DESIGN.md) -- so it stays an opt-in experiment.
-static bool use_bottleneck2() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SSG_BNECK2"); v = e ? atoi(e) : 0; }
-  return v != 0;
-}
 extern "C" int ssg_bottleneck_supported(int H, int W, int CIN, int C, int MID) {
   if (C == 256 && MID == 64 && (CIN == 256 || CIN == 64) && W == 32 && H > 0 && H % 4 == 0) return 1;
-  if (C == 512 && MID == 128 && CIN == 512 && W == 16 && H > 0 && H % (use_bottleneck2() ? 4 : 8) == 0) return 1;
+  if (C == 512 && MID == 128 && CIN == 512 && W == 16 && H > 0 && H % 8 == 0) return 1;
   return 0;
 }
 
@@ -632,7 +622,7 @@ extern "C" int ssg_bottleneck_nhwc_x(const void* x, const void* w1, const float*
   p.x = (const float*)x; p.out = (float*)out;
   p.w1 = (const float*)w1; p.b1 = b1; p.cs1 = cs1; p.w2 = (const float*)w2; p.b2 = b2; p.cs2 = cs2; p.w3 = (const float*)w3; p.b3 = b3; p.cs3 = cs3;
   p.B = B; p.H = H; p.overflow = overflow;
-  if (C == 512) return use_bottleneck2() ? launch_bottleneck2(p, stream) : launch_bottleneck<512, 128, 16, 8, 512, 8>(p, stream);
+  if (C == 512) return launch_bottleneck<512, 128, 16, 8, 512, 8>(p, stream);
   return launch_bottleneck<256, 64, 32, 4, 256, 4>(p, stream);
 }
 

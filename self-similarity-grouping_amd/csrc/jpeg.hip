@@ -42,10 +42,11 @@ struct BitReader {
   const uint8_t* base; int64_t pos, end;
   uint64_t cur, nxt; int64_t chunk;       // cur = bytes [8*chunk, 8*chunk+8) of the pool, nxt the following eight
   uint64_t acc; int n;
+  int pad;                                // zero bits fed since the data ran out (or a marker was hit): consuming any of them = a short segment
   __device__ __forceinline__ void init(const uint8_t* pool, int64_t off, int64_t len) {
     base = pool; pos = off; end = off + len; chunk = off >> 3;
     cur = *reinterpret_cast<const uint64_t*>(base + (chunk << 3)); nxt = *reinterpret_cast<const uint64_t*>(base + (chunk << 3) + 8);
-    acc = 0; n = 0;
+    acc = 0; n = 0; pad = 0;
   }
   __device__ __forceinline__ unsigned byte_at(int64_t q) {     // q in the current or the next chunk
     const int64_t c = q >> 3;
@@ -60,9 +61,9 @@ struct BitReader {
         if (b == 0xffu) {
           const unsigned nx = pos < end ? byte_at(pos) : 1u;
           if (nx == 0) pos++;
-          else { pos = end; b = 0; }
+          else { pos = end; b = 0; pad += 8; }
         }
-      }
+      } else pad += 8;
       acc = (acc << 8) | b; n += 8;
     }
   }
@@ -84,7 +85,8 @@ __device__ __forceinline__ int decode_symbol(BitReader& br, const Tables& t, int
 __device__ __forceinline__ int extend(int r, int s) { return r < (1 << (s - 1)) ? r - (1 << s) + 1 : r; }
 
 __global__ __launch_bounds__(64) void huffman_kernel(const uint8_t* __restrict__ ecs, const int64_t* __restrict__ segs, int nseg,
-                                                     const int64_t* __restrict__ imgs, Tables t, int16_t* __restrict__ coef) {
+                                                     const int64_t* __restrict__ imgs, Tables t, int16_t* __restrict__ coef,
+                                                     int32_t* __restrict__ status) {
   const int si = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (si >= nseg) return;
   const int64_t* sd = segs + (int64_t)si * SEG_WORDS;
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(64) void huffman_kernel(const uint8_t* __restrict__
   BitReader br;
   br.init(ecs, sd[1], sd[2]);
   int pred[3] = {0, 0, 0};
+  int bad = 0;                            // 1: a run pushed the coefficient index past 63 (libjpeg warns and writes elsewhere), 2: segment ran out of data
   const int mcu0 = (int)sd[3], mcu1 = mcu0 + (int)sd[4];
   for (int mcu = mcu0; mcu < mcu1; mcu++) {
     const int my = mcu / mcux, mx = mcu - my * mcux;
@@ -112,6 +115,7 @@ __global__ __launch_bounds__(64) void huffman_kernel(const uint8_t* __restrict__
             const int rs = decode_symbol(br, t, act), r = rs >> 4, sz = rs & 15;
             if (sz) {
               k += r;
+              bad |= (k > 63);
               blk[c_zigzag[k & 63]] = (int16_t)extend((int)br.get(sz), sz);
               k++;
             } else if (r == 15) k += 16;
@@ -120,6 +124,10 @@ __global__ __launch_bounds__(64) void huffman_kernel(const uint8_t* __restrict__
         }
     }
   }
+  // the host validated the tables (DC categories <= 15, jpeg.py), so every shift above is defined; what cannot be known before decoding
+  // is flagged per image and the host hands those files to Pillow (whose behaviour on damaged data is the reference's)
+  if (br.n < br.pad) bad |= 2;
+  if (bad) atomicOr(status + sd[0], bad);
 }
 
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
@@ -246,16 +254,20 @@ using namespace ssg;
 //                quantisation table index, DC table index, AC table index
 //   look / maxcode / valoff / vals    derived Huffman tables (jdhuff.c jpeg_make_d_derived_tbl), qts uint16 [nqt][64] natural order
 //   coef         workspace int16 [total blocks][64] (zeroed here), planes workspace uint8, out uint8 RGB pixels (H x W x 3 per image)
+//   status       int32 [nimg] (zeroed here): non-zero = the file's entropy-coded data is damaged (bit 0: a zero run past coefficient 63,
+//                bit 1: a segment ended before its MCUs were decoded); its pixels are then NOT what libjpeg produces -- the caller re-decodes
+//                such files with the reference's decoder, which warns / raises as the reference does
 extern "C" int ssg_jpeg_decode_batch(const uint8_t* ecs, const int64_t* segs, int nseg, const int64_t* imgs, int nimg, const uint16_t* look,
                                      const int32_t* maxcode, const int32_t* valoff, const uint8_t* vals, const uint16_t* qts, int16_t* coef,
-                                     int64_t total_blocks, int max_blocks, uint8_t* planes, int max_pixels, uint8_t* out, hipStream_t stream) {
-  if (nseg <= 0 || nimg <= 0 || total_blocks <= 0 || max_blocks <= 0 || max_pixels <= 0 || nimg > 21845) {
+                                     int64_t total_blocks, int max_blocks, uint8_t* planes, int max_pixels, uint8_t* out, int32_t* status, hipStream_t stream) {
+  if (!status || nseg <= 0 || nimg <= 0 || total_blocks <= 0 || max_blocks <= 0 || max_pixels <= 0 || nimg > 21845) {
     ssg_set_error("ssg_jpeg_decode_batch: bad shape (nseg=%d nimg=%d blocks=%lld)", nseg, nimg, (long long)total_blocks);
     return SSG_ERR_INVALID;
   }
   SSG_HIP(hipMemsetAsync(coef, 0, (size_t)total_blocks * 64 * sizeof(int16_t), stream));
+  SSG_HIP(hipMemsetAsync(status, 0, (size_t)nimg * sizeof(int32_t), stream));
   jpeg::Tables t{look, maxcode, valoff, vals};
-  hipLaunchKernelGGL(jpeg::huffman_kernel, dim3((nseg + 63) / 64), dim3(64), 0, stream, ecs, segs, nseg, imgs, t, coef);
+  hipLaunchKernelGGL(jpeg::huffman_kernel, dim3((nseg + 63) / 64), dim3(64), 0, stream, ecs, segs, nseg, imgs, t, coef, status);
   hipLaunchKernelGGL(jpeg::idct_kernel, dim3((max_blocks + 63) / 64, nimg * 3), dim3(64), 0, stream, imgs, coef, qts, planes);
   hipLaunchKernelGGL(jpeg::colour_kernel, dim3((max_pixels + 255) / 256, nimg), dim3(256), 0, stream, imgs, planes, out);
   SSG_LAUNCH_CHECK("jpeg kernels");

@@ -697,7 +697,7 @@ __host__ inline size_t tail_bytes(int nrows) { const int t = tail_threshold(); r
 template <bool LDS, int NT>
 __host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, uint32_t* arena, uint32_t* tails, hipStream_t stream) {
   const size_t lds = lds_fixed_bytes(N) + (LDS ? entry_words(N) * 4 : 0);
-  const int tailn = tail_threshold();
+  const int tailn = tails ? tail_threshold() : 0;             // no hand-over buffer: the unsplit single-launch kernel
   SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_introsort_kernel<LDS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((topk_introsort_kernel<LDS, NT>), dim3(LDS ? nrows : arena_blocks(nrows)), dim3(NT), lds, stream, D, rowmax, N, nrows, K,
                      mask_words(N), arena, entry_words(N), rank, tailn, tails, tail_stride_words(tailn));
@@ -737,13 +737,16 @@ extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax
   }
   const size_t tb = intro::tail_bytes(nrows), full = ssg_topk_rank_introsort_arena_bytes(N, nrows);
   const bool arena = !intro::fits_lds(N) || (ws != nullptr && ws_bytes >= full);       // (a caller may force the arena path by passing its size)
-  const size_t need = arena ? full : tb;
+  // LDS-resident rows need no workspace at all: without one (ws == NULL or too small for the hand-over records) the whole replay
+  // runs in the single-launch kernel, as before round 3 (slower: one wave finishes each row's tail); only the arena is mandatory
+  const bool split = tb > 0 && ws != nullptr && ws_bytes >= (arena ? full : tb);
+  const size_t need = arena ? (split ? full : full - tb) : 0;
   if (need > 0 && (ws == nullptr || ws_bytes < need)) {
     ssg_set_error("ssg_topk_rank_introsort: workspace of %zu bytes needed for N=%d, %d rows (got %zu): ssg_topk_rank_introsort_ws_bytes()", need, N, nrows, ws_bytes);
     return SSG_ERR_INVALID;
   }
-  uint32_t* tails = tb ? (uint32_t*)ws : nullptr;
-  uint32_t* ar = arena ? (uint32_t*)((unsigned char*)ws + tb) : nullptr;
+  uint32_t* tails = split ? (uint32_t*)ws : nullptr;
+  uint32_t* ar = arena ? (uint32_t*)((unsigned char*)ws + (split ? tb : 0)) : nullptr;
   static int nt = -1;
   if (nt < 0) { const char* e_ = getenv("SSG_INTRO_NT"); nt = e_ ? atoi(e_) : 512; }
   int rc;

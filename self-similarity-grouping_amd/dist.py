@@ -33,17 +33,19 @@ def shard_bounds(n, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-_FLAT_OK = {}       # backend name -> does it implement all_gather_into_tensor (probed once per backend, never per call)
+_FLAT_OK = {}       # (backend name, ranks of the group) -> does it implement all_gather_into_tensor (probed once per group, never per call)
 
 
 def _flat_gather_supported(group):
-    """Decided ONCE per backend on a 1-element tensor: a per-call try/except would let a rank-local failure (OOM, an async RCCL
+    """Decided ONCE per group on a 1-element tensor: a per-call try/except would let a rank-local failure (OOM, an async RCCL
     error) send one rank into the list-form collective while its peers sit in the flat one -- mismatched collectives hang and
-    hide the original error.  Every rank runs the same probe at the same point (the first gather of the group), so they agree."""
+    hide the original error.  The probe is itself a collective, so the cache is keyed by the group's membership: every member of
+    a group probes at that group's first gather (a per-backend key would let ranks that already probed through another group
+    skip a collective their peers still run)."""
     import torch.distributed as dist
-    be = str(dist.get_backend(group))
+    be = (str(dist.get_backend(group)), tuple(dist.get_process_group_ranks(group if group is not None else dist.group.WORLD)))
     if be not in _FLAT_OK:
-        dev = torch.device("cuda", torch.cuda.current_device()) if be == "nccl" else torch.device("cpu")
+        dev = torch.device("cuda", torch.cuda.current_device()) if be[0] == "nccl" else torch.device("cpu")
         ws = dist.get_world_size(group)
         try:
             dist.all_gather_into_tensor(torch.empty(ws, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev), group=group)

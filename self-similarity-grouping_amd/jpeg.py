@@ -35,7 +35,17 @@ class _Header(object):
 
 
 def scan_header(buf):
-    """marker walk of one file -> _Header (raises NotBaseline for anything the GPU decoder does not take)"""
+    """marker walk of one file -> _Header (raises NotBaseline for anything the GPU decoder does not take, including files whose
+    marker segments are short, truncated or inconsistent: those go to Pillow, which raises what the reference would raise)"""
+    try:
+        return _scan_header(buf)
+    except (IndexError, struct.error, ValueError, KeyError) as e:
+        if isinstance(e, NotBaseline):
+            raise
+        raise NotBaseline("malformed marker segment (%s)" % (e,))
+
+
+def _scan_header(buf):
     mv = memoryview(buf)
     n = len(mv)
     if n < 4 or mv[0] != 0xFF or mv[1] != 0xD8:
@@ -43,6 +53,7 @@ def scan_header(buf):
     h = _Header()
     h.qt, h.dc, h.ac, h.ri, h.comps, h.scan = {}, {}, {}, 0, None, None
     adobe = None
+    jfif = False
     p = 2
     while True:
         while p < n and mv[p] != 0xFF:
@@ -57,6 +68,8 @@ def scan_header(buf):
         if marker == 0xD9 or p + 2 > n:
             raise NotBaseline("no scan")
         (length,) = struct.unpack_from(">H", mv, p)
+        if length < 2 or p + length > n:
+            raise NotBaseline("segment length past the end of the file")
         body = bytes(mv[p + 2:p + length])
         p += length
         if marker == 0xDB:                                   # DQT
@@ -77,7 +90,17 @@ def scan_header(buf):
                 cls, tid = body[q] >> 4, body[q] & 15
                 counts = body[q + 1:q + 17]
                 total = sum(counts)
-                (h.ac if cls else h.dc)[tid] = (bytes(counts), bytes(body[q + 17:q + 17 + total]))
+                symbols = bytes(body[q + 17:q + 17 + total])
+                # jdhuff.c jpeg_make_d_derived_tbl / jdmarker.c get_dht raise JERR_BAD_HUFF_TABLE for these: leave them to Pillow
+                if len(counts) != 16 or total > 256 or len(symbols) != total or cls > 1 or tid > 3 or (cls == 0 and any(v > 15 for v in symbols)):
+                    raise NotBaseline("bad Huffman table")
+                code = 0
+                for length, cnt in enumerate(counts, 1):     # more codes of a length than the code space holds
+                    code += cnt
+                    if code > (1 << length):
+                        raise NotBaseline("bad Huffman table")
+                    code <<= 1
+                (h.ac if cls else h.dc)[tid] = (bytes(counts), symbols)
                 q += 17 + total
         elif marker in (0xC0, 0xC1):                         # baseline / extended sequential, Huffman
             if body[0] != 8:
@@ -90,6 +113,8 @@ def scan_header(buf):
             (h.ri,) = struct.unpack_from(">H", body, 0)
         elif marker == 0xEE and body[:5] == b"Adobe" and len(body) >= 12:
             adobe = body[11]
+        elif marker == 0xE0 and body[:5] == b"JFIF\0":
+            jfif = True
         elif marker == 0xDA:                                 # SOS: must be the single scan of a sequential file
             if h.comps is None:
                 raise NotBaseline("scan before frame")
@@ -105,6 +130,10 @@ def scan_header(buf):
             break
     ncomp = len(h.comps)
     if ncomp == 3:
+        # jdapimin.c default_decompress_parms: without a JFIF or Adobe marker, component ids 'R','G','B' mean the data IS RGB (no colour
+        # transform); any other id triple than (1, 2, 3) makes libjpeg emit a trace message and assume YCbCr, like here
+        if not jfif and adobe is None and [c[0] for c in h.comps] == [82, 71, 66]:
+            raise NotBaseline("RGB component ids")
         if adobe not in (None, 1) or h.comps[1][1:3] != (1, 1) or h.comps[2][1:3] != (1, 1) or h.comps[0][1:3] not in ((1, 1), (2, 1), (2, 2)):
             raise NotBaseline("colour transform / sampling factors")
     elif ncomp == 1:
@@ -222,10 +251,17 @@ def decode_batch(files, device=None):
     coef = torch.empty(blocks * 64, dtype=torch.int16, device=device)
     planes = torch.empty(max(plane_off, 1), dtype=torch.uint8, device=device)
     rgb = torch.empty(out_off, dtype=torch.uint8, device=device)
+    status = torch.empty(len(hdrs), dtype=torch.int32, device=device)
     check(L.ssg_jpeg_decode_batch(ptr(pool_d), ptr(segs_d), int(segs.shape[0]), ptr(imgs_d), len(hdrs), ptr(look_d), ptr(maxcode_d), ptr(valoff_d), ptr(vals_d),
-                                  ptr(qts_d), ptr(coef), blocks, max_blocks, ptr(planes), max_pixels, ptr(rgb), stream()), "ssg_jpeg_decode_batch")
+                                  ptr(qts_d), ptr(coef), blocks, max_blocks, ptr(planes), max_pixels, ptr(rgb), ptr(status), stream()), "ssg_jpeg_decode_batch")
+    damaged = set(torch.nonzero(status).flatten().tolist())     # one small read-back per batch (the pixels are consumed on the device)
     for k, (i, h) in enumerate(hdrs):
+        if k in damaged:
+            # short / corrupt entropy-coded data: Pillow decodes (or raises "image file is truncated") exactly like the reference
+            out[i] = torch.from_numpy(np.array(_pillow_rgb(files[i]))).to(device)
+            stats["pillow"] += 1; stats["damaged"] = stats.get("damaged", 0) + 1
+            continue
         o = int(imgs[k, 7])
         out[i] = rgb[o:o + h.width * h.height * 3].view(h.height, h.width, 3)
-    stats["gpu"] += len(hdrs)
+    stats["gpu"] += len(hdrs) - len(damaged)
     return out

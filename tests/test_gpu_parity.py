@@ -217,6 +217,25 @@ def test_introsort_rank_vs_numpy_argsort(N, dev, ora):
         assert np.array_equal(got[r], np.argsort(keys[r].view(np.float16), kind="stable")[:K]), (N, r)
 
 
+def test_introsort_rank_without_workspace(dev):
+    """the pre-round-3 calling convention (ws = NULL for rows that fit in LDS) still works -- the replay then runs unsplit
+    in the single-launch kernel -- and gives the same ranking as the split (workspace) path."""
+    from ssg_amd import _lib
+    from ssg_amd._lib import check, ptr, stream
+    L = _lib.lib()
+    rng = np.random.default_rng(4)
+    N, K = 6000, 21
+    keys = np.stack([rng.integers(0, nv, N) for nv in (3, 40, 700, 12000)]).astype(np.uint16)
+    D = torch.from_numpy(keys.view(np.int16)).to(dev).view(torch.float16)
+    rowmax = torch.full((4,), 0x3C00, dtype=torch.int32, device=dev)
+    rank = torch.empty((4, K), dtype=torch.int32, device=dev)
+    check(L.ssg_topk_rank_introsort(ptr(D), ptr(rowmax), N, 4, K, ptr(rank), None, 0, stream()), "ssg_topk_rank_introsort(ws=NULL)")
+    got = rank.cpu().numpy()
+    for r in range(4):
+        assert np.array_equal(got[r], np.argsort(keys[r].view(np.float16))[:K]), r
+    assert np.array_equal(got, _rank_rows(keys, K, dev))
+
+
 @pytest.mark.parametrize("n", [100, 300, 1000, 3000])
 def test_introsort_rank_heapsort_fallback(n, dev):
     """keys built by an adversary against median-of-3 quicksort (tools/antiqsort.py): numpy's argsort runs out of its
@@ -875,7 +894,7 @@ def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkey
     """ssg_stem_pool_nchw_x (image -> conv1 + bn + relu -> maxpool in one launch) and ssg_bottleneck[_ds]_nhwc_x (a whole layer1
     block in one launch) against the launch-per-layer path they replace: same k-steps, product order and epilogues, so the
     layer4 map must be bit-identical.  H = 104: ragged last strip of the stem, layer1 / layer2 heights 26 / 13 have no fused block
-    kernel (fall back per block); H = 96: short images, layer1 height 24 is fused, layer2 height 12 falls back (fused too with SSG_BNECK2=1)."""
+    kernel (fall back per block); H = 96: short images, layer1 height 24 is fused, layer2 height 12 falls back."""
     import ssg_amd
     from ssg_amd import _lib
     m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, seed=5).cuda().eval()
@@ -883,7 +902,7 @@ def test_fused_stem_and_bottleneck_match_the_separate_launches(B, H, dev, monkey
     L = _lib.lib()
     assert L.ssg_stem_pool_supported(H, 128) == 1 and L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64) == (1 if (H // 4) % 4 == 0 else 0)
     assert L.ssg_bottleneck_supported(H // 4, 32, 64, 256, 64) == L.ssg_bottleneck_supported(H // 4, 32, 256, 256, 64)
-    assert L.ssg_bottleneck_supported(32, 16, 512, 512, 128) == 1 and L.ssg_bottleneck_supported(26, 16, 512, 512, 128) == 0   # layer2 identity blocks: 8-row tiles (4-row tiles with SSG_BNECK2=1)
+    assert L.ssg_bottleneck_supported(32, 16, 512, 512, 128) == 1 and L.ssg_bottleneck_supported(26, 16, 512, 512, 128) == 0   # layer2 identity blocks: 8-row tiles
     assert L.ssg_bottleneck_supported(16, 8, 1024, 1024, 256) == 0        # layer3 / layer4: separate launches
     maps = {}
     for stem, bneck in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
@@ -1021,6 +1040,39 @@ def test_jpeg_decode_vs_pillow_golden(golden, dev):
         assert out[i].dtype == torch.uint8 and out[i].is_cuda
         assert np.array_equal(out[i].cpu().numpy(), g["rgb_%02d" % i]), i
     assert np.array_equal(out[n].cpu().numpy(), g["progressive_rgb"])
+
+
+def test_jpeg_damaged_files_behave_like_pillow(golden, dev):
+    """damaged entropy-coded data must not come back as plausible pixels.  A file cut short inside its scan is flagged by the
+    Huffman kernel's per-image status word and handed to Pillow, which raises "image file is truncated" exactly like the reference's
+    Image.open(...).convert('RGB'); a file whose scan is short but still ends in EOI decodes to what Pillow produces (libjpeg feeds
+    zeros); the undamaged files of the same batch are unaffected."""
+    import io
+    from PIL import Image
+    from ssg_amd import jpeg as pj
+    g = golden("jpeg_cases.npz")
+    good = [g["file_%02d" % i].tobytes() for i in range(4)]
+    victim = good[1]
+    h = pj.scan_header(victim)
+    cut = victim[:h.ecs_start + (h.ecs_end - h.ecs_start) // 2]
+    with pytest.raises(OSError):
+        Image.open(io.BytesIO(cut)).convert("RGB")
+    with pytest.raises(OSError):
+        pj.decode_batch([good[0], cut, good[2]])
+    short = cut + b"\xff\xd9"                   # half the scan, then EOI: libjpeg pads with zeros and warns, Pillow returns pixels
+    try:
+        ref = np.asarray(Image.open(io.BytesIO(short)).convert("RGB"))
+    except OSError:
+        ref = None
+    before = pj.stats.get("damaged", 0)
+    if ref is None:
+        with pytest.raises(OSError):
+            pj.decode_batch([good[0], short, good[2]])
+    else:
+        out = pj.decode_batch([good[0], short, good[2]])
+        assert np.array_equal(out[1].cpu().numpy(), ref)
+        assert np.array_equal(out[0].cpu().numpy(), g["rgb_00"]) and np.array_equal(out[2].cpu().numpy(), g["rgb_02"])
+    assert pj.stats.get("damaged", 0) == before + 1
 
 
 def test_jpeg_decode_generated_files_and_loader(dev, ora, tmp_path):

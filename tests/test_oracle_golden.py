@@ -267,3 +267,44 @@ def test_jpeg_host_parser_matches_oracle(golden):
     for bad in (g["progressive_file"].tobytes(), b"\x89PNG\r\n\x1a\n" + bytes(32), b""):
         with pytest.raises(pj.NotBaseline):
             pj.scan_header(bad)
+
+
+def test_jpeg_host_parser_hands_malformed_files_to_pillow(golden):
+    """a short / odd marker segment must never abort the batch with IndexError / struct.error -- every truncation and a set of
+    corrupted headers either parses (damage inside the entropy-coded data is caught on the device) or raises NotBaseline (-> Pillow);
+    3-component files whose ids spell 'RGB' without a JFIF / Adobe marker are RGB for libjpeg (no colour transform): refused too."""
+    from ssg_amd import jpeg as pj
+    g = golden("jpeg_cases.npz")
+    data = g["file_00"].tobytes()
+    hdr = pj.scan_header(data)
+    for cut in list(range(0, hdr.ecs_start + 4)) + list(range(hdr.ecs_start + 4, len(data), 97)):
+        try:
+            pj.scan_header(data[:cut])
+        except pj.NotBaseline:
+            pass
+    rng = np.random.default_rng(3)
+    for _ in range(300):                       # random byte damage inside the header region
+        b = bytearray(data)
+        for q in rng.integers(2, hdr.ecs_start, int(rng.integers(1, 4))):
+            b[int(q)] = int(rng.integers(0, 256))
+        try:
+            pj.scan_header(bytes(b))
+        except pj.NotBaseline:
+            pass
+    # a DC table with a category > 15 is JERR_BAD_HUFF_TABLE in libjpeg
+    q = data.index(b"\xff\xc4")
+    b = bytearray(data); b[q + 4 + 17] = 200
+    assert (b[q + 4] >> 4) == 0
+    with pytest.raises(pj.NotBaseline):
+        pj.scan_header(bytes(b))
+    # component ids R, G, B and no JFIF / Adobe marker
+    q = data.index(b"\xff\xc0")
+    b = bytearray(data)
+    assert b[q + 9] == 3
+    b[q + 10], b[q + 13], b[q + 16] = 82, 71, 66
+    s = data.index(b"\xff\xda"); b[s + 5], b[s + 7], b[s + 9] = 82, 71, 66
+    j = data.index(b"\xff\xe0"); b[j + 4:j + 8] = b"XXXX"
+    with pytest.raises(pj.NotBaseline):
+        pj.scan_header(bytes(b))
+    b[j + 4:j + 8] = b"JFIF"                   # with the JFIF marker the ids do not matter: YCbCr
+    pj.scan_header(bytes(b))

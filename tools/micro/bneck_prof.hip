@@ -7,7 +7,6 @@
 #include <algorithm>
 #include "ssg_api.hip"
 #include "bottleneck.hip"
-static int launch_bottleneck2(const ssg::bneck::Params&, hipStream_t) { return -1; }   // (bottleneck2.hip is not part of this build)
 
 static void fill_halves(std::vector<uint16_t>& v, unsigned seed, int emin, int espan) {
   unsigned s = seed;
