@@ -76,6 +76,36 @@ def test_bench_dimension_stages_vs_oracle(N, Ns, dev, ora):
     assert torch.equal(rerank.source_vector(s, t), rerank.source_vector(s, t, exact_gemm=True))
 
 
+def test_bench_width_vs_reference_golden(golden, dev):
+    """the HIP path against the UNTOUCHED reference at the bench's feature width -- tests/golden/rerank_wide_d2048_ref.npz
+    (tools/make_golden.py --only-wide: reid/rerank.py re_ranking at N = Ns = 2000, d = 2048, hard set, lambda = 0.3, numpy's default
+    argsort; eps rule of selftraining.py:289-293; sklearn DBSCAN).  No oracle in between: euclidean_dist and final_dist by sha256 of
+    the materialised matrices, the rank columns, the source vector, eps, labels."""
+    import hashlib
+    from ssg_amd import rerank, cluster
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    g = golden("rerank_wide_d2048_ref.npz")
+    N, Ns, d = int(g["N"]), int(g["Ns"]), int(g["d"])
+    tgt = hard_clustered(N, d, int(g["seed_tgt"])); src = hard_clustered(Ns, d, int(g["seed_src"]), intra=float(g["intra_src"]))
+    assert sha(tgt) == str(g["sha_tgt"]) and sha(src) == str(g["sha_src"])
+    st = {}
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k1=int(g["k1"]), k2=int(g["k2"]),
+                                 lambda_value=float(g["lambda_value"]), stages=st)
+    assert sha(h.euclid.cpu().numpy()) == str(g["sha_euclid"]), "euclidean_dist (int8 Gram at d = 2048) vs the reference's cdist"
+    assert np.array_equal(st["rank"].cpu().numpy()[:, :21], g["rank"]), "initial_rank[:, :21] in numpy's introsort order"
+    v = st["v"].cpu().numpy()
+    assert np.array_equal((v + v[0]).astype(np.float64), g["v"]), "source vector"
+    final = h.final_dist().cpu().numpy()
+    assert np.array_equal(final[0], g["final_row0"]) and np.array_equal(np.diag(final), g["final_diag"])
+    assert sha(final) == str(g["sha_final"]), "final_dist vs the reference"
+    eps, cnt, top = cluster.eps_rule(h, float(g["rho"]))
+    assert (eps, cnt, top) == (float(g["eps"]), int(g["count"]), int(g["top_num"]))
+    assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h), g["labels"])
+    # the drop-in numpy API on the same inputs
+    e2, f2 = rerank.re_ranking(src, tgt, k1=int(g["k1"]), k2=int(g["k2"]), lambda_value=float(g["lambda_value"]))
+    assert sha(e2) == str(g["sha_euclid"]) and sha(np.asarray(f2)) == str(g["sha_final"])
+
+
 @pytest.mark.parametrize("kind", ["track_g", "hard"])
 def test_headline_size_labels_vs_oracle(kind, dev, ora):
     """BASELINE configs[1]+[2] at the size the bench is quoted on: N = 16 000 (DukeMTMC-size), Ns = 12 936 (Market

@@ -483,6 +483,16 @@ def test_conv_split_half_vs_fp64(cfg, L, dev):
     (400, 16, 8, 1024, 256, 1, 1, 0, False),       # layer3 conv1: K = 1024 streamed from HBM
     (420, 16, 8, 96, 256, 3, 1, 1, False),         # K = 864: 54 k-tiles, two left over after the four-stage rounds; ragged last tile (M = 53 760)
     (400, 16, 8, 256, 1024, 1, 1, 0, True),        # conv3 + residual: 128 x 256 tiles (three stages) at this size
+    # round 4: the layer2 and layer4 shapes of the unfused path as well
+    (400, 32, 16, 512, 128, 1, 1, 0, False),       # layer2 conv1
+    (400, 32, 16, 128, 128, 3, 1, 1, False),       # layer2 3x3
+    (400, 32, 16, 128, 512, 1, 1, 0, True),        # layer2 conv3 + residual
+    (300, 64, 32, 128, 128, 3, 2, 1, False),       # layer2 first block: 3x3 stride 2
+    (400, 32, 16, 256, 256, 3, 2, 1, False),       # layer3 first block: 3x3 stride 2
+    (400, 8, 4, 2048, 512, 1, 1, 0, False),        # layer4 conv1
+    (400, 8, 4, 512, 512, 3, 1, 1, False),         # layer4 3x3
+    (400, 8, 4, 512, 2048, 1, 1, 0, True),         # layer4 conv3 + residual
+    (400, 16, 8, 512, 512, 3, 2, 1, False),        # layer4 first block: 3x3 stride 2
 ])
 def test_conv_tile_shapes_agree_bitwise(cfg, L, dev):
     """The tile shape is a launch-time choice (conv.hip launch_conv_wide: 256 x 256 tiles with four LDS stages when at least 200
@@ -521,6 +531,48 @@ def test_conv_tile_shapes_agree_bitwise(cfg, L, dev):
         ref = ref + r[:2].cpu().permute(0, 3, 1, 2).double()
     ref = torch.relu(ref)
     assert (dec.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("cfg", [
+    (400, 32, 16, 128, 64, 32, 256, 2, 512),       # layer2 first block: conv3 (128 ch) | downsample (256 ch at stride 2) -> 512
+    (400, 16, 8, 256, 32, 16, 512, 2, 1024),       # layer3 first block
+    (400, 8, 4, 512, 16, 8, 1024, 2, 2048),        # layer4 first block
+    (200, 64, 32, 64, 64, 32, 64, 1, 256),         # layer1 first block (stride-1 downsample), the unfused fallback
+])
+def test_conv_dual_tile_shapes_agree_bitwise(cfg, L, dev):
+    """the DUAL instantiation (conv3 | downsample as one GEMM over the concatenated K, ssg_conv1x1_dual_nhwc_x) --
+    a large batch (conv_dma_kernel<256, false, 128, true>, 128 x 256 tiles) must equal the same images in small batches (the
+    register-staged kernel on short tiles) bit for bit, twice in a row (the LDS-DMA race of round 3 showed up run to run), and a
+    float64 convolution of two images."""
+    from ssg_amd._lib import check, ptr, stream
+    from ssg_amd.resnet import _h8l8, _row_scales
+    B, H, W, Cin, H2, W2, Cin2, s2, Cout = cfg
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    o = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    x = torch.randn(B, H2, W2, Cin2, generator=g).to(dev)
+    w3 = torch.randn(Cout, Cin, generator=g) * (1.0 / Cin) ** 0.5
+    wd = torch.randn(Cout, Cin2, generator=g) * (1.0 / Cin2) ** 0.5
+    wcat = torch.cat([w3, wd], 1)
+    sc = _row_scales(wcat)
+    ws = _h8l8(wcat * sc.view(-1, 1)).to(dev)
+    cs = (1.0 / sc).contiguous().to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    os_ = torch.empty_like(o); check(L.ssg_h8l8_encode(ptr(o), ptr(os_), o.numel(), 1.0, stream()), "enc")
+    xs = torch.empty_like(x); check(L.ssg_h8l8_encode(ptr(x), ptr(xs), x.numel(), 1.0, stream()), "enc")
+
+    def run(lo, hi):
+        out = torch.empty(hi - lo, H, W, Cout, device=dev)
+        check(L.ssg_conv1x1_dual_nhwc_x(ptr(os_[lo:hi]), ptr(xs[lo:hi]), ptr(ws), ptr(bias), ptr(out), hi - lo, H, W, Cin, H2, W2, Cin2, s2, Cout, 1, 3,
+                                        1.0, ptr(cs), None, stream()), "dual")
+        return out
+    big = run(0, B)
+    small = torch.cat([run(lo, min(lo + 40, B)) for lo in range(0, B, 40)], 0)
+    assert torch.equal(big.view(torch.int32), small.view(torch.int32))
+    assert torch.equal(run(0, B).view(torch.int32), big.view(torch.int32))
+    dec = torch.empty_like(big[:2]); check(L.ssg_h8l8_decode(ptr(big[:2].contiguous()), ptr(dec), dec.numel(), 1.0, stream()), "dec")
+    ref = torch.einsum("bhwc,oc->bhwo", o[:2].cpu().double(), w3.double()) + torch.einsum("bhwc,oc->bhwo", x[:2, ::s2, ::s2][:, :H, :W].cpu().double(), wd.double())
+    ref = torch.relu(ref + bias.cpu().double())
+    assert (dec.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("precision", ["split", "f32"])

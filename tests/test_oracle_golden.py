@@ -50,6 +50,28 @@ def test_rerank_stages_match_reference(name, golden, ora):
     assert np.array_equal(ora.dbscan(f, eps, 4), g["labels"])
 
 
+def test_rerank_at_bench_width_matches_reference(golden, ora):
+    """the oracle at the bench's feature width (d = 2048: 2048-term float64 cdist sums, rerank.py:37,61) against the
+    UNTOUCHED reference run by tools/make_golden.py (--only-wide) at N = Ns = 2000 on the hard set, lambda = 0.3: every N x N
+    stage by sha256, the first 21 rank columns, the source vector, eps and sklearn's labels.  The inputs are regenerated from their
+    seeds (tools/synth.py) and checked against the stored sha256."""
+    from conftest import hard_clustered
+    g = golden("rerank_wide_d2048_ref.npz")
+    N, Ns, d = int(g["N"]), int(g["Ns"]), int(g["d"])
+    tgt = hard_clustered(N, d, int(g["seed_tgt"])); src = hard_clustered(Ns, d, int(g["seed_src"]), intra=float(g["intra_src"]))
+    assert sha(tgt) == str(g["sha_tgt"]) and sha(src) == str(g["sha_src"]), "tools/synth.py no longer reproduces the fixture's inputs"
+    ora.set_num_threads(min(os.cpu_count() or 8, 16))
+    e, f, st = ora.re_ranking(src, tgt, k1=int(g["k1"]), k2=int(g["k2"]), lambda_value=float(g["lambda_value"]), rank_mode="introsort", stages=True)
+    assert sha(e) == str(g["sha_euclid"]), "euclidean_dist"
+    assert np.array_equal(st["rank"][:, :21], g["rank"]), "initial_rank[:, :21]"
+    assert sha(st["V"]) == str(g["sha_V"]) and sha(st["V_qe"]) == str(g["sha_Vqe"]) and sha(st["jaccard"]) == str(g["sha_jaccard"])
+    assert sha(f) == str(g["sha_final"]), "final_dist"
+    assert np.array_equal((st["v"] + st["v"][0]).astype(np.float64), g["v"])
+    eps, cnt, top = ora.eps_rule(f, float(g["rho"]))
+    assert eps == float(g["eps"]) and cnt == int(g["count"]) and top == int(g["top_num"])
+    assert np.array_equal(ora.dbscan(f, eps, 4), g["labels"])
+
+
 @pytest.mark.parametrize("name", ["norerank_n256.npz", "norerank_n1024.npz"])
 def test_norerank_path(name, golden, ora):
     g = golden(name)

@@ -24,6 +24,7 @@ import numpy as np
 sys.dont_write_bytecode = True
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
 
@@ -428,6 +429,38 @@ def variant_fixtures(mod):
     return ok
 
 
+def wide_fixture(mod):
+    """the UNTOUCHED reference at the bench's feature width -- N = 2000, Ns = 2000, d = 2048 on the hard set
+    (tools/synth.hard_clustered, lambda = 0.3): the 2048-term float64 cdist sums (rerank.py:37,61), the introsort tie order at
+    N = 2000, eps and sklearn's labels.  The inputs are regenerated from their seeds by the tests (their sha256 is stored);
+    the N x N outputs are stored as sha256 + the first 21 rank columns + eps + labels (small)."""
+    import synth
+    N, Ns, d, lam, rho = 2000, 2000, 2048, 0.3, 1.6e-3
+    tgt = synth.hard_clustered(N, d, 31); src = synth.hard_clustered(Ns, d, 32, intra=0.7)
+    e, f, cap = run_ref(mod, src, tgt, False, k1=20, k2=6, lambda_value=lam)
+    ora.set_num_threads(8)
+    oe, of, st = ora.re_ranking(src, tgt, k1=20, k2=6, lambda_value=lam, rank_mode="introsort", stages=True)
+    chk = dict(euclid=beq(e, oe), rank=beq(cap["rank"], st["rank"]), V=beq(cap["V"], st["V"]), V_qe=beq(cap["V_qe"], st["V_qe"]),
+               jaccard=beq(cap["jaccard"], st["jaccard"]), final=beq(f, of))
+    eps, cnt, top = eps_rule_ref(f, rho)
+    oeps, ocnt, otop = ora.eps_rule(f, rho)
+    labels = DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(f)
+    chk.update(eps=(float(eps) == oeps and cnt == ocnt and top == otop), labels=beq(labels, ora.dbscan(f, eps, 4)))
+    allh, npx, cr, bad = exp_quirk_inputs()
+    used = set(np.unique((-cap["Dn"][cap["V"] != 0]).view(np.uint16)).tolist())
+    quirky = bool(used & set(int(b) for b in bad))
+    print("wide d=2048 N=%d Ns=%d oracle==reference: %s exp-quirk=%s eps=%.6f clusters=%d noise=%d" % (
+        N, Ns, chk, quirky, eps, labels.max() + 1, int((labels < 0).sum())))
+    # source vector exactly as the reference forms it (rerank.py:36-40) = row 0 of the captured source_dist
+    np.savez_compressed(os.path.join(OUT, "rerank_wide_d2048_ref.npz"), N=N, Ns=Ns, d=d, seed_tgt=31, seed_src=32, intra_src=0.7,
+                        lambda_value=lam, rho=rho, k1=20, k2=6, sha_tgt=sha(tgt), sha_src=sha(src), sha_euclid=sha(e), sha_final=sha(f),
+                        sha_V=sha(cap["V"]), sha_Vqe=sha(cap["V_qe"]), sha_jaccard=sha(cap["jaccard"]),
+                        rank=cap["rank"].astype(np.int32), v=cap["source_dist_row0"].astype(np.float64),
+                        euclid_row0=e[0].copy(), final_row0=f[0].copy(), final_diag=np.diag(f).copy(),
+                        eps=np.float64(eps), count=cnt, top_num=top, labels=labels.astype(np.int64), exp_quirk=quirky)
+    return all(chk.values()) and not quirky
+
+
 def preprocess_fixture():
     """tests/golden/preprocess.npz: decoded-image inputs and what the reference's extraction transform makes of them
     (selftraining.py:43-47 via reid/utils/data/preprocessor.py:22-30).  The resize is run with PIL itself (what
@@ -481,6 +514,10 @@ def main():
         sys.exit(0 if ok else 1)
     ora.build(force=True)
     mod = load_ref_rerank()
+    if "--only-wide" in sys.argv:         # regenerate just tests/golden/rerank_wide_d2048_ref.npz
+        ok = wide_fixture(mod)
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     if "--only-tiefree" in sys.argv:      # regenerate just tests/golden/rerank_tiefree_*.npz and rerank_var_*.npz
         ok = tiefree_fixture(mod)
         ok = variant_fixtures(mod) and ok
@@ -598,6 +635,7 @@ def main():
     ok = pairwise_fixture() and ok
     ok = jpeg_fixture() and ok
     ok = plain_fixture() and ok
+    ok = wide_fixture(mod) and ok
     print("ALL OK" if ok else "ORACLE MISMATCH")
     sys.exit(0 if ok else 1)
 
