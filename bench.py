@@ -97,6 +97,45 @@ class SyncCounter:
             setattr(torch.Tensor, k, fn)
 
 
+class CollectiveCounter:
+    """counts the torch.distributed collectives (and the bytes this rank contributes / receives) issued inside a `with` block: the
+    exchange steps of one sharded grouping leg (VERDICT r3 #6).  World 1 issues none."""
+
+    NAMES = ("all_gather_into_tensor", "all_gather", "all_reduce", "all_gather_object", "broadcast", "barrier")
+
+    def __init__(self):
+        self.calls, self.bytes_out, self.bytes_in = {}, 0, 0
+
+    def __enter__(self):
+        import torch.distributed as tdist
+        self._d, self._orig = tdist, {k: getattr(tdist, k) for k in self.NAMES}
+        me = self
+
+        def wrap(name):
+            fn = self._orig[name]
+
+            def counted(*a, **kw):
+                me.calls[name] = me.calls.get(name, 0) + 1
+                if name == "all_gather_into_tensor":
+                    me.bytes_in += a[0].numel() * a[0].element_size(); me.bytes_out += a[1].numel() * a[1].element_size()
+                elif name == "all_gather":
+                    me.bytes_in += sum(t.numel() * t.element_size() for t in a[0]); me.bytes_out += a[1].numel() * a[1].element_size()
+                elif name == "all_reduce":
+                    me.bytes_in += a[0].numel() * a[0].element_size(); me.bytes_out += a[0].numel() * a[0].element_size()
+                return fn(*a, **kw)
+            return counted
+        for k in self.NAMES:
+            setattr(tdist, k, wrap(k))
+        return self
+
+    def __exit__(self, *exc):
+        for k, fn in self._orig.items():
+            setattr(self._d, k, fn)
+
+    def summary(self):
+        return {"calls": dict(self.calls), "n": sum(self.calls.values()), "bytes_sent": self.bytes_out, "bytes_received": self.bytes_in}
+
+
 class KernelTimer:
     """HIP-event timing of individual C-ABI launches on the stream they are launched on."""
 
@@ -339,8 +378,9 @@ def main():
                                           "noise": int((l_o < 0).sum()), "eps": e_o}
         del so, to
 
-    # host round trips of one grouping leg (re-rank + eps rule + DBSCAN), counted on an extra untimed pass
-    with SyncCounter() as sc:
+    # host round trips and collectives of one grouping leg (re-rank + eps rule + DBSCAN), counted on an extra untimed pass -- on every
+    # rank, at any world size (the sharded path adds its own blocking reads: sizes of the ragged candidate / edge blocks)
+    with CollectiveCounter() as cc, SyncCounter() as sc:
         h_ = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
                                       row0=row0, nrows=nrows, group=group)
         n_rr = sc.n
@@ -349,9 +389,12 @@ def main():
         cluster.DBSCAN(eps=e_, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h_)
         n_db = sc.n - n_rr - n_eps
     del h_
-    host_syncs = {"rerank": n_rr, "eps_rule": n_eps, "dbscan": n_db, "per_split": n_rr + n_eps + n_db,
-                  "what": "blocking device->host reads (item/tolist/cpu) of one grouping leg: value ranges of the features + longest sparse row (re-rank), "
-                          "candidate count + eps (eps rule), labels + edge count (DBSCAN)"}
+    host_syncs = {"rerank": n_rr, "eps_rule": n_eps, "dbscan": n_db, "per_split": n_rr + n_eps + n_db, "world": world,
+                  "what": "blocking device->host reads (item/tolist/cpu) of one grouping leg on rank 0: value ranges of the features (re-rank; sharded: + longest "
+                          "sparse row), candidate count + status words + eps (eps rule; sharded: + block sizes of the candidate gather), labels + edge count (DBSCAN)"}
+    collectives = cc.summary()
+    collectives["what"] = ("torch.distributed collectives of one grouping leg on rank 0 (all-gathers of the row-block tables: source minima, rank lists, V, V_qe, "
+                           "eps candidates, neighbour counts, edges; all-reduces of the eps histograms / counters); bytes = this rank's contribution / what it receives")
     if rank != 0:
         return
     n_img = args.N + args.Ns
@@ -451,11 +494,16 @@ def main():
         "config": {"workload": "BASELINE configs[1]+[2]: N=%d target + Ns=%d source images -> ResNet-50 2048-d embed (orig+flip) -> "
                                "k-reciprocal re-rank (k1=20,k2=6,lambda=%.1f) -> eps rule (rho=%.1e) -> DBSCAN(min_samples=4), 1 feature split"
                                % (args.N, args.Ns, args.lambda_value, args.rho),
-                   "N": args.N, "Ns": args.Ns, "d": 2048, "embed_batch": args.batch, "parallelism": "images + NxN row blocks sharded over %d GPU(s)" % world},
+                   "N": args.N, "Ns": args.Ns, "d": 2048, "embed_batch": args.batch, "parallelism": "images + NxN row blocks sharded over %d GPU(s)" % world,
+                   "legs": "two synthetic tracks (SURVEY.md 8d): the embed leg embeds N(0,1) images; the grouping leg re-ranks resident clustered "
+                           "embeddings of the same shape, NOT the embed leg's output (random-init features hit reid/rerank.py:40's NaN path); the "
+                           "hand-off embed -> grouping is covered by tests/test_gpu_chain.py",
+                   "embed_mode": "two HIP streams per batch (product default); every 8th batch on one stream for the per-launch events of `roofline`"},
         "embed_images_per_s": round(n_img / (t_embed * 1e-3), 1), "embed_ms": round(t_embed, 2),
         "rerank_dbscan_s_per_iter": round((t_rerank + t_cluster) * 1e-3, 5), "rerank_ms": round(t_rerank, 3), "eps_dbscan_ms": round(t_cluster, 3),
-        "labels": {"clusters": int(labels.max() + 1), "noise": int((labels < 0).sum()), "eps": eps},
-        "rank_mode": rerank.default_rank_mode(), "host_syncs": host_syncs, "build": build_fingerprint(),
+        "labels": {"clusters": int(labels.max() + 1), "noise": int((labels < 0).sum()), "eps": eps,
+                   "sha256": __import__("hashlib").sha256(np.ascontiguousarray(labels, dtype=np.int64).tobytes()).hexdigest()[:16]},
+        "rank_mode": rerank.default_rank_mode(), "host_syncs": host_syncs, "collectives": collectives, "build": build_fingerprint(),
         "roofline": roof, "roofline_kernels": hbm,
         "roofline_k5_k12": {"bound": "hbm", "achieved": round(k5_12, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k5_12 / PEAK_HBM_GBS, 4),
                             "algorithmic": "8*N^2 bytes per split over all K5..K12 kernel time (SURVEY.md 8d); K5 = the introsort replay "

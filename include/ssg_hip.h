@@ -44,6 +44,10 @@ int ssg_version(void);
 uint16_t ssg_double_to_half_bits(double d);
 
 /* ---- K3/K4 pairwise distance (replaces scipy cdist in reid/rerank.py:36-37,61-62) ------ */
+/* Value ranges of the two feature sets in one launch: out4 (device, 4 floats) = [max|a|, max|b|, max row norm of a, max row norm of b];
+ * the norms are float32 upper bounds (inflated by 1e-5).  a [rows_a,d], b [rows_b,d] or NULL.  The host picks the digit count of
+ * ssg_gram_i8_encode and the tolerance / operand scales of ssg_source_rowmin_filtered* from them (one read-back). */
+int ssg_range_stats_f32(const float* a, int rows_a, const float* b, int rows_b, int d, float* out4, ssg_stream_t stream);
 /* norms[i] = sum_k x[i,k]^2 in float64, accumulated exactly like the Gram kernel.
  * round_to_half != 0 first rounds x to half (rerank.py:33 feat = astype(float16)). */
 int ssg_row_norms_f64(const float* x, int n, int d, int round_to_half, double* norms, ssg_stream_t stream);
@@ -115,10 +119,14 @@ int ssg_krecip(const uint16_t* D, const uint32_t* rowmax, const int32_t* rank, i
                int32_t* v_idx, uint16_t* v_val, int32_t* v_nnz, ssg_stream_t stream);
 
 /* ---- K7 local query expansion (reid/rerank.py:94-99) ------------------------------------ */
-/* v_* are FULL [N,capV] tables; max_nnz = max(v_nnz) (sizes the LDS staging); q_* cover rows
- * [row0,row0+nrows) with row stride capQ >= k2*max_nnz. */
+/* v_* are FULL [N,capV] tables; max_nnz = an upper bound of the V rows the k2 neighbours of these rows have (sizes the LDS staging:
+ * max(v_nnz) read back, or a GUESS); q_* cover rows [row0,row0+nrows) with row stride capQ >= k2*max_nnz.
+ * overflow (device int32 [2], zeroed by the caller, may be NULL; round 4): [0] = the longest V row met when one exceeds max_nnz (that
+ * row of q_* is then truncated, never written out of bounds), [1] = the longest V row met at all -- lets the caller run on a guessed
+ * max_nnz without a host round trip, redo the rare miss and size its next guess. */
 int ssg_query_expand(const int32_t* v_idx, const uint16_t* v_val, const int32_t* v_nnz, const int32_t* rank, int N, int row0, int nrows,
-                     int K, int k2, int capV, int capQ, int max_nnz, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz, ssg_stream_t stream);
+                     int K, int k2, int capV, int capQ, int max_nnz, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz, int32_t* overflow,
+                     ssg_stream_t stream);
 
 /* ---- K8 inverted index (reid/rerank.py:101-103) ------------------------------------------ */
 /* colcnt [ncols] int32 scratch, colptr [ncols+1] int64, inv_row/inv_val >= sum(q_nnz) entries */
@@ -347,6 +355,10 @@ int ssg_selftest_d2h(const double* a, int n, uint16_t* out, ssg_stream_t stream)
  * (backend "nccl" = RCCL on ROCm); a host language without torch binds these four calls instead.
  * ssg_comm_unique_id: 128 host bytes created by rank 0, passed by EVERY rank to ssg_comm_init (a collective; the communicator
  * binds to the caller's current HIP device).  ssg_allgather: recv[r * bytes_per_rank ...] = rank r's block. */
+/* RCCL is bound at the first collective call, to the build that is already mapped into the process if there is one (torch's
+ * torch/lib/librccl.so next to torch.distributed), else $SSG_RCCL_PATH / librccl.so.1: never two RCCL builds in one process.
+ * ssg_comm_library() = path of the bound library ("" if none). */
+const char* ssg_comm_library(void);
 int ssg_comm_unique_id(void* id128_host);
 int ssg_comm_init(void** comm, int world, int rank, const void* id128_host);
 int ssg_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, ssg_stream_t stream);

@@ -95,7 +95,10 @@ def _eps_rule_sampled(L, h, rho, st):
     vals = torch.cat([cursor, thr3[:1]] + ([pend.to(torch.int64)] if pend is not None else [])).tolist()       # host round trip 1
     got, zeros, thr_bits = vals[:3]
     if pend is not None:
-        h.resolve_pending(vals[3:5])
+        if h.resolve_pending(vals[3:3 + int(pend.numel())]):
+            # the query expansion had run on too small a guess and the distance matrix was rebuilt just now: the passes above
+            # saw the old contents -- run them again (once; the handle has no pending words any more)
+            return _eps_rule_sampled(L, h, rho, st)
         h.validate()
     thr = float(np.uint32(thr_bits & 0xFFFFFFFF).view(np.float32))
     overflow = int(got > n_cap)

@@ -8,15 +8,72 @@
 // The Python product drives the same exchanges through torch.distributed, whose "nccl" backend IS this library on ROCm;
 // `ssg_amd.dist.AbiComm` is the thin wrapper over the entry points below (world-size-1 GPU test: tests/test_abi.py).
 #include "ssg_common.h"
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library itself is bound at run time (below)
+#include <dlfcn.h>
+#include <link.h>
 #include <cstring>
+#include <string>
+
+// One RCCL per process.  libssg_hip.so does NOT link librccl: a process that also runs torch.distributed already
+// maps torch's own build (torch/lib/librccl.so), and a second copy from /opt/rocm/lib would give it two sets of RCCL globals (two
+// bootstrap threads, two views of the xGMI topology, two IPC caches).  The first collective call binds the six entry points to
+//   1. the RCCL that is ALREADY mapped into the process, whichever it is (dl_iterate_phdr -> dlopen(path, RTLD_NOLOAD)),
+//   2. else $SSG_RCCL_PATH, else "librccl.so.1" from the loader's default path (/opt/rocm/lib via the RUNPATH of this library).
+namespace {
+struct Rccl {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string path;
+  bool ok = false;
+};
+Rccl g_rccl;
+
+int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
+  if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) { *static_cast<std::string*>(out) = info->dlpi_name; return 1; }
+  return 0;
+}
+
+int rccl_bind() {
+  if (g_rccl.ok) return SSG_OK;
+  std::string loaded;
+  dl_iterate_phdr(find_loaded_rccl, &loaded);
+  void* h = nullptr;
+  if (!loaded.empty()) h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_NOLOAD);
+  if (!h) {
+    const char* e = getenv("SSG_RCCL_PATH");
+    loaded = e && *e ? e : "librccl.so.1";
+    h = dlopen(loaded.c_str(), RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!h) { ssg_set_error("RCCL not available: %s", dlerror()); return SSG_ERR_HIP; }
+  g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(h, "ncclAllGather"));
+  g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+  g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.GetErrorString) {
+    ssg_set_error("RCCL at %s lacks an entry point", loaded.c_str());
+    return SSG_ERR_HIP;
+  }
+  g_rccl.path = loaded; g_rccl.ok = true;
+  return SSG_OK;
+}
+}  // namespace
 
 static int ssg_check_nccl(ncclResult_t r, const char* what) {
   if (r == ncclSuccess) return SSG_OK;
-  ssg_set_error("RCCL error %d (%s) at %s", (int)r, ncclGetErrorString(r), what);
+  ssg_set_error("RCCL error %d (%s) at %s", (int)r, g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?", what);
   return SSG_ERR_HIP;
 }
 #define SSG_NCCL(call) do { int rc_ = ssg_check_nccl((call), #call); if (rc_) return rc_; } while (0)
+#define SSG_RCCL_BIND() do { int rc_ = rccl_bind(); if (rc_) return rc_; } while (0)
+
+// path of the RCCL library the collectives are bound to ("" before the first collective call / when none could be bound)
+extern "C" const char* ssg_comm_library(void) { rccl_bind(); return g_rccl.path.c_str(); }
 
 static_assert(sizeof(ncclUniqueId) == 128, "ssg_comm_unique_id hands out 128 bytes");
 
@@ -25,7 +82,8 @@ static_assert(sizeof(ncclUniqueId) == 128, "ssg_comm_unique_id hands out 128 byt
 extern "C" int ssg_comm_unique_id(void* id128_host) {
   if (!id128_host) { ssg_set_error("ssg_comm_unique_id: null buffer"); return SSG_ERR_INVALID; }
   ncclUniqueId id;
-  SSG_NCCL(ncclGetUniqueId(&id));
+  SSG_RCCL_BIND();
+  SSG_NCCL(g_rccl.GetUniqueId(&id));
   memcpy(id128_host, &id, sizeof(id));
   return SSG_OK;
 }
@@ -39,7 +97,8 @@ extern "C" int ssg_comm_init(void** comm, int world, int rank, const void* id128
   ncclUniqueId id;
   memcpy(&id, id128_host, sizeof(id));
   ncclComm_t c = nullptr;
-  SSG_NCCL(ncclCommInitRank(&c, world, id, rank));
+  SSG_RCCL_BIND();
+  SSG_NCCL(g_rccl.CommInitRank(&c, world, id, rank));
   *comm = (void*)c;
   return SSG_OK;
 }
@@ -48,7 +107,8 @@ extern "C" int ssg_comm_init(void** comm, int world, int rank, const void* id128
 extern "C" int ssg_allgather(void* comm, const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) {
   if (!comm || (bytes_per_rank && (!send || !recv))) { ssg_set_error("ssg_allgather: null communicator / buffer"); return SSG_ERR_INVALID; }
   if (bytes_per_rank == 0) return SSG_OK;
-  SSG_NCCL(ncclAllGather(send, recv, bytes_per_rank, ncclInt8, (ncclComm_t)comm, stream));
+  SSG_RCCL_BIND();
+  SSG_NCCL(g_rccl.AllGather(send, recv, bytes_per_rank, ncclInt8, (ncclComm_t)comm, stream));
   return SSG_OK;
 }
 
@@ -56,12 +116,14 @@ extern "C" int ssg_allgather(void* comm, const void* send, void* recv, size_t by
 extern "C" int ssg_allreduce_sum_i64(void* comm, int64_t* buf, size_t count, hipStream_t stream) {
   if (!comm || (count && !buf)) { ssg_set_error("ssg_allreduce_sum_i64: null communicator / buffer"); return SSG_ERR_INVALID; }
   if (count == 0) return SSG_OK;
-  SSG_NCCL(ncclAllReduce(buf, buf, count, ncclInt64, ncclSum, (ncclComm_t)comm, stream));
+  SSG_RCCL_BIND();
+  SSG_NCCL(g_rccl.AllReduce(buf, buf, count, ncclInt64, ncclSum, (ncclComm_t)comm, stream));
   return SSG_OK;
 }
 
 extern "C" int ssg_comm_destroy(void* comm) {
   if (!comm) return SSG_OK;
-  SSG_NCCL(ncclCommDestroy((ncclComm_t)comm));
+  SSG_RCCL_BIND();
+  SSG_NCCL(g_rccl.CommDestroy((ncclComm_t)comm));
   return SSG_OK;
 }

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void query_expand_kernel(const int32_t* __rest
                                                            const int32_t* __restrict__ v_nnz, const int32_t* __restrict__ rank,
                                                            int row0, int nrows, int K, int kk, int capV, int capQ, int capL,
                                                            int32_t* __restrict__ q_idx, hbits* __restrict__ q_val,
-                                                           int32_t* __restrict__ q_nnz) {
+                                                           int32_t* __restrict__ q_nnz, int32_t* __restrict__ overflow) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int il = (int)blockIdx.x * 4 + wave;
@@ -164,15 +164,23 @@ __global__ __launch_bounds__(256) void query_expand_kernel(const int32_t* __rest
   int32_t* nn = reinterpret_cast<int32_t*>(wbase + per_list * kk);   // list lengths
 
   // stage the kk source rows (V rows of the first k2 ranked neighbours, rerank.py:97)
+  int nmax = 0;
   for (int r = 0; r < kk; r++) {
     const int src = rank[(int64_t)i * K + r];
-    const int n = v_nnz[src];
+    int n = v_nnz[src];
+    nmax = n > nmax ? n : nmax;
+    if (n > capL) {                      // a guessed max_nnz was too small: flag it (the caller redoes the step), keep the row in bounds
+      if (lane == 0 && overflow) atomicMax(overflow, n);
+      n = capL;
+    }
     if (lane == 0) nn[r] = n;
     for (int p = lane; p < n; p += 64) {
       L_idx(r)[p] = v_idx[(int64_t)src * capV + p];
       L_val(r)[p] = v_val[(int64_t)src * capV + p];
     }
   }
+  // overflow[1] = longest V row met so far (feeds the caller's next guess); a plain read first: after the first waves almost no atomics
+  if (lane == 0 && overflow && nmax > *reinterpret_cast<volatile int32_t*>(overflow + 1)) atomicMax(overflow + 1, nmax);
   wave_sync();
   // head flags: element (r,p) is the head of its column iff no earlier list holds the column;
   // hpre[r][p] = number of heads among list r's first p entries
@@ -256,7 +264,7 @@ extern "C" int ssg_krecip(const uint16_t* D, const uint32_t* rowmax, const int32
 
 extern "C" int ssg_query_expand(const int32_t* v_idx, const uint16_t* v_val, const int32_t* v_nnz, const int32_t* rank, int N, int row0,
                                 int nrows, int K, int k2, int capV, int capQ, int max_nnz, int32_t* q_idx, uint16_t* q_val, int32_t* q_nnz,
-                                hipStream_t stream) {
+                                int32_t* overflow, hipStream_t stream) {
   int kk = k2; if (kk > N) kk = N; if (kk > K) kk = K;
   const int capL = max_nnz < 1 ? 1 : max_nnz;
   if (kk <= 0 || capL > capV || capQ < kk * capL) {
@@ -269,7 +277,7 @@ extern "C" int ssg_query_expand(const int32_t* v_idx, const uint16_t* v_val, con
   if (lds > 160 * 1024) { ssg_set_error("ssg_query_expand: k2=%d max_nnz=%d needs %zu B LDS", k2, capL, lds); return SSG_ERR_INVALID; }
   if (lds > 64 * 1024) SSG_HIP(hipFuncSetAttribute((const void*)query_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(query_expand_kernel, dim3((nrows + 3) / 4), dim3(256), lds, stream, v_idx, v_val, v_nnz, rank, row0, nrows, K, kk, capV,
-                     capQ, capL, q_idx, q_val, q_nnz);
+                     capQ, capL, q_idx, q_val, q_nnz, overflow);
   SSG_LAUNCH_CHECK("query_expand_kernel");
   return SSG_OK;
 }

@@ -245,7 +245,49 @@ __global__ __launch_bounds__(1024) void source_vec_finish_kernel(const unsigned*
 
 }  // namespace ssg
 
+namespace ssg {
+// one wave per row: max |x| and the row's float32 norm (inflated by 1e-5 relative so that it is an UPPER bound whatever order
+// the float32 sum of squares is taken in); non-negative floats order like their bit patterns, NaN patterns sort above +inf
+__global__ __launch_bounds__(256) void range_stats_kernel(const float* __restrict__ a, int rows_a, const float* __restrict__ b, int rows_b, int d,
+                                                          unsigned* __restrict__ out4) {
+  const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (row >= rows_a + rows_b) return;
+  const bool second = row >= rows_a;
+  const float* x = second ? b + (int64_t)(row - rows_a) * d : a + (int64_t)row * d;
+  const int lane = lane_id();
+  unsigned mx = 0u; float s = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    const float v = x[c];
+    const unsigned bits = __float_as_uint(v) & 0x7fffffffu;
+    mx = bits > mx ? bits : mx;
+    s += v * v;
+  }
+  for (int sh = 1; sh < 64; sh <<= 1) {
+    const unsigned o = (unsigned)__shfl_xor((int)mx, sh, 64);
+    mx = o > mx ? o : mx;
+    s += __shfl_xor(s, sh, 64);
+  }
+  if (lane == 0) {
+    const float nrm = sqrtf(s) * 1.00001f;
+    atomicMax(out4 + (second ? 1 : 0), mx);
+    atomicMax(out4 + (second ? 3 : 2), __float_as_uint(nrm) & 0x7fffffffu);
+  }
+}
+}  // namespace ssg
+
 using namespace ssg;
+
+// The value ranges the re-rank pipeline decides on (digit count of the exact Gram, operand scales and the rigorous tolerance of the
+// source term's bound pass): out4 = [max|a|, max|b|, max row norm of a, max row norm of b] as float32 (norms are upper bounds), in ONE
+// launch -- replaces five torch reductions per split (round 4).  b may be NULL (rows_b = 0).  NaN inputs give NaN outputs.
+extern "C" int ssg_range_stats_f32(const float* a, int rows_a, const float* b, int rows_b, int d, float* out4, hipStream_t stream) {
+  if (!a || rows_a <= 0 || d <= 0 || rows_b < 0 || (rows_b > 0 && !b) || !out4) { ssg_set_error("ssg_range_stats_f32: bad arguments"); return SSG_ERR_INVALID; }
+  SSG_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(float), stream));
+  const int rows = rows_a + rows_b;
+  hipLaunchKernelGGL(range_stats_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, a, rows_a, b, rows_b, d, reinterpret_cast<unsigned*>(out4));
+  SSG_LAUNCH_CHECK("range_stats_kernel");
+  return SSG_OK;
+}
 
 extern "C" int ssg_row_norms_f64(const float* x, int n, int d, int round_to_half, double* norms, hipStream_t stream) {
   if (n <= 0 || d <= 0) { ssg_set_error("ssg_row_norms_f64: empty input"); return SSG_ERR_INVALID; }

@@ -46,6 +46,8 @@ class DistHandle:
 
     _pending = None
     _error = None
+    _redo = None
+    _k1 = None
 
     def validate(self):
         """Raise what the pipeline could only detect on the device.  The status words are read once (with the caller's host
@@ -58,15 +60,25 @@ class DistHandle:
         return self
 
     def take_pending(self):
-        """the two device status words (or None when they were read already): a consumer that is about to read something else
+        """the device status words (or None when they were read already): a consumer that is about to read something else
         back appends them to ITS read (cluster.eps_rule does) and hands the values to resolve_pending -- one host round trip less"""
         return self._pending
 
     def resolve_pending(self, values):
-        """values = the two status words as python numbers (read with the caller's host round trip)"""
+        """values = the status words as python numbers (read with the caller's host round trip).  Returns True when the distance
+        matrix was REBUILT (a V row was longer than the guessed capacity of the query expansion): kernels the caller queued on the
+        old contents before reading the words must be run again."""
+        redone = False
         if self._pending is not None:
             vmax_h, flag_h = int(values[0]), int(values[1])
+            over, seen = (int(values[2]), int(values[3])) if len(values) >= 4 else (0, 0)
             self._pending = None
+            if seen > 0 and self._k1 is not None:
+                _QE_GUESS[self._k1] = max(32, ((seen * 3 // 2) + 15) // 16 * 16)
+            if over and self._redo is not None:
+                self._redo()
+                redone = True
+            self._redo = None
             if flag_h:
                 self._error = _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
             elif int(vmax_h) & 0x7FFF == 0:
@@ -74,7 +86,7 @@ class DistHandle:
                                              "reference (reid/rerank.py:40) would return an all-NaN final_dist")
         if self._error is not None:
             raise self._error
-        return self
+        return redone
 
     def final_dist(self):
         """float64 [nrows, N] device tensor (API materialisation, 8 bytes/entry)."""
@@ -124,6 +136,17 @@ def _as_dev_f32(x, device):
     return x
 
 
+def range_stats(tgt, src=None):
+    """[max|tgt|, max|src|, max row norm of tgt, max row norm of src] as python floats: ONE kernel + ONE blocking read (the norms are
+    float32 upper bounds).  Every host-side choice of the pipeline follows from them: digit count of the exact Gram, operand scales
+    and the rigorous tolerance of the source term's bound pass."""
+    L = _lib.lib()
+    rs = torch.empty(4, dtype=torch.float32, device=tgt.device)
+    check(L.ssg_range_stats_f32(ptr(tgt), tgt.shape[0], None if src is None else ptr(src), 0 if src is None else src.shape[0], tgt.shape[1], ptr(rs),
+                                stream()), "ssg_range_stats_f32")
+    return rs.tolist()
+
+
 def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
     """reid/rerank.py:35-40 on device -> (rowmin uint32-as-int32 [nrows]) for a row block.
 
@@ -149,7 +172,7 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
         # (|err| <= gamma_d * sum|x_k y_k| <= gamma_d |x||y|, gamma_d = d*u/(1-d*u), u = 2^-24); the squared
         # norms come from a 32-term chain + 6-level tree (38 u relative); a few ulps for the final adds.
         if stats is None:      # (max|tgt|, max|src|, max row norm of the block, max row norm of src): one host read
-            stats = torch.stack([tblk.abs().max(), src.abs().max(), tblk.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
+            stats = range_stats(tblk.contiguous(), src)
         mt, ms, nx, ny = (float(s) for s in stats)
         u = 2.0 ** -24
         bound = os.environ.get("SSG_SOURCE_BOUND", "half")
@@ -188,7 +211,7 @@ def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
     return rowmin
 
 
-def _original_distance(L, tgt, row0, nrows, max_abs, st, memory_save=False):
+def _original_distance(L, tgt, row0, nrows, max_abs, st, memory_save=False, flag=None):
     """rows [row0,row0+nrows) of the half original distance (rerank.py:33,61-62) + their maxima -> (D, rowmax, flag).
     max_abs = max|tgt| on the host; flag = device flag of the int8 encoder (None on the fp64 path), to be read with the
     caller's next host round trip (it cannot be set after the range check here)."""
@@ -197,7 +220,6 @@ def _original_distance(L, tgt, row0, nrows, max_abs, st, memory_save=False):
     D = torch.empty((nrows, N), dtype=torch.float16, device=dev)
     rowmax = torch.empty(nrows, dtype=torch.int32, device=dev)
     use_i8 = os.environ.get("SSG_SELF_GRAM", "i8") == "i8" and d <= 16384
-    flag = None
     if use_i8:
         # exact integer Gram on the int8 matrix cores (half-rounded features in [-1, 1]: scipy's float64 sum is exact);
         # 3 radix-256 digits cover |feat| <= 0.498 (any real L2-normalised embedding), 4 digits |feat| <= 1
@@ -207,7 +229,8 @@ def _original_distance(L, tgt, row0, nrows, max_abs, st, memory_save=False):
     if use_i8:
         enc = torch.empty(L.ssg_gram_i8_encoded_bytes(N, d, nd), dtype=torch.int8, device=dev)
         inorm = torch.empty(N, dtype=torch.int64, device=dev)
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        if flag is None:
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
         check(L.ssg_gram_i8_encode(ptr(tgt), N, d, nd, ptr(enc), ptr(inorm), ptr(flag), st), "ssg_gram_i8_encode")
         check(L.ssg_sqdist_self_i8(ptr(enc), ptr(inorm), N, d, nd, row0, nrows, int(bool(memory_save)), ptr(D), ptr(rowmax), ptr(flag), st), "ssg_sqdist_self_i8")
         del enc, inorm
@@ -215,6 +238,7 @@ def _original_distance(L, tgt, row0, nrows, max_abs, st, memory_save=False):
         norms = torch.empty(N, dtype=torch.float64, device=dev)
         check(L.ssg_row_norms_f64(ptr(tgt), N, d, 1, ptr(norms), st), "ssg_row_norms_f64")
         check(L.ssg_sqdist_self_f16(ptr(tgt), ptr(norms), N, d, row0, nrows, int(bool(memory_save)), ptr(D), ptr(rowmax), st), "ssg_sqdist_self_f16")
+        flag = None
     return D, rowmax, flag
 
 
@@ -271,13 +295,11 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     d = tgt.shape[1]
     st = stream()
 
-    # every range / norm bound the pipeline needs from the host, in ONE device round trip
-    if no_rerank:
-        stats = [float(tgt.abs().max().item())]
-    else:
-        stats = torch.stack([tgt.abs().max(), src.abs().max(), tgt.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
+    # every range / norm bound the pipeline needs from the host: ONE kernel (ssg_range_stats_f32), ONE device round trip
+    stats = range_stats(tgt, None if no_rerank else src)     # host round trip 1: max|tgt|, max|src|, max row norms (upper bounds)
     # ---- original distance (rerank.py:33,61-62): D half [nrows,N] + row max
-    D, rowmax, flag = _original_distance(L, tgt, row0, nrows, stats[0], st, memory_save)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)    # [max(v) half bits, digit overflow, V row longer than the guess, longest V row]
+    D, rowmax, flag = _original_distance(L, tgt, row0, nrows, stats[0], st, memory_save, flag=status[1:2])
     if no_rerank:
         if flag is not None and int(flag.item()):
             raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
@@ -286,7 +308,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     # ---- source-domain term (rerank.py:35-40): v half [N]
     rowmin = _gather_rows(source_vector(src, tgt, row0, nrows, stats=stats), group, N)
     v = torch.empty(N, dtype=torch.float16, device=dev)
-    vmax = torch.zeros(1, dtype=torch.int32, device=dev)
+    vmax = status[0:1]
     check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
 
     # ---- initial ranking (rerank.py:68-70): the columns that are ever read are [0, max(k1+1, k2)) (:76, :83, :97)
@@ -300,53 +322,68 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     v_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
     check(L.ssg_krecip(ptr(D), ptr(rowmax), ptr(rank), N, row0, nrows, K, k1, capV, ptr(v_idx), ptr(v_val), ptr(v_nnz), st), "ssg_krecip")
     v_idx, v_val, v_nnz = _gather_rows(v_idx, group, N), _gather_rows(v_val, group, N), _gather_rows(v_nnz, group, N)
-
-    # ---- local query expansion (rerank.py:94-99)
-    if k2 != 1:
-        kk = min(k2, N, K)
-        mx = max(int(v_nnz.max().item()), 1)       # longest V row actually present
-        capQ = kk * mx
-        q_idx = torch.empty((nrows, capQ), dtype=torch.int32, device=dev)
-        q_val = torch.empty((nrows, capQ), dtype=torch.float16, device=dev)
-        q_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
-        check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, mx, ptr(q_idx), ptr(q_val),
-                                 ptr(q_nnz), st), "ssg_query_expand")
-        if group is not None:
-            # ship only the used part of the fixed-capacity rows over xGMI
-            import torch.distributed as dist
-            m = q_nnz.max().clone(); dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-            capQ = max(int(m.item()), 1)
-            q_idx, q_val = q_idx[:, :capQ].contiguous(), q_val[:, :capQ].contiguous()
-        q_idx, q_val, q_nnz = _gather_rows(q_idx, group, N), _gather_rows(q_val, group, N), _gather_rows(q_nnz, group, N)
-    else:
-        capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
-
-    # ---- inverted index + Jaccard rows (rerank.py:101-122)
-    # the inverted lists hold at most one entry per stored V_qe entry: sized by that bound instead of reading sum(q_nnz) back
-    # (one host round trip less; the bound is N * capQ entries of 6 bytes)
-    total = int(N) * int(capQ)
-    colcnt = torch.empty(N, dtype=torch.int32, device=dev)
-    colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
-    inv_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
-    inv_val = torch.empty(max(total, 1), dtype=torch.float16, device=dev)
-    check(L.ssg_invert_index(ptr(q_idx), ptr(q_val), ptr(q_nnz), N, N, capQ, ptr(colcnt), ptr(colptr), ptr(inv_row), ptr(inv_val), st),
-          "ssg_invert_index")
     om = L.ssg_double_to_half_bits(1.0 - float(lambda_value))
     Jp = torch.empty((nrows, N), dtype=torch.float16, device=dev)
-    colmeta = torch.empty((2, nrows, capQ), dtype=torch.int32, device=dev)
-    check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
-                             om, ptr(Jp), st), "ssg_jaccard_rows")
+    tables = {}
 
-    if stages is not None:
-        stages.update(D=D, rowmax=rowmax, v=v, rank=rank, v_idx=v_idx, v_val=v_val, v_nnz=v_nnz, q_idx=q_idx, q_val=q_val, q_nnz=q_nnz,
-                      colptr=colptr, inv_row=inv_row, inv_val=inv_val, Jp=Jp)
+    def tail(mx, over):
+        """local query expansion -> inverted index -> Jaccard rows into Jp, with LDS / row capacities sized for V rows of at most `mx`
+        entries; `over` = the device words that report a longer row (None: mx is exact)"""
+        if k2 != 1:
+            kk = min(k2, N, K)
+            capQ = kk * mx
+            q_idx = torch.empty((nrows, capQ), dtype=torch.int32, device=dev)
+            q_val = torch.empty((nrows, capQ), dtype=torch.float16, device=dev)
+            q_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
+            check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, mx, ptr(q_idx), ptr(q_val),
+                                     ptr(q_nnz), ptr(over), st), "ssg_query_expand")
+            # sharded rows: the fixed-capacity rows travel as they are (k2 * longest V row entries of 6 bytes; trimming them to the longest
+            # V_qe row would cost an all-reduce and a blocking read per split for a few MB over xGMI)
+            q_idx, q_val, q_nnz = _gather_rows(q_idx, group, N), _gather_rows(q_val, group, N), _gather_rows(q_nnz, group, N)
+        else:
+            capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
+        # ---- inverted index + Jaccard rows (rerank.py:101-122)
+        # the inverted lists hold at most one entry per stored V_qe entry: sized by that bound instead of reading sum(q_nnz) back
+        total = int(N) * int(capQ)
+        colcnt = torch.empty(N, dtype=torch.int32, device=dev)
+        colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+        inv_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        inv_val = torch.empty(max(total, 1), dtype=torch.float16, device=dev)
+        check(L.ssg_invert_index(ptr(q_idx), ptr(q_val), ptr(q_nnz), N, N, capQ, ptr(colcnt), ptr(colptr), ptr(inv_row), ptr(inv_val), st),
+              "ssg_invert_index")
+        colmeta = torch.empty((2, nrows, capQ), dtype=torch.int32, device=dev)
+        check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
+                                 om, ptr(Jp), st), "ssg_jaccard_rows")
+        if stages is not None:
+            tables.update(q_idx=q_idx, q_val=q_val, q_nnz=q_nnz, colptr=colptr, inv_row=inv_row, inv_val=inv_val)
+
+    # ---- local query expansion (rerank.py:94-99) .. Jaccard rows.  The LDS staging and the row capacity of V_qe follow the longest V
+    # row.  One GPU: run on a GUESS (the longest row of the previous call + 50 %, 96 at first) and let the kernel report a longer row
+    # through the status words that the consumer reads anyway (`validate`); a miss redoes this tail with the exact bound (rare; the
+    # result is the same either way).  Sharded rows: every rank must take the same branch, so the gathered v_nnz is read back (one
+    # blocking read, no collective of its own).
+    redo = None
+    if k2 == 1:
+        tail(capV, None)
+    elif group is None and os.environ.get("SSG_QE_GUESS", "1") != "0":
+        guess = min(capV, _QE_GUESS.get(k1, 96))
+        tail(guess, status[2:4])
+        redo = lambda: tail(capV, None)            # noqa: E731  (keeps the small tables alive, not D)
+    else:
+        tail(max(int(v_nnz.max().item()), 1), None)  # host round trip 2 (sharded path)
+
     h = DistHandle(N, 0, Jp, v=v, lambda_value=lambda_value, euclid=D if keep_euclid else None, row0=row0, nrows=nrows, group=group)
-    # the two device-side status words (zero source vector -> the reference's NaN path; int8 digit overflow) are read with the
-    # consumer's first host round trip (`validate`: eps_rule / DBSCAN / final_dist), not with one of their own
-    h._pending = torch.cat([vmax, flag if flag is not None else torch.zeros_like(vmax)])
-    if validate:
+    # the device-side status words (zero source vector -> the reference's NaN path; int8 digit overflow; a V row longer than the guess)
+    # are read with the consumer's first host round trip (`validate`: eps_rule / DBSCAN / final_dist), not with one of their own
+    h._pending, h._redo, h._k1 = status, redo, k1
+    if validate or stages is not None:
         h.validate()
+    if stages is not None:
+        stages.update(D=D, rowmax=rowmax, v=v, rank=rank, v_idx=v_idx, v_val=v_val, v_nnz=v_nnz, Jp=Jp, **tables)
     return h
+
+
+_QE_GUESS = {}      # k1 -> guessed longest V row for the next call (the longest row of the last call + 50 %, a multiple of 16)
 
 
 def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.2, MemorySave=False, Minibatch=2000, no_rerank=False,

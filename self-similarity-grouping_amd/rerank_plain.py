@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream
-from .rerank import DeviceBackedArray, DistHandle, ReRankNaNError, _as_dev_f32, _original_distance, source_vector
+from .rerank import DeviceBackedArray, DistHandle, ReRankNaNError, _as_dev_f32, _original_distance, range_stats, source_vector
 
 
 def re_ranking_plain_device(src, tgt, k=20, lambda_value=0.1, stages=None, memory_save=False):
@@ -28,7 +28,7 @@ def re_ranking_plain_device(src, tgt, k=20, lambda_value=0.1, stages=None, memor
     if not (1 <= k <= min(N, 64)):
         raise ValueError("re_ranking (plain): need 1 <= k <= min(N, 64), got k=%d N=%d" % (k, N))
     st = stream()
-    stats = torch.stack([tgt.abs().max(), src.abs().max(), tgt.norm(dim=1).max(), src.norm(dim=1).max()]).tolist()
+    stats = range_stats(tgt, src)
     D, rowmax, flag = _original_distance(L, tgt, 0, N, stats[0], st, memory_save)
     # source-domain term (rerank_plain.py:130-143)
     rowmin = source_vector(src, tgt, 0, N, stats=stats)

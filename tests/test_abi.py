@@ -125,6 +125,25 @@ def test_comm_entry_points_validate_without_gpu():
     assert L.ssg_comm_destroy(None) == 0
 
 
+def test_one_rccl_build_per_process():
+    """libssg_hip.so must not bring a second RCCL into a process that runs torch.distributed -- it has no NEEDED
+    entry for librccl, and its collectives bind (lazily) to the RCCL torch already maps."""
+    import subprocess
+    import sys
+    import torch  # noqa: F401  (maps torch/lib/librccl.so)
+    out = subprocess.run(["readelf", "-d", _lib.SO_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in out, "libssg_hip.so links RCCL again"
+    code = ("import sys; sys.path.insert(0, %r); import torch, ssg_amd; from ssg_amd import _lib; L = _lib.lib(); "
+            "p = L.ssg_comm_library().decode(); "
+            "maps = sorted({l for l in open('/proc/self/maps').read().split() if 'librccl' in l}); print(p); print(len(maps)); print(maps[0] if maps else '')"
+            % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bound, nmaps, mapped = r.stdout.strip().splitlines()[-3:]
+    assert int(nmaps) == 1, "two RCCL builds mapped: %s" % r.stdout
+    assert os.path.realpath(bound) == os.path.realpath(mapped) and "torch" in bound, (bound, mapped)
+
+
 @pytest.mark.gpu
 def test_comm_entry_points_world1_on_rccl():
     """ssg_comm_unique_id -> ssg_comm_init -> ssg_allgather / ssg_allreduce_sum_i64 -> ssg_comm_destroy on a one-rank RCCL
@@ -133,6 +152,7 @@ def test_comm_entry_points_world1_on_rccl():
     from ssg_amd.dist import AbiComm
     torch.cuda.set_device(0)
     comm = AbiComm(1, 0, AbiComm.unique_id())
+    assert "torch" in _lib.lib().ssg_comm_library().decode()      # bound to the RCCL torch maps, not to a second copy
     t = torch.arange(40, dtype=torch.float32, device="cuda").view(10, 4)
     assert torch.equal(comm.all_gather_rows(t), t)
     hh = torch.arange(7, dtype=torch.int64, device="cuda")

@@ -48,6 +48,15 @@ def _cpu_worker(rank, world, port, q):
     ok = ok and torch.equal(sd.all_reduce_sum(h, g), torch.tensor([1, 2, 3]) * (world * (world + 1) // 2))
     empty = sd.gather_varlen(torch.zeros((0, 2), dtype=torch.int32) if rank == 0 else torch.ones((2, 2), dtype=torch.int32), g)
     ok = ok and empty.shape == (2 * (world - 1), 2)
+    if world >= 3:
+        # two groups of different membership on one backend -- ranks 0, 1 gather over {0, 1} first, then everybody gathers
+        # over the world group.  The flat-gather probe is a collective: it must run per group, or rank 2 probes alone and hangs.
+        sub = dist.new_group(ranks=[0, 1])
+        if rank < 2:
+            part = sd.gather_rows(torch.full((2, 2), float(rank)), sub)
+            ok = ok and part.shape == (4, 2) and float(part[2:].min()) == 1.0
+        allr = sd.gather_rows(torch.full((1, 2), float(rank)), g)
+        ok = ok and allr.shape == (world, 2) and [float(v) for v in allr[:, 0]] == [float(r) for r in range(world)]
     sd.barrier(g)
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
@@ -377,3 +386,43 @@ def test_config4_sharded_footprint_and_result():
         assert peak < 2 * block + 2.5e9, "rank %d peak allocation %.2f GB (two half row blocks are %.2f GB)" % (r, peak / 1e9, 2 * block / 1e9)
     print("configs[4] sharded over 8 ranks: peak allocation per rank %.2f .. %.2f GB (D + J' row blocks: %.2f GB)" % (
         min(x[4] for x in res) / 1e9, max(x[4] for x in res) / 1e9, 2 * block / 1e9))
+
+
+def _run_bench(world, extra_env=None):
+    """bench.py as the driver launches it (torchrun for world > 1), on a reduced problem; returns the parsed JSON line"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--gpus", str(world), "--steps", "1", "--warmup", "0", "--N", "4000", "--Ns", "2000", "--batch", "250", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, OMP_NUM_THREADS="8", MKL_NUM_THREADS="8", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
+    if world == 1:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(root, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_step_at_world_2_and_8_equals_world_1():
+    """the bench's own step (sharded extraction -> all-gather of the embeddings -> row-block sharded re-rank -> eps ->
+    DBSCAN) under torchrun at world 2 and 8 -- every rank on the one GPU of the test box (SSG_BENCH_SHARE_GPU=1: gloo collectives,
+    the same product code path as RCCL) -- must produce the world-1 labels; the line reports the host syncs and the collectives of
+    the sharded leg."""
+    one = _run_bench(1)
+    assert one["n_gpus"] == 1 and one["collectives"]["n"] == 0 and one["host_syncs"]["per_split"] <= 4
+    for world in (2, 8):
+        out = _run_bench(world, {"SSG_BENCH_SHARE_GPU": "1"})
+        assert out["n_gpus"] == world and out["config"]["N"] == 4000
+        assert out["labels"] == one["labels"], (world, out["labels"], one["labels"])
+        assert out["collectives"]["n"] > 0 and out["collectives"]["calls"].get("all_gather_into_tensor", 0) + out["collectives"]["calls"].get("all_gather", 0) >= 6
+        assert out["host_syncs"]["world"] == world
+        print("world %d: %d collectives, %.1f MB received, %d host syncs per split, %.1f ms grouping" % (
+            world, out["collectives"]["n"], out["collectives"]["bytes_received"] / 1e6, out["host_syncs"]["per_split"],
+            out["rerank_dbscan_s_per_iter"] * 1e3))

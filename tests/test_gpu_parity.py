@@ -174,6 +174,61 @@ def test_rerank_stages_vs_reference_golden(name, golden, dev, ora):
             _check_rerank_golden(g, "stable", dev, ora)
 
 
+def test_query_expansion_guess_miss_is_redone(golden, dev, ora):
+    """round 4: on one GPU the query expansion runs on a GUESSED longest V row (no host round trip) and reports a longer row through
+    the status words the eps rule reads anyway.  Force a miss (guess = 4 entries): the eps rule must notice it with its first
+    read-back, the Jaccard matrix must be rebuilt with the exact bound, the passes rerun, and everything equal the reference's
+    outputs; the next guess must have grown; the exact-bound path (SSG_QE_GUESS=0) gives the same bits."""
+    from ssg_amd import rerank, cluster
+    g = golden("rerank_n256_l03_ref.npz")
+    src, tgt = torch.from_numpy(g["src"]).to(dev), torch.from_numpy(g["tgt"]).to(dev)
+    old = dict(rerank._QE_GUESS)
+    try:
+        rerank._QE_GUESS[20] = 4
+        h = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.3, validate=False)
+        assert h._pending is not None and h._redo is not None
+        stale = h.M.clone()
+        eps, cnt, top = cluster.eps_rule(h, float(g["rho"]))
+        assert h._pending is None and not torch.equal(stale, h.M), "the truncated matrix was not rebuilt"
+        assert (eps, cnt, top) == (float(g["eps"]), int(g["count"]), int(g["top_num"]))
+        assert np.array_equal(h.final_dist().cpu().numpy(), g["final"])
+        assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h), g["labels"])
+        assert rerank._QE_GUESS[20] >= 32
+        # the same miss caught by validate() (DBSCAN / final_dist as the first consumer)
+        rerank._QE_GUESS[20] = 4
+        h2 = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.3, validate=False)
+        assert np.array_equal(h2.final_dist().cpu().numpy(), g["final"])
+        # a sufficient guess: nothing is redone
+        h3 = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.3, validate=False)
+        before = h3.M.clone()
+        h3.validate()
+        assert torch.equal(before, h3.M) and np.array_equal(h3.final_dist().cpu().numpy(), g["final"])
+    finally:
+        rerank._QE_GUESS.clear(); rerank._QE_GUESS.update(old)
+    os.environ["SSG_QE_GUESS"] = "0"
+    try:
+        h4 = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.3)
+    finally:
+        del os.environ["SSG_QE_GUESS"]
+    assert np.array_equal(h4.final_dist().cpu().numpy(), g["final"])
+
+
+def test_range_stats_kernel(dev):
+    """ssg_range_stats_f32 (one launch for the four value ranges the host decides on) against torch: maxima exact, norms upper bounds
+    within 2e-5 relative; NaN propagates."""
+    from ssg_amd import rerank
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(333, 160, generator=g).to(dev) * 0.3; b = torch.randn(77, 160, generator=g).to(dev)
+    s = rerank.range_stats(a, b)
+    assert s[0] == float(a.abs().max()) and s[1] == float(b.abs().max())
+    for got, ref in ((s[2], float(a.double().norm(dim=1).max())), (s[3], float(b.double().norm(dim=1).max()))):
+        assert ref <= got <= ref * (1 + 2e-5)
+    s1 = rerank.range_stats(a)
+    assert s1[0] == s[0] and s1[1] == 0.0 and s1[3] == 0.0
+    a[7, 3] = float("nan")
+    assert np.isnan(rerank.range_stats(a, b)[0])
+
+
 def _rank_rows(keys, K, dev, mode="introsort", force_arena=False):
     """rows of order keys (uint16, < 0x3c00) -> device ranking of half(D / 1.0) with D = the keys as half bit patterns"""
     from ssg_amd import rerank
