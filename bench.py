@@ -30,11 +30,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_FP32_MFMA_TF = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak
-PEAK_FP16_MFMA_TF = 2516.6    # MI355X_MICROARCH.md: dense fp16/bf16 matrix peak (v_mfma_f32_32x32x16_f16)
-PEAK_INT8_MFMA_TOPS = 5033.2  # dense int8 matrix peak (v_mfma_i32_32x32x32_i8 = 2x the fp16 rate)
-PEAK_FP64_MFMA_TF = 78.6      # SURVEY.md 8d / BASELINE.md
-PEAK_HBM_GBS = 8000.0         # HBM3E spec
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from roofline import (KernelTimer, grouping_roofline, PEAK_FP32_MFMA_TF, PEAK_FP16_MFMA_TF, PEAK_HBM_GBS)  # noqa: E402,F401  (shared with tools/run_configs.py)
 FLOP_PER_IMAGE = 10.68e9      # 2 forwards x 2 x 2.669 GMAC
 
 
@@ -51,14 +48,32 @@ def build_fingerprint():
     return h.hexdigest()[:16]
 
 
+EMBED_SOURCES = ("conv.hip", "bottleneck.hip", "stem_pool.hip", "ssg_common.h")
+
+
+def embed_fingerprint():
+    """sha256 over the sources of the embedding's convolution kernels only: what a PMC traffic summary of the embedding depends on (a
+    change to the grouping kernels does not make it stale)"""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "self-similarity-grouping_amd", "csrc")
+    for f in EMBED_SOURCES:
+        h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_conv_traffic.json")
+
+
 def pmc_traffic(path, build, batch, launches_per_forward):
     """HBM bytes per convolution launch from the PMC summary `tools/pmc_embed.sh` wrote (FETCH_SIZE x 2 + WRITE_SIZE over one forward, divided
-    by its launches) -> (bytes or None, note).  None when there is no summary, when it was taken on another build of the kernels (the
-    fingerprint it carries differs) or on another launch set / batch size: a stale figure is not quoted."""
+    by its launches) -> (bytes or None, note).  None when there is no summary, when it was taken on another build of the embedding kernels
+    (`embed_build`, the fingerprint of `embed_fingerprint()`, differs) or on another launch set / batch size: a stale figure is not quoted."""
     try:
         pm = json.load(open(path))
-        if pm.get("build") != build:
-            return None, "%s was taken on another build (%s, this one is %s): not quoted" % (os.path.basename(path), pm.get("build"), build)
+        have = pm.get("embed_build", pm.get("build"))
+        if have != build:
+            return None, "%s was taken on another build (%s, this one is %s): not quoted" % (os.path.basename(path), have, build)
         if pm["batch"] != batch or pm["launches_per_forward"] != launches_per_forward:
             return None, "%s covers %d launches per forward at batch %d, this run has %d at batch %d: not quoted" % (
                 os.path.basename(path), pm["launches_per_forward"], pm["batch"], launches_per_forward, batch)
@@ -134,31 +149,6 @@ class CollectiveCounter:
 
     def summary(self):
         return {"calls": dict(self.calls), "n": sum(self.calls.values()), "bytes_sent": self.bytes_out, "bytes_received": self.bytes_in}
-
-
-class KernelTimer:
-    """HIP-event timing of individual C-ABI launches on the stream they are launched on."""
-
-    def __init__(self, L):
-        self.L, self.ev, self.on = L, {}, False
-        self.sample, self.sampled_images = True, 0      # embed batches are sampled 1 in 8 (the events cost 2.7 % when on every launch, and a sampled batch runs its two forwards on one stream)
-
-    def __getattr__(self, k):
-        fn = getattr(self.L, k)
-        if not self.on or not self.sample or not k.startswith("ssg_") or k.endswith("_bytes") or k.endswith("_supported") or k in (
-                "ssg_last_error", "ssg_krecip_row_capacity", "ssg_double_to_half_bits", "ssg_version", "ssg_eps_mean_prepare"):
-            return fn
-
-        def timed(*a):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); rc = fn(*a); e1.record()
-            self.ev.setdefault(k, []).append((e0, e1))
-            return rc
-        return timed
-
-    def totals(self):
-        torch.cuda.synchronize()
-        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v)) for k, v in self.ev.items()}
 
 
 def cpu_baseline(args, src, tgt, gpu_labels, gpu_eps):
@@ -422,65 +412,15 @@ def main():
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, collected on this
     # kernel set at the same batch size); null when the configuration differs from the profiled one
     if split:
-        roof["traffic"], note = pmc_traffic(os.path.join(ROOT, "profiles", "r03_pmc_conv_traffic.json"), build_fingerprint(), args.batch, n_conv_per_fwd)
+        roof["traffic"], note = pmc_traffic(PMC_TRAFFIC_JSON, embed_fingerprint(), args.batch, n_conv_per_fwd)
         if note:
             roof["traffic_note"] = note
     if split:
         roof["peak_is"] = "fp16 dense MFMA peak %.1f / 3 products per fp32 multiply" % PEAK_FP16_MFMA_TF
         roof["executed_fp16_tflops"] = round(3.0 * conv_tf, 1)
         roof["vs_fp32_mfma_peak"] = round(conv_tf / PEAK_FP32_MFMA_TF, 3)
-    nn2 = 2.0 * nrows * args.N   # bytes of one half row block
-    hbm = []
-    for k, byt, what in (("ssg_topk_rank", nn2, "reads D (2*N^2 B); canonical (value, column) order, opt-in rank_mode='stable'"),
-                         ("ssg_topk_rank_introsort", nn2, "reads D (2*N^2 B); replays numpy's unstable introsort argsort per row (reference tie order, "
-                          "default): VALU/latency-bound emulation of a sequential algorithm, listed against the same bytes"),
-                         ("ssg_jaccard_rows", nn2, "writes J' (2*N^2 B)"),
-                         ("ssg_eps_hist", nn2 / 2, "radix-select fallback of the eps rule: reads upper triangle of J' (N^2 B) per level"),
-                         ("ssg_eps_compact", nn2 / 2, "radix-select fallback: reads upper triangle of J' (N^2 B)"),
-                         ("ssg_eps_compact_below", nn2 / 2, "eps rule, the one full pass of the sampled-threshold path: reads upper triangle of J' (N^2 B)"),
-                         ("ssg_region_query", nn2, "reads J' (2*N^2 B)")):
-        if k in tot:
-            n, ms = tot[k]
-            gbs = byt * n / (ms * 1e-3) / 1e9
-            hbm.append({"kernel": k, "bound": "hbm", "what": what, "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(gbs, 1),
-                        "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
-    # the self term computes only the upper-triangle tiles when one GPU holds the whole matrix (mirrored on store)
-    t128 = (args.N + 127) // 128
-    self_flop = (t128 * (t128 + 1) // 2) * 128 * 128 * 2.0 * 2048 if world == 1 else 2.0 * nrows * args.N * 2048
-    for k, flop in (("ssg_sqdist_self_f16", self_flop), ("ssg_source_rowmin_f16", 2.0 * nrows * args.Ns * 2048)):
-        if k in tot:
-            n, ms = tot[k]
-            tf = flop * n / (ms * 1e-3) / 1e12
-            hbm.append({"kernel": k, "bound": "mfma", "what": "fp64 Gram (v_mfma_f64_16x16x4); executed flops (self term: upper-triangle tiles only on 1 GPU)", "launches": n, "avg_launch_ms": round(ms / n, 4),
-                        "achieved": round(tf, 2), "peak": PEAK_FP64_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP64_MFMA_TF, 4)})
-    if "ssg_sqdist_self_i8" in tot:
-        n, ms = tot["ssg_sqdist_self_i8"]
-        t64 = (args.N + 63) // 64
-        alg = ((t64 * (t64 + 1) // 2) * 64 * 64 if world == 1 else nrows * args.N) * 2.0 * 2048      # executed tiles (upper triangle on 1 GPU)
-        tops = 9.0 * alg * n / (ms * 1e-3) / 1e12                                                     # 3 x 3 digit products per multiply
-        hbm.append({"kernel": "ssg_sqdist_self_i8", "bound": "mfma", "what": "exact integer Gram on v_mfma_i32_32x32x32_i8: 3 balanced radix-256 digits per "
-                    "feature, 9 digit products per multiply; achieved = executed int8 ops, algorithmic_tflops = the 2*d flop per distance it replaces "
-                    "(fp64 MFMA peak for that: 78.6)", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tops, 1),
-                    "peak": PEAK_INT8_MFMA_TOPS, "unit": "TOP/s", "frac": round(tops / PEAK_INT8_MFMA_TOPS, 4),
-                    "algorithmic_tflops": round(alg * n / (ms * 1e-3) / 1e12, 1)})
-    if "ssg_source_rowmin_filtered" in tot:
-        n, ms = tot["ssg_source_rowmin_filtered"]
-        tf = 2.0 * nrows * args.Ns * 2048 * n / (ms * 1e-3) / 1e12
-        hbm.append({"kernel": "ssg_source_rowmin_filtered", "bound": "mfma", "what": "source term by filter-and-refine: split-half fp16-MFMA bound pass (2*N*Ns*d flop, 3 products each) + fp64 "
-                    "re-evaluation of candidate granules; time covers both; peak = fp16 MFMA / 3", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
-                    "peak": round(PEAK_FP16_MFMA_TF / 3.0, 1), "unit": "TFLOP/s", "frac": round(tf / (PEAK_FP16_MFMA_TF / 3.0), 4)})
-    if "ssg_source_rowmin_filtered1" in tot:
-        n, ms = tot["ssg_source_rowmin_filtered1"]
-        tf = 2.0 * nrows * args.Ns * 2048 * n / (ms * 1e-3) / 1e12
-        hbm.append({"kernel": "ssg_source_rowmin_filtered1", "bound": "mfma", "what": "source term by filter-and-refine: bound pass = plain fp16 GEMM on half copies of the "
-                    "operands (2*N*Ns*d flop, one v_mfma_f32_32x32x16_f16 product per term) + fp64 re-evaluation of the candidate granules; time covers the encode, "
-                    "both passes and the row norms; peak = dense fp16 MFMA", "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(tf, 2),
-                    "peak": PEAK_FP16_MFMA_TF, "unit": "TFLOP/s", "frac": round(tf / PEAK_FP16_MFMA_TF, 4)})
-    hbm_ms = sum(tot[k][1] for k in ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
-                                    "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_compact_below", "ssg_fill_u64",
-                                    "ssg_sort_u64", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_dbscan_cc", "ssg_dbscan_cc_dev")
-                 if k in tot) / args.steps
-    k5_12 = 8.0 * nrows * args.N / (hbm_ms * 1e-3) / 1e9 if hbm_ms > 0 else float("nan")
+    hbm, k5_k12 = grouping_roofline(tot, args.N, nrows, args.Ns, world, args.steps)
+    hbm_ms = k5_k12["kernel_ms"]
     out = {
         "metric": "images/s embed + s/iter for NxN rerank+DBSCAN, N=16k, 1/2/4/8 GPU",
         "value": round(n_img / (ms_step * 1e-3), 2), "unit": "images/s (embedded + grouped per wall second, whole iteration)",
@@ -505,9 +445,7 @@ def main():
                    "sha256": __import__("hashlib").sha256(np.ascontiguousarray(labels, dtype=np.int64).tobytes()).hexdigest()[:16]},
         "rank_mode": rerank.default_rank_mode(), "host_syncs": host_syncs, "collectives": collectives, "build": build_fingerprint(),
         "roofline": roof, "roofline_kernels": hbm,
-        "roofline_k5_k12": {"bound": "hbm", "achieved": round(k5_12, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(k5_12 / PEAK_HBM_GBS, 4),
-                            "algorithmic": "8*N^2 bytes per split over all K5..K12 kernel time (SURVEY.md 8d); K5 = the introsort replay "
-                                           "unless rank_mode is 'stable'", "kernel_ms": round(hbm_ms, 3)},
+        "roofline_k5_k12": k5_k12,
     }
     out.update(extras)
     if "rank_mode" in extras and "ssg_topk_rank_introsort" in tot:

@@ -339,6 +339,18 @@ int ssg_jpeg_decode_batch(const uint8_t* ecs, const int64_t* segs, int nseg, con
                           const int32_t* maxcode, const int32_t* valoff, const uint8_t* vals, const uint16_t* qts, int16_t* coef,
                           int64_t total_blocks, int max_blocks, uint8_t* planes, int max_pixels, uint8_t* out, int32_t* status,
                           ssg_stream_t stream);
+/* Host side of the same path, native and threaded (csrc/jpeg_host.hip; no device work): the marker walk + table building that
+ * ssg_amd/jpeg.py states in Python, for a batch of files in host memory -- what the reference's DataLoader workers do in libjpeg's
+ * jdmarker.c before decoding.  ssg_jpeg_parse_open: pass over files[i] (lens[i] bytes each; must stay valid until _close) on
+ * `nthreads` threads; counts10 = [images the GPU decodes, restart segments, bytes of entropy-coded data incl. 64 of padding, Huffman
+ * tables, quantisation tables, coefficient blocks, largest component (blocks), plane bytes, output bytes, largest image (pixels)];
+ * file_status[i] = 0 (decoded on the GPU, images are numbered in file order) or 1 (not baseline / malformed header: left to the
+ * reference's decoder).  ssg_jpeg_parse_fill writes the arguments of ssg_jpeg_decode_batch into host buffers of those sizes. */
+int ssg_jpeg_parse_open(const void* const* files, const int64_t* lens, int nfiles, int nthreads, void** handle, int64_t* counts10,
+                        int32_t* file_status);
+int ssg_jpeg_parse_fill(void* handle, int64_t* imgs, int64_t* segs, uint8_t* pool, uint16_t* look, int32_t* maxcode, int32_t* valoff,
+                        uint8_t* vals, uint16_t* qts);
+int ssg_jpeg_parse_close(void* handle);
 /* x = sqrt(max(x, lo)) in place: with ssg_pairwise_sqdist_f32 the pairwise block of the fine-tune phase's TripletLoss
  * (reid/loss/triplet.py:28-31: dist = (|x|^2 + |x|^2' - 2 x x').clamp(min=1e-12).sqrt()) */
 int ssg_clamp_sqrt_f32(float* x, int64_t n, float lo, ssg_stream_t stream);

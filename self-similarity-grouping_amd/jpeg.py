@@ -77,6 +77,8 @@ def _scan_header(buf):
             while q < len(body):
                 prec, tid = body[q] >> 4, body[q] & 15
                 q += 1
+                if tid > 3 or prec > 1:                      # jdmarker.c get_dqt: JERR_DQT_INDEX
+                    raise NotBaseline("bad quantisation table index")
                 if prec:
                     vals = struct.unpack_from(">64H", body, q); q += 128
                 else:
@@ -184,21 +186,72 @@ def _pillow_rgb(data):
     return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
 
 
-def decode_batch(files, device=None):
-    """list of file contents (bytes) -> list of uint8 CUDA tensors [H, W, 3] (RGB), one per file, in order"""
-    import re
+class _Parsed(object):
+    """host-side description of a batch (everything ssg_jpeg_decode_batch needs), numpy arrays + the files left to Pillow"""
+    __slots__ = ("kept", "fallback", "dims", "imgs", "segs", "pool", "look", "maxcode", "valoff", "vals", "qts", "blocks", "max_blocks", "plane_bytes",
+                 "out_bytes", "max_pixels")
+
+
+def parse_batch(files, threads=None):
+    """marker walk + table building for a batch of files (host only, no device work) -> _Parsed.
+    kept = indices of the files the GPU decodes (in batch order), fallback = indices left to Pillow, dims[k] = (H, W) of kept[k].
+    Default: the native threaded parser of the C ABI (csrc/jpeg_host.hip: ssg_jpeg_parse_open / _fill / _close; `threads` or
+    SSG_JPEG_THREADS, default 4); SSG_JPEG_PARSER=python runs the Python statement below (same result, one core, ~55 us per file)."""
+    import os
+    if os.environ.get("SSG_JPEG_PARSER", "native") != "python":
+        return _parse_batch_native(files, threads)
+    return parse_batch_python(files)
+
+
+def _parse_batch_native(files, threads=None):
+    import ctypes
+    import os
     L = _lib.lib()
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    out = [None] * len(files)
-    hdrs = []
+    n = len(files)
+    P = _Parsed()
+    P.kept, P.fallback, P.dims = [], [], []
+    if n == 0:
+        return P
+    nt = int(threads or os.environ.get("SSG_JPEG_THREADS", "4"))
+    keep = [f if isinstance(f, bytes) else bytes(f) for f in files]           # (the C side reads them in place: keep them alive)
+    arr = (ctypes.c_char_p * n)(*keep)
+    lens = np.fromiter((len(f) for f in keep), np.int64, n)
+    counts = np.zeros(10, np.int64); status = np.zeros(n, np.int32)
+    h = ctypes.c_void_p()
+    check(L.ssg_jpeg_parse_open(ctypes.cast(arr, ctypes.c_void_p), lens.ctypes.data_as(ctypes.c_void_p), n, nt, ctypes.byref(h),
+                                counts.ctypes.data_as(ctypes.c_void_p), status.ctypes.data_as(ctypes.c_void_p)), "ssg_jpeg_parse_open")
+    try:
+        nk, nseg, npool, ntab, nqt = (int(c) for c in counts[:5])
+        P.fallback = np.nonzero(status)[0].tolist()
+        P.kept = np.nonzero(status == 0)[0].tolist()
+        if nk == 0:
+            return P
+        P.imgs = np.empty((nk, IMG_WORDS), np.int64); P.segs = np.empty((nseg, SEG_WORDS), np.int64); P.pool = np.empty(npool, np.uint8)
+        P.look = np.empty((ntab, 256), np.uint16); P.maxcode = np.empty((ntab, 18), np.int32); P.valoff = np.empty((ntab, 17), np.int32)
+        P.vals = np.empty((ntab, 256), np.uint8); P.qts = np.empty((nqt, 64), np.uint16)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)    # noqa: E731
+        check(L.ssg_jpeg_parse_fill(h, vp(P.imgs), vp(P.segs), vp(P.pool), vp(P.look), vp(P.maxcode), vp(P.valoff), vp(P.vals), vp(P.qts)), "ssg_jpeg_parse_fill")
+    finally:
+        L.ssg_jpeg_parse_close(h)
+    P.dims = [(int(hh), int(ww)) for ww, hh in P.imgs[:, :2]]
+    P.blocks, P.max_blocks, P.plane_bytes, P.out_bytes, P.max_pixels = (int(c) for c in counts[5:10])
+    return P
+
+
+def parse_batch_python(files):
+    """the host bookkeeping stated in Python (the checker of the native parser; SSG_JPEG_PARSER=python makes it the product path)"""
+    import re
+    P = _Parsed()
+    hdrs, P.fallback = [], []
     for i, data in enumerate(files):
         try:
             hdrs.append((i, scan_header(data)))
         except NotBaseline:
-            out[i] = torch.from_numpy(np.array(_pillow_rgb(data))).to(device)
-            stats["pillow"] += 1
+            P.fallback.append(i)
+    P.kept = [i for i, _ in hdrs]
+    P.dims = [(h.height, h.width) for _, h in hdrs]
     if not hdrs:
-        return out
+        return P
     huff, huff_ids, qts, qt_ids = [], {}, [], {}
 
     def huff_id(spec):
@@ -242,26 +295,49 @@ def decode_batch(files, device=None):
             segs.append((k, ecs_off + start, len(ecs) - start, m0, min(ri, nmcu - m0)))
         chunks.append(ecs)
         ecs_off += len(ecs)
-    pool = np.frombuffer(b"".join(chunks) + bytes(64), np.uint8)
-    segs = np.asarray(segs, np.int64).reshape(-1, SEG_WORDS)
-    look = np.stack([t[0] for t in huff]); maxcode = np.stack([t[1] for t in huff]); valoff = np.stack([t[2] for t in huff]); vals = np.stack([t[3] for t in huff])
+    P.pool = np.frombuffer(b"".join(chunks) + bytes(64), np.uint8)
+    P.segs = np.asarray(segs, np.int64).reshape(-1, SEG_WORDS)
+    P.imgs = imgs
+    P.look = np.stack([t[0] for t in huff]); P.maxcode = np.stack([t[1] for t in huff]); P.valoff = np.stack([t[2] for t in huff])
+    P.vals = np.stack([t[3] for t in huff]); P.qts = np.stack(qts)
+    P.blocks, P.max_blocks, P.plane_bytes, P.out_bytes, P.max_pixels = blocks, max_blocks, plane_off, out_off, max_pixels
+    return P
+
+
+def decode_batch(files, device=None, packed=False):
+    """list of file contents (bytes) -> list of uint8 CUDA tensors [H, W, 3] (RGB), one per file, in order.
+    packed=True: when every file was decoded on the GPU and all share one size (a Market-1501 batch), ONE tensor [B, H, W, 3] is
+    returned instead of the list (no per-file views, no stack)."""
+    L = _lib.lib()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    out = [None] * len(files)
+    P = parse_batch(files)
+    for i in P.fallback:
+        out[i] = torch.from_numpy(np.array(_pillow_rgb(files[i]))).to(device)
+        stats["pillow"] += 1
+    if not P.kept:
+        return out
     d = lambda a: torch.from_numpy(np.array(a)).to(device)
-    pool_d, segs_d, imgs_d = d(pool), d(segs), d(imgs)
-    look_d, maxcode_d, valoff_d, vals_d, qts_d = d(look), d(maxcode), d(valoff), d(vals), d(np.stack(qts))
-    coef = torch.empty(blocks * 64, dtype=torch.int16, device=device)
-    planes = torch.empty(max(plane_off, 1), dtype=torch.uint8, device=device)
-    rgb = torch.empty(out_off, dtype=torch.uint8, device=device)
-    status = torch.empty(len(hdrs), dtype=torch.int32, device=device)
-    check(L.ssg_jpeg_decode_batch(ptr(pool_d), ptr(segs_d), int(segs.shape[0]), ptr(imgs_d), len(hdrs), ptr(look_d), ptr(maxcode_d), ptr(valoff_d), ptr(vals_d),
-                                  ptr(qts_d), ptr(coef), blocks, max_blocks, ptr(planes), max_pixels, ptr(rgb), ptr(status), stream()), "ssg_jpeg_decode_batch")
+    pool_d, segs_d, imgs_d = d(P.pool), d(P.segs), d(P.imgs)
+    look_d, maxcode_d, valoff_d, vals_d, qts_d = d(P.look), d(P.maxcode), d(P.valoff), d(P.vals), d(P.qts)
+    coef = torch.empty(P.blocks * 64, dtype=torch.int16, device=device)
+    planes = torch.empty(max(P.plane_bytes, 1), dtype=torch.uint8, device=device)
+    rgb = torch.empty(P.out_bytes, dtype=torch.uint8, device=device)
+    status = torch.empty(len(P.kept), dtype=torch.int32, device=device)
+    check(L.ssg_jpeg_decode_batch(ptr(pool_d), ptr(segs_d), int(P.segs.shape[0]), ptr(imgs_d), len(P.kept), ptr(look_d), ptr(maxcode_d), ptr(valoff_d), ptr(vals_d),
+                                  ptr(qts_d), ptr(coef), P.blocks, P.max_blocks, ptr(planes), P.max_pixels, ptr(rgb), ptr(status), stream()), "ssg_jpeg_decode_batch")
     damaged = set(torch.nonzero(status).flatten().tolist())     # one small read-back per batch (the pixels are consumed on the device)
-    for k, (i, h) in enumerate(hdrs):
+    if packed and not damaged and not P.fallback and all(dm == P.dims[0] for dm in P.dims):
+        stats["gpu"] += len(P.kept)
+        return rgb.view(len(P.kept), P.dims[0][0], P.dims[0][1], 3)
+    for k, i in enumerate(P.kept):
         if k in damaged:
             # short / corrupt entropy-coded data: Pillow decodes (or raises "image file is truncated") exactly like the reference
             out[i] = torch.from_numpy(np.array(_pillow_rgb(files[i]))).to(device)
             stats["pillow"] += 1; stats["damaged"] = stats.get("damaged", 0) + 1
             continue
-        o = int(imgs[k, 7])
-        out[i] = rgb[o:o + h.width * h.height * 3].view(h.height, h.width, 3)
-    stats["gpu"] += len(hdrs) - len(damaged)
+        o = int(P.imgs[k, 7])
+        hh, ww = P.dims[k]
+        out[i] = rgb[o:o + ww * hh * 3].view(hh, ww, 3)
+    stats["gpu"] += len(P.kept) - len(damaged)
     return out

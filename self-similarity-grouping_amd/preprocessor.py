@@ -153,12 +153,15 @@ class GpuBatchLoader(object):
         for b0 in range(self.first, n, self.batch_size):
             recs = [self.items[i] for i in range(b0, min(n, b0 + self.batch_size))]
             dev = torch.device("cuda", torch.cuda.current_device()) if self.device is None else torch.device(self.device)
-            out = torch.empty((len(recs), 3, self.height, self.width), dtype=torch.float32, device=dev)
             if self.decode == "gpu":
                 from .jpeg import decode_batch
-                pix = decode_batch([r[0] for r in recs], dev)          # uint8 CUDA [H, W, 3] per file
+                pix = decode_batch([r[0] for r in recs], dev, packed=True)   # uint8 CUDA [H, W, 3] per file, or ONE [B, H, W, 3] tensor
+                if torch.is_tensor(pix):                               # a batch of equally sized baseline files: straight into the transform
+                    yield preprocess_batch(pix, self.height, self.width, self.mean, self.std, dev), [r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs]
+                    continue
             else:
                 pix = [r[0] for r in recs]
+            out = torch.empty((len(recs), 3, self.height, self.width), dtype=torch.float32, device=dev)
             by_size = {}
             for j, a in enumerate(pix):
                 by_size.setdefault(tuple(a.shape[:2]), []).append(j)

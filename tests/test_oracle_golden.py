@@ -291,6 +291,40 @@ def test_jpeg_host_parser_matches_oracle(golden):
             pj.scan_header(bad)
 
 
+def test_jpeg_native_parser_matches_python(golden):
+    """csrc/jpeg_host.hip (ssg_jpeg_parse_open / _fill / _close: the threaded native marker walk the product uses) against the Python
+    statement of the same bookkeeping (ssg_amd.jpeg.parse_batch_python), field by field -- which files go to the GPU, geometry,
+    block / plane / output offsets, restart segments, the entropy-coded pool, derived Huffman tables, quantisation tables -- on the
+    committed files, on every 3rd truncation of one of them and on 2000 files with random byte damage in their headers (both must
+    hand exactly the same files to Pillow).  Host code only: no GPU."""
+    from ssg_amd import jpeg as pj
+    g = golden("jpeg_cases.npz")
+    files = [g["file_%02d" % i].tobytes() for i in range(int(g["count"]))] + [g["progressive_file"].tobytes(), b"", b"\x89PNG\r\n\x1a\n" + bytes(32)]
+
+    def same(a, b):
+        assert a.kept == b.kept and a.fallback == b.fallback and a.dims == b.dims
+        if not a.kept:
+            return
+        for k in ("imgs", "segs", "pool", "look", "maxcode", "valoff", "vals", "qts"):
+            x, y = getattr(a, k), getattr(b, k)
+            assert x.shape == y.shape and x.dtype == y.dtype and np.array_equal(x, y), k
+        for k in ("blocks", "max_blocks", "plane_bytes", "out_bytes", "max_pixels"):
+            assert getattr(a, k) == getattr(b, k), k
+    same(pj._parse_batch_native(files), pj.parse_batch_python(files))
+    same(pj._parse_batch_native(files, threads=1), pj._parse_batch_native(files, threads=7))
+    rng = np.random.default_rng(0)
+    cases = [files[0][:c] for c in range(0, len(files[0]), 3)]
+    for _ in range(2000):
+        f = bytearray(files[int(rng.integers(0, len(files) - 3))])
+        for q in rng.integers(2, min(len(f), 700), int(rng.integers(1, 4))):
+            f[int(q)] = int(rng.integers(0, 256))
+        cases.append(bytes(f))
+    nat = pj._parse_batch_native(cases, threads=4)
+    same(nat, pj.parse_batch_python(cases))
+    assert len(nat.fallback) > 100 and len(nat.kept) > 100
+    assert pj._parse_batch_native([]).kept == []
+
+
 def test_jpeg_host_parser_hands_malformed_files_to_pillow(golden):
     """a short / odd marker segment must never abort the batch with IndexError / struct.error -- every truncation and a set of
     corrupted headers either parses (damage inside the entropy-coded data is caught on the device) or raises NotBaseline (-> Pillow);

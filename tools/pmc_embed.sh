@@ -8,4 +8,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "== $c"; python3 $R/tools/pmc_agg.py $OUT/$c 40
 done > $OUT.txt 2>&1
 tail -60 $OUT.txt
-python3 $R/tools/pmc_embed_summary.py $OUT.txt ${PMC_B:-1000} $R/gpurun_out/r03_pmc_conv_traffic
+python3 $R/tools/pmc_embed_summary.py $OUT.txt ${PMC_B:-1000} $R/gpurun_out/${PMC_PREFIX:-r04}_pmc_conv_traffic

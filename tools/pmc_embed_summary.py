@@ -61,11 +61,11 @@ def main():
     fetch, write = fs * 1024 * 2 / 4, ws * 1024 / 4
     alg, nl = algorithmic_bytes(B)
     sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-    from bench import build_fingerprint
-    js = {"source": "profiles/r03_pmc_conv_traffic.md", "build": build_fingerprint(), "batch": B, "launches_per_forward": fn // 4, "fetch_bytes_per_forward": fetch,
+    from bench import build_fingerprint, embed_fingerprint
+    js = {"source": "profiles/%s.md" % __import__("os").path.basename(out), "build": build_fingerprint(), "embed_build": embed_fingerprint(), "batch": B, "launches_per_forward": fn // 4, "fetch_bytes_per_forward": fetch,
           "write_bytes_per_forward": write, "algorithmic_bytes_per_forward": alg}
     json.dump(js, open(out + ".json", "w"))
-    md = """# rocprofv3 PMC: HBM traffic of the embedding's convolution launches (round 3 build: fused stem, layer1 and layer2 identity blocks)
+    md = """# rocprofv3 PMC: HBM traffic of the embedding's convolution launches (fused stem, layer1 and layer2 identity blocks)
 
 Separate passes `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (`--output-format csv`, `tools/pmc_embed.sh`) over
 `python tools/time_embed.py --B %d --iters 1` = 4 forwards of %d images (warm-up + timed, original + flipped), aggregated per

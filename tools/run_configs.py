@@ -11,11 +11,35 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def sync():
     torch.cuda.synchronize()
     return time.perf_counter()
+
+
+def group_roofline(src, tgt, lam, rho, splits=1):
+    """one more (untimed by the wall clock) grouping leg with HIP events around every C-ABI launch -> the same `roofline_kernels` /
+    `roofline_k5_k12` objects as bench.py (tools/roofline.py), at this configuration's size, plus the full per-entry-point table"""
+    from ssg_amd import rerank, cluster, _lib
+    from roofline import KernelTimer, grouping_roofline
+    real = _lib.lib()
+    timer = KernelTimer(real)
+    _lib._lib = timer
+    try:
+        timer.on = True
+        h = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=lam, keep_euclid=False, validate=False)
+        eps, _, _ = cluster.eps_rule(h, rho)
+        cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h)
+        tot = timer.totals()
+    finally:
+        _lib._lib = real
+    del h
+    N, Ns = tgt.shape[0], src.shape[0]
+    kernels, k5 = grouping_roofline(tot, N, N, Ns, 1, 1, d=tgt.shape[1])
+    table = {k: {"launches": n, "ms": round(ms, 3)} for k, (n, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1])}
+    return {"roofline_kernels": kernels, "roofline_k5_k12": k5, "abi_launch_ms": table, "all_abi_ms": round(sum(ms for _, ms in tot.values()), 3)}
 
 
 def group(src, tgt, lam, rho, no_rerank=False, reps=2):
@@ -84,17 +108,21 @@ def main():
         tot = 0.0; parts = []
         for s in range(3):
             tgt = torch.from_numpy(clustered(30000, 2048, 10 + s)).to(dev); src = torch.from_numpy(clustered(12936, 2048, 20 + s, intra=0.7)).to(dev)
-            r = group(src, tgt, 0.3, 1.6e-3, reps=1); parts.append(r); tot += r["total_s"]
+            r = group(src, tgt, 0.3, 1.6e-3, reps=1 if s else 2); parts.append(r); tot += r["total_s"]
+            if s == 0:
+                roof = group_roofline(src, tgt, 0.3, 1.6e-3)
             del tgt, src
         print(json.dumps({"config": 3, "what": "N=30000 (Ns=12936), 3 feature splits, ONE GPU: embed (num_split=2) + 3 x (re-rank + eps + DBSCAN)",
-                          "embed_s": es, "embed_img_s": rate, "grouping_s_3_splits": round(tot, 4), "iteration_s": round(es + tot, 3), "splits": parts}), flush=True)
+                          "embed_s": es, "embed_img_s": rate, "grouping_s_3_splits": round(tot, 4), "iteration_s": round(es + tot, 3), "splits": parts,
+                          "per_kernel_of_one_split": roof}), flush=True)
     if "4" in which:
         N = 128000
         tgt = torch.from_numpy(clustered(N, 2048, 31)).to(dev); src = torch.from_numpy(clustered(12936, 2048, 32, intra=0.7)).to(dev)
         r = group(src, tgt, 0.3, 1.6e-3, reps=2)       # best of two: the first call pays for 64+ GB of fresh allocations
         nn2 = 8.0 * N * N
+        roof = group_roofline(src, tgt, 0.3, 1.6e-3)
         print(json.dumps({"config": 4, "what": "N=128000 re-rank + eps + DBSCAN on ONE GPU (32 GB half D + 32 GB half J'), second call", **r,
-                          "k5_k12_algorithmic_GB": round(nn2 / 1e9, 1)}), flush=True)
+                          "k5_k12_algorithmic_GB": round(nn2 / 1e9, 1), "per_kernel": roof}), flush=True)
 
 
 if __name__ == "__main__":
