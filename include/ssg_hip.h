@@ -139,6 +139,16 @@ int ssg_invert_index(const int32_t* q_idx, const uint16_t* q_val, const int32_t*
 int ssg_jaccard_rows(const int32_t* q_idx, const uint16_t* q_val, const int32_t* q_nnz, int capQ, const int64_t* colptr,
                      const int32_t* inv_row, const uint16_t* inv_val, int64_t inv_nnz, int32_t* colmeta, int N, int row0, int nrows,
                      uint16_t one_minus_lambda_half, uint16_t* Jp, ssg_stream_t stream);
+/* Second generation (round 4): the same J' rows with every line written once, plus a SPARSE copy S of the columns the row's walk
+ * touched -- every other column holds the constant J'(0) = half(1 - lambda), the largest value of the row.  s_pool [s_cap] uint32 =
+ * packed (J' << 17 | column); seg_off / seg_len [nrows * ssg_jaccard_segments(N)] = the segment of every (row, 32768-column chunk);
+ * s_cursor [2] uint64 (zeroed by the call): entries allocated, and 1 when a segment did not fit (S unusable: consumers go dense).
+ * s_pool == NULL: J' only.  ssg_eps_compact_below_s / ssg_region_query_s are the passes that walk S instead of the N x N matrix. */
+int ssg_jaccard_segments(int N);
+int ssg_jaccard_rows2(const int32_t* q_idx, const uint16_t* q_val, const int32_t* q_nnz, int capQ, const int64_t* colptr,
+                      const int32_t* inv_row, const uint16_t* inv_val, int64_t inv_nnz, int32_t* colmeta, int N, int row0, int nrows,
+                      uint16_t one_minus_lambda_half, uint16_t* Jp, uint32_t* s_pool, uint64_t s_cap, uint64_t* s_cursor, int64_t* seg_off,
+                      int32_t* seg_len, ssg_stream_t stream);
 /* API materialisation of final_dist (rerank.py:122): out[il,k] = f64(Jp) + f64(half(v_i+v_k))*lambda */
 int ssg_final_dist_f64(const uint16_t* Jp, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double* out,
                        ssg_stream_t stream);
@@ -169,6 +179,12 @@ int ssg_eps_select_threshold(const uint64_t* hist, double quantile, uint64_t* th
 int ssg_eps_refine_threshold(const uint64_t* hist2, uint64_t* thr, ssg_stream_t stream);
 int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
                           const uint64_t* thr3, uint64_t* buf, uint64_t cap, uint64_t* cursor2, ssg_stream_t stream);
+/* the same pass through the sparse copy S (mode 0 handles only): cursor3 = {keys collected, exact zeros, dense pass needed} zeroed by
+ * the caller; the walk over S does the work when the threshold lies below J'(0) and S is complete, otherwise it raises cursor3[2]
+ * and the dense pass queued behind it (inside this call) runs -- decided on the device, no read-back in between */
+int ssg_eps_compact_below_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, const uint64_t* thr3,
+                            uint64_t* buf, uint64_t cap, uint64_t* cursor3, const uint32_t* s_pool, const int64_t* seg_off,
+                            const int32_t* seg_len, int nseg, const uint64_t* s_cursor, uint16_t jp0_half, ssg_stream_t stream);
 int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t value, ssg_stream_t stream);
 int ssg_sort_u64(uint64_t* buf, uint64_t n_pow2, ssg_stream_t stream); /* ascending, n = 2^k >= 2048 */
 size_t ssg_eps_mean_workspace_bytes(int64_t top);
@@ -184,6 +200,10 @@ int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mode, void* w
 /* cnt[il] = |{k: d(i,k) <= eps}|; edges[2e],[2e+1] = (i,k) for every hit (cursor counts all) */
 int ssg_region_query(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps,
                      int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, ssg_stream_t stream);
+/* the same through S: only valid for eps < f64(J'(0)) and a complete S (the caller has read s_cursor[1] == 0); refused otherwise */
+int ssg_region_query_s(const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
+                       const int64_t* seg_off, const int32_t* seg_len, int nseg, uint16_t jp0_half, int32_t* cnt, int32_t* edges,
+                       uint64_t cap_edges, uint64_t* cursor, ssg_stream_t stream);
 size_t ssg_dbscan_cc_workspace_bytes(int N);
 /* cnt is the FULL [N] table, edges the concatenated edge list: labels[N] int64, -1 = noise */
 int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,

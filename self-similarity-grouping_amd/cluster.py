@@ -89,24 +89,38 @@ def _eps_rule_sampled(L, h, rho, st):
     cap = max(6 * expected_top * h.nrows // N + (1 << 16), 1 << 16)
     n_cap = max(2048, 1 << (cap - 1).bit_length())
     buf = torch.empty(n_cap, dtype=torch.int64, device=dev)
-    cursor = torch.zeros(2, dtype=torch.int64, device=dev)
-    check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
+    cursor = torch.zeros(3, dtype=torch.int64, device=dev)
+    sp = getattr(h, "sparse", None) if h.mode == 0 else None
+    if sp is not None:
+        # through the sparse copy S of J' when the threshold lies below J'(0) (decided on the device; the dense pass is queued behind it)
+        check(L.ssg_eps_compact_below_s(ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.lambda_value, ptr(thr3), ptr(buf), n_cap, ptr(cursor), ptr(sp["pool"]),
+                                        ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]), sp["jp0"], st), "ssg_eps_compact_below_s")
+    else:
+        check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
     pend = h.take_pending() if hasattr(h, "take_pending") else None    # the re-rank's status words ride along with this read-back
-    vals = torch.cat([cursor, thr3[:1]] + ([pend.to(torch.int64)] if pend is not None else [])).tolist()       # host round trip 1
+    npend = int(pend.numel()) if pend is not None else 0
+    local = torch.cat([cursor[:2], thr3[:1]] + ([pend.to(torch.int64)] if pend is not None else []))
+    if h.group is not None:
+        # sharded rows: ONE flat all-gather of every rank's (candidates, zeros, threshold, status words) and ONE blocking read of
+        # the table give each rank its own values, the global sums for the accept / fall-back decision (the same on every rank)
+        # and the block lengths of the candidate gather -- no all-reduce + read, no separate size exchange
+        import torch.distributed as dist
+        table = gather_rows(local.view(1, -1), h.group).tolist()                                                # host round trip 1
+        vals = table[dist.get_rank(h.group)]
+        gots = [int(r[0]) for r in table]
+        zeros_all, got_all, overflow = sum(int(r[1]) for r in table), sum(gots), int(any(g > n_cap for g in gots))
+    else:
+        vals = local.tolist()                                                                                    # host round trip 1
     got, zeros, thr_bits = vals[:3]
     if pend is not None:
-        if h.resolve_pending(vals[3:3 + int(pend.numel())]):
+        if h.resolve_pending(vals[3:3 + npend]):
             # the query expansion had run on too small a guess and the distance matrix was rebuilt just now: the passes above
             # saw the old contents -- run them again (once; the handle has no pending words any more)
             return _eps_rule_sampled(L, h, rho, st)
         h.validate()
     thr = float(np.uint32(thr_bits & 0xFFFFFFFF).view(np.float32))
-    overflow = int(got > n_cap)
-    if h.group is not None:             # the accept / fall-back decision must be the same on every rank
-        tot = _all_reduce(torch.tensor([zeros, got, overflow], dtype=torch.int64, device=dev), h.group).tolist()
-        zeros_all, got_all, overflow = int(tot[0]), int(tot[1]), int(tot[2])
-    else:
-        zeros_all, got_all = int(zeros), int(got)
+    if h.group is None:
+        zeros_all, got_all, overflow = int(zeros), int(got), int(got > n_cap)
     count = upper_total - zeros_all
     top = int(np.round(rho * count))                  # np.round: half to even (selftraining.py:292)
     if top <= 0:
@@ -114,7 +128,8 @@ def _eps_rule_sampled(L, h, rho, st):
     if overflow or got_all < top or not np.isfinite(thr):
         return None
     if h.group is not None:
-        allk = gather_varlen(buf[:got], h.group)
+        from .dist import gather_ragged
+        allk = gather_ragged(buf[:got], gots, h.group)
         got = int(allk.shape[0])
         n_pow2 = max(2048, 1 << (got - 1).bit_length())
         buf = torch.empty(n_pow2, dtype=torch.int64, device=dev)
@@ -220,8 +235,15 @@ class DBSCAN:
         while True:
             edges = torch.empty((cap, 2), dtype=torch.int32, device=dev)
             cursor = torch.zeros(1, dtype=torch.int64, device=dev)
-            check(L.ssg_region_query(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, eps, ptr(cnt), ptr(edges), cap,
-                                     ptr(cursor), st), "ssg_region_query")
+            sp = getattr(h, "sparse", None) if h.mode == 0 else None
+            if (sp is not None and h.sparse_ok and h.lambda_value >= 0.0 and 0 < sp["jp0"] < 0x7C00
+                    and eps < float(np.uint16(sp["jp0"]).view(np.float16))):
+                # eps lies below J'(0): only the columns of the sparse copy S can be neighbours
+                check(L.ssg_region_query_s(ptr(h.v), N, h.row0, h.nrows, h.lambda_value, eps, ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"],
+                                           sp["jp0"], ptr(cnt), ptr(edges), cap, ptr(cursor), st), "ssg_region_query_s")
+            else:
+                check(L.ssg_region_query(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, eps, ptr(cnt), ptr(edges), cap,
+                                         ptr(cursor), st), "ssg_region_query")
             if h.group is None:
                 # one GPU: components and labels follow on the stream, the edge count stays on the device; ONE read-back at
                 # the end brings labels, neighbour counts and the count (which tells whether the edge list was big enough)
@@ -235,17 +257,21 @@ class DBSCAN:
                     break
                 cap = ne       # the cursor counted every hit: retry once with the exact size
                 continue
-            ne = int(cursor.item())
-            if ne <= cap:
-                edges = edges[:ne]
+            # sharded rows: ONE flat all-gather of the edge counts + ONE blocking read give this rank's count (capacity check) and the
+            # block lengths of the edge gather; the labels and the neighbour counts come back with one more read
+            from .dist import gather_ragged
+            nes = [int(x) for x in gather_rows(cursor.view(1, 1), h.group).flatten().tolist()]
+            if max(nes) <= cap:
                 cnt_all = gather_rows(cnt, h.group, N)
-                edges = gather_varlen(edges, h.group).contiguous()
+                import torch.distributed as dist
+                edges = gather_ragged(edges[:nes[dist.get_rank(h.group)]], nes, h.group).contiguous()
                 ne = int(edges.shape[0])
                 check(L.ssg_dbscan_cc(ptr(cnt_all), ptr(edges), ne, N, int(self.min_samples), ptr(ws), ws_bytes, ptr(labels), st), "ssg_dbscan_cc")
-                self.labels_ = labels.cpu().numpy()
-                self.core_sample_indices_ = torch.nonzero(cnt_all >= int(self.min_samples)).flatten().cpu().numpy()
+                host = torch.cat([labels, cnt_all.to(torch.int64)]).cpu().numpy()
+                self.labels_ = host[:N].copy()
+                self.core_sample_indices_ = np.nonzero(host[N:] >= int(self.min_samples))[0]
                 break
-            cap = ne
+            cap = max(nes)          # every rank retries with the same capacity (the collectives stay matched)
         self.n_features_in_ = N
         return self
 

@@ -431,8 +431,10 @@ __global__ __launch_bounds__(1024) void eps_select2_kernel(const unsigned long l
 // cursor[1] += number of exact zeros in the strict upper triangle
 template <int MODE>
 __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const unsigned long long* __restrict__ thr3, unsigned long long* __restrict__ buf,
-                                                              unsigned long long cap, unsigned long long* __restrict__ cursor) {
+                                                              unsigned long long cap, unsigned long long* __restrict__ cursor,
+                                                              const unsigned long long* __restrict__ gate) {
   __shared__ unsigned long long sbuf[4][STAGE_CAP];
+  if (gate && *gate == 0ull) return;          // the sparse pass queued in front of this launch has done the work
   const int lane = lane_id();
   WaveStage<unsigned long long> st{sbuf[threadIdx.x >> 6], 0};
   const float thr = __uint_as_float((unsigned)thr3[0]);
@@ -784,6 +786,110 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
   st.flush(eout, cap, cursor, lane);
 }
 
+// ------------------------------------------------------------------ round 4: the sparse copy S of J' (jaccard.hip, second generation)
+// S holds, per (row, column chunk), the packed words (J' << 17 | column) of every column the row's Jaccard walk touched; every other
+// column of the row holds the constant J'(0) = half(1 - lambda), the LARGEST value J' takes.  final_dist = J' + lambda * half(v_i + v_k)
+// with v >= 0 and lambda >= 0, so an entry outside S is >= f64(J'(0)): while the bound a pass asks about stays below that, only S can
+// hold what it looks for -- a few hundred entries per row instead of N.
+struct SparseView {
+  const uint32_t* pool; const int64_t* seg_off; const int32_t* seg_len; int nseg;
+  const unsigned long long* s_cursor;      // [1] != 0: a segment did not fit, S is unusable
+  hbits jp0;                               // J'(0)
+};
+// Is the sparse walk valid for an (exclusive) upper bound `bound` on the values looked for?  (all lanes agree)
+__device__ __forceinline__ bool sparse_usable(const SparseView& sv, const MatView& mv, double bound) {
+  return sv.pool && mv.mode == 0 && sv.s_cursor[1] == 0ull && mv.lambda_value >= 0.0 && (sv.jp0 & 0x7fffu) != 0 && (sv.jp0 & 0x8000u) == 0 &&
+         bound <= (double)h2f(sv.jp0);
+}
+
+// eps rule, the one full pass, on S: exact float64 keys of the strict-upper non-zero elements whose surrogate is < *thr -> buf
+// (cursor[0]); cursor[1] += exact zeros.  When S cannot answer (threshold at or above J'(0), overflowed pool, exotic lambda) the
+// kernel only raises cursor[2] and the dense pass that is queued behind it (gate = cursor + 2) does the work.
+__global__ __launch_bounds__(256) void eps_compact_sparse_kernel(MatView mv, SparseView sv, const unsigned long long* __restrict__ thr3,
+                                                                 unsigned long long* __restrict__ buf, unsigned long long cap,
+                                                                 unsigned long long* __restrict__ cursor) {
+  __shared__ unsigned long long sbuf[4][STAGE_CAP];
+  const int lane = lane_id();
+  const float thr = __uint_as_float((unsigned)thr3[0]);
+  // the surrogate is within 4e-7 * (1 + |x|) of the exact value: leave that margin below J'(0)
+  if (!(thr > 0.f) || !sparse_usable(sv, mv, (double)thr * 1.000002 + 2e-6)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) cursor[2] = 1ull;
+    return;
+  }
+  WaveStage<unsigned long long> st{sbuf[threadIdx.x >> 6], 0};
+  const float lam32 = (float)mv.lambda_value;
+  unsigned long long zeros = 0;
+  for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
+    const int gi = mv.row0 + il;
+    const hbits vi = mv.v[gi];
+    for (int sg = 0; sg < sv.nseg; sg++) {
+      const int64_t off = sv.seg_off[(int64_t)il * sv.nseg + sg];
+      const int len = sv.seg_len[(int64_t)il * sv.nseg + sg];
+      for (int q0 = 0; q0 < len; q0 += 64) {
+        const int q = q0 + lane;
+        unsigned long long key = ~0ULL;
+        if (q < len) {
+          const uint32_t e = sv.pool[off + q];
+          const int k = (int)(e & 0x1ffffu);
+          const hbits jp = (hbits)(e >> 17);
+          if (k > gi) {
+            const hbits s = h_add(mv.v[k], vi);
+            const float sur = h2f(jp) + h2f(s) * lam32;
+            if (sur < thr) {
+              const double d = final_dist_value(jp, vi, mv.v[k], mv.lambda_value);
+              if (d != 0.0) key = (unsigned long long)__double_as_longlong(d); else zeros++;
+            } else if ((jp & 0x7fffu) == 0 && ((s & 0x7fffu) == 0 || mv.lambda_value == 0.0)) zeros++;     // (an exact zero has surrogate 0 < thr: never here)
+          }
+        }
+        const uint64_t bm = __ballot(key != ~0ULL);
+        if (bm) {
+          if (key != ~0ULL) st.buf[st.n + __popcll(bm & lanemask_lt())] = key;
+          st.n += __popcll(bm);
+          if (st.n > STAGE_CAP - 64) st.flush(buf, cap, cursor, lane);
+        }
+      }
+    }
+  }
+  st.flush(buf, cap, cursor, lane);
+  for (int sh = 1; sh < 64; sh <<= 1) zeros += (unsigned long long)__shfl_xor((long long)zeros, sh, 64);
+  if (lane == 0 && zeros) atomicAdd(&cursor[1], zeros);
+}
+
+// region query on S: valid while eps < f64(J'(0)) (the host checks that and the pool's overflow word before it chooses this kernel)
+__global__ __launch_bounds__(256) void region_query_sparse_kernel(MatView mv, SparseView sv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
+                                                                  unsigned long long cap, unsigned long long* __restrict__ cursor) {
+  __shared__ Edge sbuf[4][STAGE_CAP];
+  const int lane = lane_id();
+  WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
+  Edge* eout = reinterpret_cast<Edge*>(edges);
+  for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
+    const int gi = mv.row0 + il;
+    const hbits vi = mv.v[gi];
+    int rowcnt = 0;
+    for (int sg = 0; sg < sv.nseg; sg++) {
+      const int64_t off = sv.seg_off[(int64_t)il * sv.nseg + sg];
+      const int len = sv.seg_len[(int64_t)il * sv.nseg + sg];
+      for (int q0 = 0; q0 < len; q0 += 64) {
+        const int q = q0 + lane;
+        bool hit = false; int k = 0;
+        if (q < len) {
+          const uint32_t e = sv.pool[off + q];
+          k = (int)(e & 0x1ffffu);
+          hit = final_dist_value((hbits)(e >> 17), vi, mv.v[k], mv.lambda_value) <= eps;     // exact, rerank.py:122
+        }
+        const uint64_t bm = __ballot(hit);
+        if (bm) {
+          if (hit) { Edge ed; ed.i = gi; ed.k = k; st.buf[st.n + __popcll(bm & lanemask_lt())] = ed; }
+          st.n += __popcll(bm); rowcnt += __popcll(bm);
+          if (st.n > STAGE_CAP - 64) st.flush(eout, cap, cursor, lane);
+        }
+      }
+    }
+    if (lane == 0) cnt[il] = rowcnt;
+  }
+  st.flush(eout, cap, cursor, lane);
+}
+
 // ------------------------------------------------------------------ K12 union-find
 __device__ __forceinline__ int uf_load(int* parent, int x) { return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ int uf_find(int* parent, int x) {
@@ -926,10 +1032,32 @@ extern "C" int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, in
                                      const uint64_t* thr3, uint64_t* buf, uint64_t cap, uint64_t* cursor2, hipStream_t stream) {
   int rc = check_view("ssg_eps_compact_below", M, v, N, row0, nrows, mode); if (rc) return rc;
 #define SSG_CT(MD) hipLaunchKernelGGL(eps_compact_thr_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
-                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor2)
+                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor2, (const unsigned long long*)nullptr)
   if (mode == 0) SSG_CT(0); else if (mode == 1) SSG_CT(1); else SSG_CT(2);
 #undef SSG_CT
   SSG_LAUNCH_CHECK("eps_compact_thr_kernel");
+  return SSG_OK;
+}
+
+static SparseView make_sparse(const uint32_t* pool, const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, uint16_t jp0) {
+  SparseView sv; sv.pool = pool; sv.seg_off = seg_off; sv.seg_len = seg_len; sv.nseg = nseg; sv.s_cursor = (const unsigned long long*)s_cursor; sv.jp0 = jp0;
+  return sv;
+}
+
+// The same pass through the sparse copy S of J' (ssg_jaccard_rows2): cursor3 = {keys collected, exact zeros, dense pass needed}, zeroed by
+// the caller.  Two launches: the walk over S, which either does the work or raises cursor3[2] (threshold at or above J'(0), S
+// overflowed, lambda < 0), and the dense pass gated on that word -- no host decision, no read-back in between.
+extern "C" int ssg_eps_compact_below_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, const uint64_t* thr3,
+                                       uint64_t* buf, uint64_t cap, uint64_t* cursor3, const uint32_t* s_pool, const int64_t* seg_off,
+                                       const int32_t* seg_len, int nseg, const uint64_t* s_cursor, uint16_t jp0_half, hipStream_t stream) {
+  int rc = check_view("ssg_eps_compact_below_s", M, v, N, row0, nrows, 0); if (rc) return rc;
+  if (!s_pool || !seg_off || !seg_len || nseg <= 0 || !s_cursor) { ssg_set_error("ssg_eps_compact_below_s: no sparse copy"); return SSG_ERR_INVALID; }
+  const MatView mv = make_view(M, v, N, row0, nrows, 0, lambda_value);
+  hipLaunchKernelGGL(eps_compact_sparse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, make_sparse(s_pool, seg_off, seg_len, nseg, s_cursor, jp0_half),
+                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor3);
+  hipLaunchKernelGGL(eps_compact_thr_kernel<0>, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, (const unsigned long long*)thr3, (unsigned long long*)buf,
+                     (unsigned long long)cap, (unsigned long long*)cursor3, (const unsigned long long*)(cursor3 + 2));
+  SSG_LAUNCH_CHECK("eps_compact_sparse_kernel");
   return SSG_OK;
 }
 
@@ -1050,6 +1178,26 @@ extern "C" int ssg_region_query(const void* M, const uint16_t* v, int N, int row
   if (mode == 0) SSG_RQ(0); else if (mode == 1) SSG_RQ(1); else SSG_RQ(2);
 #undef SSG_RQ
   SSG_LAUNCH_CHECK("region_query_kernel");
+  return SSG_OK;
+}
+
+// Region query through the sparse copy S of J' -- the caller has checked eps < f64(J'(0)) and that S did not overflow
+// (ssg_jaccard_rows2's s_cursor[1] == 0): then no column outside S can be a neighbour.  Same outputs as ssg_region_query.
+extern "C" int ssg_region_query_s(const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
+                                  const int64_t* seg_off, const int32_t* seg_len, int nseg, uint16_t jp0_half, int32_t* cnt, int32_t* edges,
+                                  uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
+  if (!v || !s_pool || !seg_off || !seg_len || nseg <= 0 || N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N) {
+    ssg_set_error("ssg_region_query_s: bad arguments (N=%d row0=%d nrows=%d)", N, row0, nrows); return SSG_ERR_INVALID;
+  }
+  const float jp0 = (float)__builtin_bit_cast(_Float16, jp0_half);
+  if (!(lambda_value >= 0.0) || !(eps < (double)jp0) || (jp0_half & 0x8000u)) {
+    ssg_set_error("ssg_region_query_s: eps = %g is not below J'(0) = %g (or lambda < 0): the dense region query must be used", eps, (double)jp0);
+    return SSG_ERR_INVALID;
+  }
+  const MatView mv = make_view(s_pool, v, N, row0, nrows, 0, lambda_value);
+  hipLaunchKernelGGL(region_query_sparse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, make_sparse(s_pool, seg_off, seg_len, nseg, nullptr, jp0_half), eps,
+                     cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor);
+  SSG_LAUNCH_CHECK("region_query_sparse_kernel");
   return SSG_OK;
 }
 

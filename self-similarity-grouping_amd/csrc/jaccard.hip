@@ -13,6 +13,7 @@
 // columns of row i are walked in ascending order (the reference's sequential half
 // rounding), the entries of one inverted list are independent and spread over the lanes.
 #include "ssg_common.h"
+#include <cstdlib>
 
 namespace ssg {
 
@@ -212,6 +213,198 @@ __global__ __launch_bounds__(64) void jaccard_rows_kernel(const int32_t* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- round 4
+// Second generation of the row kernel.  Same sparse walk (the reference's sequential half adds, ascending columns), new epilogue:
+//   * the touched columns are finished IN LDS first (t[k] <- J'[i,k] | 0x8000: a J' value is a non-negative half, so bit 15 is
+//     free to mark "touched"), then ONE streaming pass turns the LDS row into the J' row -- marked halves give their value, all
+//     others the constant J'(0) -- with whole 16-byte stores, and zeroes the LDS row behind itself.  Every line of J' is written
+//     exactly once (the first generation wrote the constant, waited for the stores, then patched 2-byte pieces: 577 MB of HBM
+//     writes for 512, and a full drain of the store queue per row);
+//   * the touched entries also go out as a SPARSE copy S of the row: packed (J' << 17 | column) words in a pool, one segment per
+//     (row, column chunk).  Everything not in S equals the constant J'(0) = half(1 - lambda), the largest value a row holds; the
+//     eps rule and the region query only ever ask for entries BELOW a bound, so while that bound stays under J'(0) they walk S
+//     (a few hundred entries per row) instead of streaming the N columns again (cluster.hip);
+//   * no store drain between rows, and the next row's list heads are fetched before the epilogue of the current one, so that a
+//     wave's rows overlap (the first generation paid the q_nnz -> metadata -> entries load chain at the start of every row).
+struct SparseOut {
+  uint32_t* pool;                      // packed touched entries
+  unsigned long long cap;              // pool capacity in entries
+  unsigned long long* cursor;          // [0] = entries allocated so far, [1] = 1 when a segment did not fit (S is then unusable)
+  int64_t* seg_off;                    // [nrows * nseg] start of the segment in the pool (-1: dropped)
+  int32_t* seg_len;                    // [nrows * nseg]
+  int nseg;                            // column chunks per row
+};
+
+__global__ __launch_bounds__(64) void jaccard_rows2_kernel(const int32_t* __restrict__ q_nnz, int capQ, const int64_t* __restrict__ colptr,
+                                                           const int32_t* __restrict__ q_idx, const int32_t* __restrict__ inv_row,
+                                                           const hbits* __restrict__ inv_val, int64_t inv_nnz,
+                                                           const int32_t* __restrict__ meta_base, const uint32_t* __restrict__ meta_lv, int N,
+                                                           int row0, int nrows, hbits om, hbits* __restrict__ Jp, SparseOut so) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = lane_id();
+  const int cwmax = N < JCHUNK ? N : JCHUNK;
+  hbits* t = reinterpret_cast<hbits*>(smem);
+  const int tpad = (cwmax + 7) & ~7;         // the LDS row is read in 8-column vectors
+  unsigned short* touched = reinterpret_cast<unsigned short*>(smem + (((size_t)tpad * 2 + 15) & ~(size_t)15) + 16);
+  for (int x = lane * 8; x < tpad; x += 512) *reinterpret_cast<uint4*>(t + x) = make_uint4(0, 0, 0, 0);
+  wave_sync2();
+  const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(inv_row), 0, (int)(inv_nnz * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rval = __builtin_amdgcn_make_buffer_rsrc(const_cast<hbits*>(inv_val), 0, (int)(inv_nnz * 2), 0x00020000);
+  const hbits jp0 = jaccard_scaled(0, om);   // columns that share nothing with row i
+  const unsigned jp0x2 = (unsigned)jp0 | ((unsigned)jp0 << 16);
+  const uint64_t lt = lanemask_lt();
+
+  // walk state of one (row, chunk): list heads four columns deep + metadata eight columns deep (named slots, no arrays)
+  int n = 0, mb0, mb1, mb2, mb3, k0, k1, k2, k3, ab0, ab1, ab2, ab3;
+  uint32_t ml0, ml1, ml2, ml3, al0, al1, al2, al3;
+  hbits v0, v1, v2, v3;
+  const int32_t* mb = meta_base;
+  const uint32_t* ml = meta_lv;
+#define SSG_META(P, MB, ML) { const int pp_ = (P) < n ? (P) : (n > 0 ? n - 1 : 0); MB = mb[pp_]; ML = ((P) < n && n > 0) ? ml[pp_] : 0u; }
+#define SSG_ENTRIES(MB, ML, K, V, AB, AL)                                                                \
+  {                                                                                                     \
+    AB = MB; AL = ML;                                                                                   \
+    const bool in_ = lane < (int)(ML >> 16);                                                            \
+    const unsigned o_ = (unsigned)(MB + lane);                                                          \
+    K = __builtin_amdgcn_raw_buffer_load_b32(rrow, in_ ? o_ * 4u : 0xfffffff0u, 0, 0);                 \
+    V = (hbits)__builtin_amdgcn_raw_buffer_load_b16(rval, in_ ? o_ * 2u : 0xfffffff0u, 0, 0);          \
+  }
+#define SSG_PROLOGUE(IL)                                                                                \
+  {                                                                                                     \
+    n = q_nnz[row0 + (IL)];                                                                             \
+    mb = meta_base + (int64_t)(IL) * capQ; ml = meta_lv + (int64_t)(IL) * capQ;                         \
+    SSG_META(0, mb0, ml0) SSG_META(1, mb1, ml1) SSG_META(2, mb2, ml2) SSG_META(3, mb3, ml3)             \
+    SSG_ENTRIES(mb0, ml0, k0, v0, ab0, al0) SSG_ENTRIES(mb1, ml1, k1, v1, ab1, al1)                     \
+    SSG_ENTRIES(mb2, ml2, k2, v2, ab2, al2) SSG_ENTRIES(mb3, ml3, k3, v3, ab3, al3)                     \
+    SSG_META(4, mb0, ml0) SSG_META(5, mb1, ml1) SSG_META(6, mb2, ml2) SSG_META(7, mb3, ml3)             \
+  }
+  int il = (int)blockIdx.x, cbase = 0;
+  if (il < nrows) SSG_PROLOGUE(il)
+  while (il < nrows) {
+    const int i = row0 + il;
+    const int cw = (N - cbase) < JCHUNK ? (N - cbase) : JCHUNK;
+    int ntouched = 0;          // > TCAP => the list overflowed, dense patch pass
+#define SSG_RMW(KK, VV, VIC)                                                                            \
+    {                                                                                                   \
+      const int kk = (KK) - cbase;                                                                      \
+      const bool hit_ = kk >= 0 && kk < cw;                                                             \
+      bool first_ = false;                                                                              \
+      if (hit_) { const hbits old_ = t[kk]; first_ = (old_ == 0); t[kk] = h_add(old_, h2f(VV) < h2f(VIC) ? (VV) : (VIC)); } \
+      const uint64_t fm_ = __ballot(first_);                                                            \
+      if (first_) { const int w_ = ntouched + __popcll(fm_ & lt); if (w_ < TCAP) touched[w_] = (unsigned short)kk; } \
+      ntouched += __popcll(fm_);                                                                        \
+    }
+#define SSG_APPLY(K, V, AB, AL)                                                                         \
+    {                                                                                                   \
+      const int len_ = (int)(AL >> 16);                                                                 \
+      const hbits vic_ = (hbits)(AL & 0xffffu);                                                         \
+      if (len_ > 0) {                                                                                   \
+        { const int kq_ = lane < len_ ? K : -1; SSG_RMW(kq_ < 0 ? cbase - 1 : kq_, V, vic_) }           \
+        if (len_ > 64) {                                                                                \
+          const int c_ = q_idx[(int64_t)i * capQ + pcur_];                                              \
+          const int64_t e1_ = colptr[c_ + 1];                                                           \
+          for (int64_t eb = (int64_t)AB + 64; eb < e1_; eb += 64) {                                     \
+            const int64_t e = eb + lane;                                                                \
+            const int kr_ = e < e1_ ? inv_row[e] : cbase - 1;                                           \
+            const hbits vk_ = e < e1_ ? inv_val[e] : (hbits)0;                                          \
+            SSG_RMW(kr_, vk_, vic_)                                                                     \
+          }                                                                                             \
+        }                                                                                               \
+        wave_sync2();                                                                                   \
+      }                                                                                                 \
+    }
+    for (int p = 0; p < n; p += 4) {
+      int pcur_ = p;
+      SSG_APPLY(k0, v0, ab0, al0) SSG_ENTRIES(mb0, ml0, k0, v0, ab0, al0) SSG_META(p + 8, mb0, ml0)
+      pcur_ = p + 1;
+      SSG_APPLY(k1, v1, ab1, al1) SSG_ENTRIES(mb1, ml1, k1, v1, ab1, al1) SSG_META(p + 9, mb1, ml1)
+      pcur_ = p + 2;
+      SSG_APPLY(k2, v2, ab2, al2) SSG_ENTRIES(mb2, ml2, k2, v2, ab2, al2) SSG_META(p + 10, mb2, ml2)
+      pcur_ = p + 3;
+      SSG_APPLY(k3, v3, ab3, al3) SSG_ENTRIES(mb3, ml3, k3, v3, ab3, al3) SSG_META(p + 11, mb3, ml3)
+    }
+#undef SSG_RMW
+#undef SSG_APPLY
+    // the walk of this (row, chunk) is over, its slots are dead: fetch the list heads of the next one now, under the epilogue below
+    const int il_cur = il, cbase_cur = cbase;
+    if (cbase + JCHUNK < N) cbase += JCHUNK; else { cbase = 0; il += (int)gridDim.x; }
+    if (il < nrows) SSG_PROLOGUE(il)
+
+    // ---- patch pass: finish the touched columns in LDS (value | 0x8000) and emit them as the sparse segment of this (row, chunk)
+    const int seg = il_cur * so.nseg + cbase_cur / JCHUNK;
+    unsigned long long sbase = 0;
+    bool sok = false;
+    if (so.pool && ntouched > 0) {
+      if (lane == 0) sbase = atomicAdd(so.cursor, (unsigned long long)ntouched);
+      sbase = (unsigned long long)__shfl((long long)sbase, 0, 64);
+      sok = sbase + (unsigned long long)ntouched <= so.cap;
+      if (!sok && lane == 0) so.cursor[1] = 1ull;
+    }
+    if (so.pool && lane == 0) { so.seg_off[seg] = (ntouched == 0 || sok) ? (int64_t)sbase : -1; so.seg_len[seg] = ntouched; }
+    if (ntouched <= TCAP) {
+      for (int q = lane; q < ntouched; q += 64) {
+        const int kk = touched[q];
+        const hbits jp = jaccard_scaled(t[kk], om);
+        t[kk] = (hbits)(jp | 0x8000u);
+        if (sok) so.pool[sbase + q] = ((uint32_t)jp << 17) | (uint32_t)(cbase_cur + kk);
+      }
+    } else {
+      int run = 0;
+      for (int x0 = 0; x0 < cw; x0 += 64) {
+        const int x = x0 + lane;
+        const hbits tv = x < cw ? t[x] : (hbits)0;
+        const bool nz = tv != 0;
+        hbits jp = 0;
+        if (nz) { jp = jaccard_scaled(tv, om); t[x] = (hbits)(jp | 0x8000u); }
+        const uint64_t bm = __ballot(nz);
+        if (nz && sok) so.pool[sbase + run + __popcll(bm & lt)] = ((uint32_t)jp << 17) | (uint32_t)(cbase_cur + x);
+        run += __popcll(bm);
+      }
+    }
+    wave_sync2();
+    // ---- streaming pass: LDS row -> J' row (marked halves: their value, the rest: the constant), LDS row zeroed behind it
+    {
+      hbits* out = Jp + (int64_t)il_cur * N + cbase_cur;
+      const int64_t eoff = (int64_t)il_cur * N + cbase_cur;
+      const int head = (int)((8 - (eoff & 7)) & 7);          // scalar elements before the first 16-byte boundary of the output
+      auto merge = [&](unsigned w) -> unsigned {
+        const unsigned m = ((w >> 15) & 0x00010001u) * 0xffffu;
+        return (w & 0x7fff7fffu & m) | (jp0x2 & ~m);
+      };
+      if (head == 0) {
+        const int nvec = cw >> 3;
+        for (int q = lane; q < nvec; q += 64) {
+          const uint4 x = *reinterpret_cast<const uint4*>(t + q * 8);
+          *reinterpret_cast<uint4*>(t + q * 8) = make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(out + q * 8) = make_uint4(merge(x.x), merge(x.y), merge(x.z), merge(x.w));
+        }
+        for (int x = (nvec << 3) + lane; x < cw; x += 64) { const hbits tv = t[x]; t[x] = 0; out[x] = (tv & 0x8000u) ? (hbits)(tv & 0x7fffu) : jp0; }
+      } else {
+        // rows that do not start on a 16-byte boundary (N % 8 != 0): the LDS vectors are re-cut with a funnel shift so that the
+        // global stores stay aligned; the scalar head and tail elements are written one by one
+        for (int x = lane; x < head && x < cw; x += 64) { const hbits tv = t[x]; out[x] = (tv & 0x8000u) ? (hbits)(tv & 0x7fffu) : jp0; }
+        const int nvec = cw > head ? (cw - head) >> 3 : 0;
+        for (int q = lane; q < nvec; q += 64) {
+          unsigned w[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int x = head + q * 8 + 2 * u;
+            w[u] = (unsigned)t[x] | ((unsigned)t[x + 1] << 16);
+          }
+          *reinterpret_cast<uint4*>(out + head + q * 8) = make_uint4(merge(w[0]), merge(w[1]), merge(w[2]), merge(w[3]));
+        }
+        for (int x = head + (nvec << 3) + lane; x < cw; x += 64) { const hbits tv = t[x]; out[x] = (tv & 0x8000u) ? (hbits)(tv & 0x7fffu) : jp0; }
+        wave_sync2();
+        for (int x = lane * 8; x < tpad; x += 512) *reinterpret_cast<uint4*>(t + x) = make_uint4(0, 0, 0, 0);
+      }
+    }
+    wave_sync2();
+  }
+#undef SSG_META
+#undef SSG_ENTRIES
+#undef SSG_PROLOGUE
+}
+
 // API materialisation of rerank.py:122 (f64 N x N); not on the fused device path.
 __global__ void final_dist_kernel(const hbits* __restrict__ Jp, const hbits* __restrict__ v, int N, int row0, int nrows, double lambda_value,
                                   double* __restrict__ out) {
@@ -255,6 +448,41 @@ extern "C" int ssg_jaccard_rows(const int32_t* q_idx, const uint16_t* q_val, con
   hipLaunchKernelGGL(jaccard_rows_kernel, dim3(grid), dim3(64), lds, stream, q_nnz, capQ, colptr, q_idx, inv_row, inv_val, inv_nnz, meta_base, meta_lv,
                      N, row0, nrows, one_minus_lambda_half, Jp);
   SSG_LAUNCH_CHECK("jaccard_rows_kernel");
+  return SSG_OK;
+}
+
+// Second generation (round 4): the same J' rows, every line written once, plus the sparse copy S of the touched entries.
+//   s_pool [s_cap] uint32: packed (J' << 17 | column); seg_off / seg_len [nrows * ssg_jaccard_segments(N)]: the segment of every (row,
+//   32768-column chunk) in the pool; s_cursor [2] uint64 (zeroed here): [0] = entries allocated, [1] = 1 when a segment did not fit (S is
+//   then unusable and its consumers take the dense passes).  s_pool == NULL: J' only.  Needs 1 - lambda >= 0 (J' values non-negative:
+//   bit 15 marks touched columns in LDS); otherwise the first-generation kernel runs and s_cursor[1] is raised.
+extern "C" int ssg_jaccard_segments(int N) { return N <= 0 ? 0 : (N + JCHUNK - 1) / JCHUNK; }
+extern "C" int ssg_jaccard_rows2(const int32_t* q_idx, const uint16_t* q_val, const int32_t* q_nnz, int capQ, const int64_t* colptr,
+                                 const int32_t* inv_row, const uint16_t* inv_val, int64_t inv_nnz, int32_t* colmeta, int N, int row0, int nrows,
+                                 uint16_t one_minus_lambda_half, uint16_t* Jp, uint32_t* s_pool, uint64_t s_cap, uint64_t* s_cursor, int64_t* seg_off,
+                                 int32_t* seg_len, hipStream_t stream) {
+  if (N <= 0 || nrows <= 0 || inv_nnz < 0 || inv_nnz > 0x3ffffff0LL || N > (1 << 17)) { ssg_set_error("ssg_jaccard_rows2: bad shape (N=%d nrows=%d nnz=%lld)", N, nrows, (long long)inv_nnz); return SSG_ERR_INVALID; }
+  if (s_pool && (!s_cursor || !seg_off || !seg_len)) { ssg_set_error("ssg_jaccard_rows2: sparse output needs s_cursor, seg_off and seg_len"); return SSG_ERR_INVALID; }
+  if (s_cursor) SSG_HIP(hipMemsetAsync(s_cursor, 0, 2 * sizeof(uint64_t), stream));
+  static int gen = -1;
+  if (gen < 0) { const char* e = getenv("SSG_JACCARD_GEN"); gen = e ? atoi(e) : 2; }
+  const bool nonneg = (one_minus_lambda_half & 0x8000u) == 0 && (one_minus_lambda_half & 0x7fffu) <= 0x7c00u;
+  if (gen != 2 || !nonneg) {
+    if (s_cursor) { const uint64_t one = 1; SSG_HIP(hipMemcpyAsync(s_cursor + 1, &one, sizeof(one), hipMemcpyHostToDevice, stream)); }
+    return ssg_jaccard_rows(q_idx, q_val, q_nnz, capQ, colptr, inv_row, inv_val, inv_nnz, colmeta, N, row0, nrows, one_minus_lambda_half, Jp, stream);
+  }
+  int32_t* meta_base = colmeta;
+  uint32_t* meta_lv = reinterpret_cast<uint32_t*>(colmeta + (int64_t)nrows * capQ);
+  hipLaunchKernelGGL(colmeta_kernel, dim3(nrows), dim3(64), 0, stream, q_idx, q_val, q_nnz, capQ, colptr, row0, nrows, meta_base, meta_lv);
+  const int cw = N < JCHUNK ? N : JCHUNK;
+  const size_t lds = (((size_t)((cw + 7) & ~7) * 2 + 15) & ~(size_t)15) + 16 + (size_t)TCAP * 2 + 64;
+  if (lds > 64 * 1024) SSG_HIP(hipFuncSetAttribute((const void*)jaccard_rows2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int per_cu = (int)(160 * 1024 / lds) > 0 ? (int)(160 * 1024 / lds) : 1;
+  const int grid = nrows < 256 * per_cu ? nrows : 256 * per_cu;   // persistent waves, one per LDS slot
+  SparseOut so; so.pool = s_pool; so.cap = s_cap; so.cursor = (unsigned long long*)s_cursor; so.seg_off = seg_off; so.seg_len = seg_len; so.nseg = ssg_jaccard_segments(N);
+  hipLaunchKernelGGL(jaccard_rows2_kernel, dim3(grid), dim3(64), lds, stream, q_nnz, capQ, colptr, q_idx, inv_row, inv_val, inv_nnz, meta_base, meta_lv,
+                     N, row0, nrows, one_minus_lambda_half, Jp, so);
+  SSG_LAUNCH_CHECK("jaccard_rows2_kernel");
   return SSG_OK;
 }
 

@@ -48,21 +48,29 @@ class DistHandle:
     _error = None
     _redo = None
     _k1 = None
+    sparse = None          # the sparse copy S of J' (re_ranking_device), or None
+    sparse_ok = False      # S is complete (its pool did not overflow): known once the status words have been read
 
     def validate(self):
         """Raise what the pipeline could only detect on the device.  The status words are read once (with the caller's host
         round trip); a failure is kept on the handle and raised again by every later call, so a caller that catches the
         error cannot go on to cluster the NaN matrix."""
         if self._pending is not None:
-            self.resolve_pending(self._pending.tolist())
+            self.resolve_pending(self.take_pending().tolist())
         if self._error is not None:
             raise self._error
         return self
 
     def take_pending(self):
-        """the device status words (or None when they were read already): a consumer that is about to read something else
-        back appends them to ITS read (cluster.eps_rule does) and hands the values to resolve_pending -- one host round trip less"""
-        return self._pending
+        """the device status words as ONE int64 tensor (or None when they were read already): a consumer that is about to read
+        something else back appends them to ITS read (cluster.eps_rule does) and hands the values to resolve_pending -- one host
+        round trip less.  Words: max(v) half bits, digit overflow, V row longer than the guess, longest V row, S entries, S overflow."""
+        if self._pending is None:
+            return None
+        words = [self._pending.to(torch.int64)]
+        if self.sparse is not None:
+            words.append(self.sparse["cursor"])
+        return torch.cat(words) if len(words) > 1 else words[0]
 
     def resolve_pending(self, values):
         """values = the status words as python numbers (read with the caller's host round trip).  Returns True when the distance
@@ -73,11 +81,14 @@ class DistHandle:
             vmax_h, flag_h = int(values[0]), int(values[1])
             over, seen = (int(values[2]), int(values[3])) if len(values) >= 4 else (0, 0)
             self._pending = None
+            self.sparse_ok = self.sparse is not None and len(values) >= 6 and int(values[5]) == 0
             if seen > 0 and self._k1 is not None:
                 _QE_GUESS[self._k1] = max(32, ((seen * 3 // 2) + 15) // 16 * 16)
             if over and self._redo is not None:
                 self._redo()
                 redone = True
+                if self.sparse is not None:          # the sparse copy was rebuilt as well: its overflow word is read on its own (rare path)
+                    self.sparse_ok = int(self.sparse["cursor"][1].item()) == 0
             self._redo = None
             if flag_h:
                 self._error = _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
@@ -325,6 +336,15 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     om = L.ssg_double_to_half_bits(1.0 - float(lambda_value))
     Jp = torch.empty((nrows, N), dtype=torch.float16, device=dev)
     tables = {}
+    # sparse copy S of J' (the columns a row's Jaccard walk touches; everything else is the constant J'(0) = half(1 - lambda)): what the
+    # eps rule and the region query walk instead of the N x N matrix while their bound stays below J'(0)
+    sparse = None
+    if os.environ.get("SSG_SPARSE", "1") != "0":
+        nseg = int(L.ssg_jaccard_segments(N))
+        s_cap = int(nrows) * int(min(N, int(os.environ.get("SSG_SPARSE_ROW_ENTRIES", "1024"))))
+        sparse = dict(pool=torch.empty(max(s_cap, 1), dtype=torch.int32, device=dev), cap=s_cap, cursor=torch.zeros(2, dtype=torch.int64, device=dev),
+                      seg_off=torch.empty(nrows * nseg, dtype=torch.int64, device=dev), seg_len=torch.empty(nrows * nseg, dtype=torch.int32, device=dev),
+                      nseg=nseg, jp0=int(om))
 
     def tail(mx, over):
         """local query expansion -> inverted index -> Jaccard rows into Jp, with LDS / row capacities sized for V rows of at most `mx`
@@ -352,8 +372,13 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
         check(L.ssg_invert_index(ptr(q_idx), ptr(q_val), ptr(q_nnz), N, N, capQ, ptr(colcnt), ptr(colptr), ptr(inv_row), ptr(inv_val), st),
               "ssg_invert_index")
         colmeta = torch.empty((2, nrows, capQ), dtype=torch.int32, device=dev)
-        check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
-                                 om, ptr(Jp), st), "ssg_jaccard_rows")
+        if sparse is not None:
+            check(L.ssg_jaccard_rows2(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
+                                      om, ptr(Jp), ptr(sparse["pool"]), sparse["cap"], ptr(sparse["cursor"]), ptr(sparse["seg_off"]), ptr(sparse["seg_len"]), st),
+                  "ssg_jaccard_rows2")
+        else:
+            check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
+                                     om, ptr(Jp), st), "ssg_jaccard_rows")
         if stages is not None:
             tables.update(q_idx=q_idx, q_val=q_val, q_nnz=q_nnz, colptr=colptr, inv_row=inv_row, inv_val=inv_val)
 
@@ -376,6 +401,9 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     # the device-side status words (zero source vector -> the reference's NaN path; int8 digit overflow; a V row longer than the guess)
     # are read with the consumer's first host round trip (`validate`: eps_rule / DBSCAN / final_dist), not with one of their own
     h._pending, h._redo, h._k1 = status, redo, k1
+    h.sparse = sparse
+    if stages is not None and sparse is not None:
+        tables["sparse"] = sparse
     if validate or stages is not None:
         h.validate()
     if stages is not None:

@@ -311,7 +311,7 @@ def _nccl_world1_worker(port, q):
     b, nb, _ = ev.extract_embeddings(model, ev.TensorBatchLoader(imgs, 4))
     out["extract"] = bool(torch.equal(a, b)) and na == nb
     t = torch.arange(12, dtype=torch.int32, device=dev).view(6, 2)
-    out["gathers"] = bool(torch.equal(sd.gather_rows(t, g, 6), t)) and bool(torch.equal(sd.gather_varlen(t, g), t)) and sd._FLAT_OK.get("nccl") is True
+    out["gathers"] = bool(torch.equal(sd.gather_rows(t, g, 6), t)) and bool(torch.equal(sd.gather_varlen(t, g), t)) and any(k[0] == "nccl" and ok is True for k, ok in sd._FLAT_OK.items())
     q.put(out)
     dist.barrier()
     dist.destroy_process_group()

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, bits, clustered
+from conftest import GOLDEN, bits, clustered, hard_clustered
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -728,6 +728,76 @@ def test_more_than_one_column_chunk_vs_oracle(dev, ora):
     oe, of, ost = ora.re_ranking(src, tgt, lambda_value=0.1, stages=True)
     assert np.array_equal(bits(h.euclid.cpu().numpy()), bits(oe))
     assert np.array_equal(bits(h.M.cpu().numpy()), bits(ost["jaccard_scaled"]))
+
+
+def _check_sparse_copy(h, N):
+    """the sparse copy S against the dense J' it was written with: every packed entry equals J' at its (row, column), no column twice,
+    and every column that is not in S holds the constant J'(0)"""
+    sp = h.sparse
+    assert sp is not None and int(sp["cursor"][1].item()) == 0
+    Jp = bits(h.M.cpu().numpy())
+    pool = sp["pool"].cpu().numpy().view(np.uint32)
+    off = sp["seg_off"].cpu().numpy().reshape(h.nrows, sp["nseg"]); ln = sp["seg_len"].cpu().numpy().reshape(h.nrows, sp["nseg"])
+    assert int(ln.sum()) == int(sp["cursor"][0].item())
+    jp0 = np.uint16(sp["jp0"])
+    rng = np.random.default_rng(1)
+    rows = np.unique(np.concatenate([np.arange(min(8, h.nrows)), rng.integers(0, h.nrows, 40), [h.nrows - 1]]))
+    for il in rows:
+        seen = np.zeros(N, bool)
+        for sg in range(sp["nseg"]):
+            e = pool[off[il, sg]:off[il, sg] + ln[il, sg]]
+            col = (e & 0x1FFFF).astype(np.int64); val = (e >> 17).astype(np.uint16)
+            assert (col // 32768 == sg).all() and not seen[col].any() and len(np.unique(col)) == len(col)
+            assert np.array_equal(Jp[il, col], val), (il, sg)
+            seen[col] = True
+        assert (Jp[il, ~seen] == jp0).all(), il
+
+
+def test_jaccard_second_generation_and_sparse_copy(dev, ora, monkeypatch):
+    """round 4: ssg_jaccard_rows2 (every J' line written once from the LDS row, touched columns marked with bit 15) against the first
+    generation kernel bit for bit -- rows that start off 16-byte boundaries (N % 8 != 0), the touched-list overflow path (k1 = 60), two
+    column chunks (N > 32768) -- and the sparse copy S it emits against the dense rows; then the eps rule and DBSCAN through S
+    against the dense passes (SSG_SPARSE=0) incl. the cases where S must NOT be used: eps above J'(0), a threshold above J'(0)
+    (rho = 0.5: decided on the device), an overflowed pool."""
+    from ssg_amd import rerank, cluster
+    rng = np.random.default_rng(12)
+    cases = []
+    t = clustered(1531, 64, 7); cases.append(("ragged", clustered(400, 64, 8, intra=0.7), t, dict(lambda_value=0.3)))
+    t = rng.standard_normal((4500, 48)).astype(np.float32); t /= np.linalg.norm(t, axis=1, keepdims=True)
+    sr = rng.standard_normal((700, 48)).astype(np.float32); sr /= np.linalg.norm(sr, axis=1, keepdims=True)
+    cases.append(("wide", sr, t, dict(k1=60, k2=16, lambda_value=0.2)))
+    cases.append(("chunks", clustered(2000, 32, 6, intra=0.7), clustered(33000, 32, 5), dict(lambda_value=0.1)))
+    cases.append(("hard", hard_clustered(2000, 128, 12, intra=0.7), hard_clustered(6000, 128, 11), dict(lambda_value=0.3)))
+    for name, src, tgt, kw in cases:
+        N = tgt.shape[0]
+        s_d, t_d = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+        monkeypatch.setenv("SSG_SPARSE", "0")
+        h1 = rerank.re_ranking_device(s_d, t_d, **kw)
+        assert h1.sparse is None
+        e1 = cluster.eps_rule(h1, 1.6e-3)
+        l1 = cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h1)
+        big = 0.95 * (1.0 - kw["lambda_value"]) + 0.4          # an eps above J'(0): dense region query on both handles
+        l1big = cluster.DBSCAN(eps=big, min_samples=4, metric="precomputed").fit_predict(h1) if N <= 6000 else None
+        e1half = cluster.eps_rule(h1, 0.5) if N <= 6000 else None
+        monkeypatch.delenv("SSG_SPARSE")
+        h2 = rerank.re_ranking_device(s_d, t_d, **kw)
+        assert torch.equal(h1.M.view(torch.int16), h2.M.view(torch.int16)), name
+        assert h2.sparse_ok
+        _check_sparse_copy(h2, N)
+        assert cluster.eps_rule(h2, 1.6e-3) == e1, name
+        assert np.array_equal(cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h2), l1), name
+        if N <= 6000:
+            assert float(np.uint16(h2.sparse["jp0"]).view(np.float16)) < big
+            assert np.array_equal(cluster.DBSCAN(eps=big, min_samples=4, metric="precomputed").fit_predict(h2), l1big), name
+            assert cluster.eps_rule(h2, 0.5) == e1half, name
+        # a pool that is too small: S is marked unusable, everything falls back to the dense passes
+        monkeypatch.setenv("SSG_SPARSE_ROW_ENTRIES", "8")
+        h3 = rerank.re_ranking_device(s_d, t_d, **kw)
+        monkeypatch.delenv("SSG_SPARSE_ROW_ENTRIES")
+        assert torch.equal(h1.M.view(torch.int16), h3.M.view(torch.int16)) and not h3.sparse_ok
+        assert cluster.eps_rule(h3, 1.6e-3) == e1
+        assert np.array_equal(cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h3), l1)
+        del h1, h2, h3
 
 
 def test_pairwise_distance_dropin(dev):
