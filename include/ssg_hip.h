@@ -374,6 +374,13 @@ int ssg_jpeg_parse_close(void* handle);
 /* x = sqrt(max(x, lo)) in place: with ssg_pairwise_sqdist_f32 the pairwise block of the fine-tune phase's TripletLoss
  * (reid/loss/triplet.py:28-31: dist = (|x|^2 + |x|^2' - 2 x x').clamp(min=1e-12).sqrt()) */
 int ssg_clamp_sqrt_f32(float* x, int64_t n, float lo, ssg_stream_t stream);
+/* Backward of that block (round 4: lets ssg_amd.triplet.pairwise_dist replace reid/loss/triplet.py:28-31 inside the training step):
+ * grad_x = diag(rowsum(S)) x - S x,  S = W + W^T,  W[i,j] = sq[i,j] >= lo ? grad_dist[i,j] / dist[i,j] : 0 (sq = the distances squared
+ * before the clamp).  _weights writes S with row pitch ld >= n (zero padded) and its row sums; S x is one fp32-MFMA GEMM
+ * (ssg_conv2d_nhwc_f32 as a 1x1 convolution: in = S [n,1,1,ld], w = x^T [d_pad][ld]); _combine forms the gradient. */
+int ssg_triplet_grad_weights(const float* grad_dist, const float* sq, const float* dist, int n, int ld, float lo, float* S, float* rowsum,
+                             ssg_stream_t stream);
+int ssg_triplet_grad_combine(const float* x, const float* rowsum, const float* Sx, int n, int d, int ldo, float* grad_x, ssg_stream_t stream);
 
 /* ---- device self-tests used by the parity suite ----------------------------------------- */
 int ssg_selftest_half_table(int which, uint16_t* out65536, ssg_stream_t stream);

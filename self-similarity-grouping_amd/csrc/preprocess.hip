@@ -12,6 +12,7 @@
 // ssg_amd/preprocessor.py), the arithmetic is the same int32 arithmetic, the float32 division is IEEE.
 // Both passes are streaming kernels over a batch of equally sized images (HBM-bound, a few bytes per pixel).
 #include "ssg_common.h"
+#include <algorithm>
 
 namespace ssg {
 
@@ -89,6 +90,61 @@ extern "C" int ssg_preprocess_u8(const uint8_t* src, int B, int h, int w, int H,
   hipLaunchKernelGGL(resize_v_normalize_kernel, dim3(g2), dim3(256), 0, stream, tmp, out, B, h, H, W, ymin, ycnt, yk, yksize, mean3_host[0],
                      mean3_host[1], mean3_host[2], std3_host[0], std3_host[1], std3_host[2]);
   SSG_LAUNCH_CHECK("preprocess kernels");
+  return SSG_OK;
+}
+
+namespace ssg {
+// backward of dist = sqrt(clamp(sq, min = lo)) w.r.t. sq's two arguments, folded into one symmetric weight matrix:
+//   w[i,j] = sq[i,j] >= lo ? g[i,j] / dist[i,j] : 0      (clamp passes the gradient where its input is >= min; d sqrt = 1 / (2 sqrt))
+//   S[i,j] = w[i,j] + w[j,i]   (x_i enters row i and column i of the distance matrix),  rowsum[i] = sum_j S[i,j]
+// S is written with a row pitch of `ld` floats (zero padding up to the GEMM's K granule), one wave per row.
+__global__ __launch_bounds__(256) void triplet_grad_weights_kernel(const float* __restrict__ g, const float* __restrict__ sq, const float* __restrict__ dist,
+                                                                   int n, int ld, float lo, float* __restrict__ S, float* __restrict__ rowsum) {
+  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (i >= n) return;
+  const int lane = lane_id();
+  float acc = 0.f;
+  for (int j = lane; j < ld; j += 64) {
+    float s = 0.f;
+    if (j < n) {
+      const int64_t a = (int64_t)i * n + j, b = (int64_t)j * n + i;
+      const float wij = sq[a] >= lo ? g[a] / dist[a] : 0.f;
+      const float wji = sq[b] >= lo ? g[b] / dist[b] : 0.f;
+      s = wij + wji;
+    }
+    S[(int64_t)i * ld + j] = s;
+    acc += s;
+  }
+  for (int sh = 1; sh < 64; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
+  if (lane == 0) rowsum[i] = acc;
+}
+// grad_x[i,c] = rowsum[i] * x[i,c] - Sx[i,c]      (Sx with a row pitch of ldo floats)
+__global__ __launch_bounds__(256) void triplet_grad_combine_kernel(const float* __restrict__ x, const float* __restrict__ rowsum, const float* __restrict__ Sx,
+                                                                   int n, int d, int ldo, float* __restrict__ out) {
+  const int64_t total = (int64_t)n * d;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(t / d), c = (int)(t - (int64_t)i * d);
+    out[t] = rowsum[i] * x[t] - Sx[(int64_t)i * ldo + c];
+  }
+}
+}  // namespace ssg
+
+// Backward of the TripletLoss pairwise block (reid/loss/triplet.py:28-31) -- the two elementwise halves around the fp32-MFMA GEMM S * x
+// (ssg_conv2d_nhwc_f32 as a 1x1 convolution): grad_x = diag(rowsum(S)) x - S x with S = W + W^T, W = grad_dist / dist where the clamp
+// passes the gradient.  ssg_triplet_grad_weights: g / sq / dist [n,n] -> S [n, ld] (ld >= n, zero padded), rowsum [n];
+// ssg_triplet_grad_combine: x [n,d], Sx [n, ldo] -> grad_x [n,d].
+extern "C" int ssg_triplet_grad_weights(const float* grad_dist, const float* sq, const float* dist, int n, int ld, float lo, float* S, float* rowsum,
+                                        hipStream_t stream) {
+  if (!grad_dist || !sq || !dist || !S || !rowsum || n <= 0 || ld < n) { ssg_set_error("ssg_triplet_grad_weights: bad arguments (n=%d ld=%d)", n, ld); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(ssg::triplet_grad_weights_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, grad_dist, sq, dist, n, ld, lo, S, rowsum);
+  SSG_LAUNCH_CHECK("triplet_grad_weights_kernel");
+  return SSG_OK;
+}
+extern "C" int ssg_triplet_grad_combine(const float* x, const float* rowsum, const float* Sx, int n, int d, int ldo, float* grad_x, hipStream_t stream) {
+  if (!x || !rowsum || !Sx || !grad_x || n <= 0 || d <= 0 || ldo < d) { ssg_set_error("ssg_triplet_grad_combine: bad arguments (n=%d d=%d ldo=%d)", n, d, ldo); return SSG_ERR_INVALID; }
+  const int64_t total = (int64_t)n * d;
+  hipLaunchKernelGGL(ssg::triplet_grad_combine_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, stream, x, rowsum, Sx, n, d, ldo, grad_x);
+  SSG_LAUNCH_CHECK("triplet_grad_combine_kernel");
   return SSG_OK;
 }
 

@@ -177,6 +177,50 @@ def test_triplet_pairwise_block_vs_torch():
         assert float(got.min()) >= 1e-6 - 1e-12          # sqrt(1e-12): the clamp floor, never NaN
 
 
+@pytest.mark.gpu
+def test_triplet_pairwise_block_backward_vs_torch():
+    """`triplet.pairwise_dist` is differentiable, so it can stand where reid/loss/triplet.py:28-31 stands inside the
+    TripletLoss of the fine-tune phase: the gradient w.r.t. the features (two HIP elementwise kernels around one fp32-MFMA GEMM) against
+    torch.autograd through the reference's four lines -- with the hardest-positive / hardest-negative mining and MarginRankingLoss of
+    reid/loss/triplet.py:32-45 as the loss, and with a dense random upstream gradient; duplicate rows (clamped distance: no gradient)."""
+    from ssg_amd import triplet
+
+    def ref_dist(x):
+        n = x.shape[0]
+        dist = torch.pow(x, 2).sum(dim=1, keepdim=True).expand(n, n)
+        dist = dist + dist.t()
+        dist = dist.addmm(x, x.t(), beta=1, alpha=-2)
+        return dist.clamp(min=1e-12).sqrt()
+
+    def triplet_loss(dist, targets, margin=0.5):
+        n = dist.shape[0]
+        mask = targets.expand(n, n).eq(targets.expand(n, n).t())
+        ap = torch.stack([dist[i][mask[i]].max() for i in range(n)]); an = torch.stack([dist[i][mask[i] == 0].min() for i in range(n)])
+        return torch.nn.functional.margin_ranking_loss(an, ap, torch.ones_like(an), margin=margin)
+    g = torch.Generator().manual_seed(11)
+    for n, d in ((64, 2048), (96, 500), (30, 37)):
+        x0 = torch.randn(n, d, generator=g) * 0.3
+        x0[5] = x0[2]                                   # an exact duplicate: sq = 0 < 1e-12, the clamp blocks the gradient of that pair
+        targets = torch.arange(n) // 4
+        up = torch.randn(n, n, generator=g)
+        for mode in ("dense", "loss"):
+            xr = x0.clone().double().requires_grad_(True)       # float64 reference
+            dr = ref_dist(xr)
+            (dr * up.double()).sum().backward() if mode == "dense" else triplet_loss(dr, targets).backward()
+            xg = x0.clone().cuda().requires_grad_(True)
+            dg = triplet.pairwise_dist(xg)
+            assert dg.requires_grad and dg.is_cuda
+            (dg * up.cuda()).sum().backward() if mode == "dense" else triplet_loss(dg, targets.cuda()).backward()
+            got, ref = xg.grad.cpu().double(), xr.grad
+            assert got.shape == ref.shape and torch.isfinite(got).all()
+            scale = float(ref.abs().max())
+            assert float((got - ref).abs().max()) < 3e-5 * max(scale, 1e-3), (n, d, mode, float((got - ref).abs().max()), scale)
+    # CPU input tensors get their gradient back on the CPU
+    xc = x0.clone().requires_grad_(True)
+    triplet.pairwise_dist(xc).sum().backward()
+    assert xc.grad is not None and xc.grad.device.type == "cpu"
+
+
 # ------------------------------------------------------------------ fused embedding kernels: shape gating (host functions, CPU)
 def test_fused_kernel_shape_gates():
     """ssg_stem_pool_supported / ssg_bottleneck_supported decide between the fused kernels and the launch-per-layer path; the
