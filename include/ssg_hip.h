@@ -180,11 +180,16 @@ int ssg_eps_refine_threshold(const uint64_t* hist2, uint64_t* thr, ssg_stream_t 
 int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value,
                           const uint64_t* thr3, uint64_t* buf, uint64_t cap, uint64_t* cursor2, ssg_stream_t stream);
 /* the same pass through the sparse copy S (mode 0 handles only): cursor3 = {keys collected, exact zeros, dense pass needed} zeroed by
- * the caller; the walk over S does the work when the threshold lies below J'(0) and S is complete, otherwise it raises cursor3[2]
- * and the dense pass queued behind it (inside this call) runs -- decided on the device, no read-back in between */
+ * the caller, vmin = ssg_half_min(v), rowmask = nrows bytes of workspace.  Row i is walked through S when its floor
+ * J'(0) + lambda * half(v_i + vmin) -- a lower bound of every column outside S -- lies at or above the threshold; the other rows (all
+ * of them when S overflowed or lambda < 0) are flagged in rowmask and done by the dense pass queued behind (inside this call), gated on
+ * cursor3[2] -- decided on the device, no read-back in between */
 int ssg_eps_compact_below_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, const uint64_t* thr3,
                             uint64_t* buf, uint64_t cap, uint64_t* cursor3, const uint32_t* s_pool, const int64_t* seg_off,
-                            const int32_t* seg_len, int nseg, const uint64_t* s_cursor, uint16_t jp0_half, ssg_stream_t stream);
+                            const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin, uint16_t jp0_half,
+                            uint8_t* rowmask, ssg_stream_t stream);
+/* *out_bits = the smallest of N non-negative halves (the source vector v of rerank.py:38-40) as half bits */
+int ssg_half_min(const uint16_t* v, int N, uint32_t* out_bits, ssg_stream_t stream);
 int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t value, ssg_stream_t stream);
 int ssg_sort_u64(uint64_t* buf, uint64_t n_pow2, ssg_stream_t stream); /* ascending, n = 2^k >= 2048 */
 size_t ssg_eps_mean_workspace_bytes(int64_t top);
@@ -200,10 +205,12 @@ int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mode, void* w
 /* cnt[il] = |{k: d(i,k) <= eps}|; edges[2e],[2e+1] = (i,k) for every hit (cursor counts all) */
 int ssg_region_query(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps,
                      int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, ssg_stream_t stream);
-/* the same through S: only valid for eps < f64(J'(0)) and a complete S (the caller has read s_cursor[1] == 0); refused otherwise */
-int ssg_region_query_s(const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
-                       const int64_t* seg_off, const int32_t* seg_len, int nseg, uint16_t jp0_half, int32_t* cnt, int32_t* edges,
-                       uint64_t cap_edges, uint64_t* cursor, ssg_stream_t stream);
+/* the same through S, row by row: row i through S when J'(0) + lambda * half(v_i + vmin) > eps, the dense scan (queued behind, gated on
+ * cursor2[1]) for the rows flagged in rowmask.  cursor2 = {edges counted, dense pass needed}, zeroed by the caller. */
+int ssg_region_query_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
+                       const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
+                       uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
+                       ssg_stream_t stream);
 size_t ssg_dbscan_cc_workspace_bytes(int N);
 /* cnt is the FULL [N] table, edges the concatenated edge list: labels[N] int64, -1 = noise */
 int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,

@@ -92,9 +92,11 @@ def _eps_rule_sampled(L, h, rho, st):
     cursor = torch.zeros(3, dtype=torch.int64, device=dev)
     sp = getattr(h, "sparse", None) if h.mode == 0 else None
     if sp is not None:
-        # through the sparse copy S of J' when the threshold lies below J'(0) (decided on the device; the dense pass is queued behind it)
+        # row by row through the sparse copy S of J' where the threshold lies below the row's floor (decided on the device; the dense pass
+        # for the other rows is queued behind it)
         check(L.ssg_eps_compact_below_s(ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.lambda_value, ptr(thr3), ptr(buf), n_cap, ptr(cursor), ptr(sp["pool"]),
-                                        ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]), sp["jp0"], st), "ssg_eps_compact_below_s")
+                                        ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), st),
+              "ssg_eps_compact_below_s")
     else:
         check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
     pend = h.take_pending() if hasattr(h, "take_pending") else None    # the re-rank's status words ride along with this read-back
@@ -236,11 +238,13 @@ class DBSCAN:
             edges = torch.empty((cap, 2), dtype=torch.int32, device=dev)
             cursor = torch.zeros(1, dtype=torch.int64, device=dev)
             sp = getattr(h, "sparse", None) if h.mode == 0 else None
-            if (sp is not None and h.sparse_ok and h.lambda_value >= 0.0 and 0 < sp["jp0"] < 0x7C00
-                    and eps < float(np.uint16(sp["jp0"]).view(np.float16))):
-                # eps lies below J'(0): only the columns of the sparse copy S can be neighbours
-                check(L.ssg_region_query_s(ptr(h.v), N, h.row0, h.nrows, h.lambda_value, eps, ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"],
-                                           sp["jp0"], ptr(cnt), ptr(edges), cap, ptr(cursor), st), "ssg_region_query_s")
+            if sp is not None:
+                # row by row through the sparse copy S of J' where eps lies below the row's floor (decided on the device), dense scan of the rest
+                cursor = torch.zeros(2, dtype=torch.int64, device=dev)
+                check(L.ssg_region_query_s(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.lambda_value, eps, ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]),
+                                           sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), ptr(cnt), ptr(edges), cap, ptr(cursor), st),
+                      "ssg_region_query_s")
+                cursor = cursor[:1]
             else:
                 check(L.ssg_region_query(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, eps, ptr(cnt), ptr(edges), cap,
                                          ptr(cursor), st), "ssg_region_query")

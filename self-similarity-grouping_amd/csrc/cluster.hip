@@ -309,6 +309,7 @@ __device__ __forceinline__ void surrogate8(const MatView& mv, const RawChunk& r,
 // refine != nullptr: second level -- only the sample elements of coarse bin refine[2] are counted, in 1024 linear sub-bins of
 // that bin's float range (hist[0..1023]); the coarse bins are 0.4 % wide, which on a dense value distribution is far more than
 // the quantile margin and would blow the candidate set up
+constexpr int SPARTS = 8;
 template <int MODE>
 __global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int stride, const unsigned long long* __restrict__ refine,
                                                               unsigned long long* __restrict__ hist) {
@@ -321,12 +322,14 @@ __global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int st
   const float rlo = rbin > 0 ? sur_bin_upper(rbin - 1) : 0.f, rhi = rbin >= 0 ? sur_bin_upper(rbin) : 1.f;
   const float rinv = 1024.f / (rhi - rlo);
   const int nsamp = (mv.nrows + stride - 1) / stride;
-  for (int sidx = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); sidx < nsamp; sidx += (int)gridDim.x * 4) {
+  // a sample row is shared by SPARTS waves (chunks round-robin): 192 rows alone leave the launch at one wave per CU and latency-bound
+  for (int widx = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); widx < nsamp * SPARTS; widx += (int)gridDim.x * 4) {
+    const int sidx = widx / SPARTS, part = widx - sidx * SPARTS;
     const int il = sidx * stride, gi = mv.row0 + il;
     RowStream rs(il, mv.N, mv.nrows);
     const hbits vi = MODE == 0 ? mv.v[gi] : (hbits)0;
     unsigned cnt = 0;
-    for (int c = (rs.first + gi + 1) / 512; c < rs.nchunks; c++) {
+    for (int c = (rs.first + gi + 1) / 512 + part; c < rs.nchunks; c += SPARTS) {
       float sv[8]; unsigned zm = 0;
       const int j0 = rs.col0(c, lane);
       if (MODE == 2) {
@@ -432,9 +435,9 @@ __global__ __launch_bounds__(1024) void eps_select2_kernel(const unsigned long l
 template <int MODE>
 __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const unsigned long long* __restrict__ thr3, unsigned long long* __restrict__ buf,
                                                               unsigned long long cap, unsigned long long* __restrict__ cursor,
-                                                              const unsigned long long* __restrict__ gate) {
+                                                              const unsigned long long* __restrict__ gate, const unsigned char* __restrict__ rowmask) {
   __shared__ unsigned long long sbuf[4][STAGE_CAP];
-  if (gate && *gate == 0ull) return;          // the sparse pass queued in front of this launch has done the work
+  if (gate && *gate == 0ull) return;          // the sparse pass queued in front of this launch has done every row
   const int lane = lane_id();
   WaveStage<unsigned long long> st{sbuf[threadIdx.x >> 6], 0};
   const float thr = __uint_as_float((unsigned)thr3[0]);
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const 
   for (int hh = 0; hh < 2; hh++) {
     const int il = hh ? mv.nrows - 1 - pidx : pidx;
     if (hh && il == pidx) continue;                // odd row count: the middle row is its own partner
+    if (rowmask && rowmask[il] == 0) continue;     // done through the sparse copy
     const int gi = mv.row0 + il;
     RowStream rs(il, mv.N, mv.nrows);
     const int c0 = (rs.first + gi + 1) / 512;
@@ -718,8 +722,10 @@ __device__ __forceinline__ unsigned rq_decide(const MatView& mv, unsigned flags,
 
 template <int MODE>
 __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
-                                                           unsigned long long cap, unsigned long long* __restrict__ cursor) {
+                                                           unsigned long long cap, unsigned long long* __restrict__ cursor,
+                                                           const unsigned long long* __restrict__ gate, const unsigned char* __restrict__ rowmask) {
   __shared__ Edge sbuf[4][STAGE_CAP];
+  if (gate && *gate == 0ull) return;          // the sparse pass queued in front of this launch has done every row
   const int lane = lane_id();
   WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
   Edge* eout = reinterpret_cast<Edge*>(edges);
@@ -734,6 +740,7 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
   const h2 lam2 = {(_Float16)(float)mv.lambda_value, (_Float16)(float)mv.lambda_value};
   const bool fast_ok = MODE == 0 && (mv.N & 7) == 0 && (float)eps < 30000.f && fabsf((float)mv.lambda_value) < 16.f;
   for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
+    if (rowmask && rowmask[il] == 0) continue;     // done through the sparse copy
     const int gi = mv.row0 + il;
     RowStream rs(il, mv.N, mv.nrows);
     int rowcnt = 0;
@@ -789,63 +796,76 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
 // ------------------------------------------------------------------ round 4: the sparse copy S of J' (jaccard.hip, second generation)
 // S holds, per (row, column chunk), the packed words (J' << 17 | column) of every column the row's Jaccard walk touched; every other
 // column of the row holds the constant J'(0) = half(1 - lambda), the LARGEST value J' takes.  final_dist = J' + lambda * half(v_i + v_k)
-// with v >= 0 and lambda >= 0, so an entry outside S is >= f64(J'(0)): while the bound a pass asks about stays below that, only S can
-// hold what it looks for -- a few hundred entries per row instead of N.
+// with v >= 0 and lambda >= 0, so an entry of row i outside S is >= J'(0) + lambda * half(v_i + min_k v_k) =: floor_i (every operation in
+// that expression is monotone in v_k): while the bound a pass asks about stays below floor_i, only S can hold what it looks for in
+// row i -- a few hundred entries instead of N.  The decision is taken PER ROW on the device: rows whose floor is too low (and all
+// rows when S is incomplete) are flagged in a row mask and done by the dense pass queued behind the sparse one.
+constexpr int SBATCH = 4;
 struct SparseView {
   const uint32_t* pool; const int64_t* seg_off; const int32_t* seg_len; int nseg;
   const unsigned long long* s_cursor;      // [1] != 0: a segment did not fit, S is unusable
+  const uint32_t* vmin;                    // half bits of min_k v_k
   hbits jp0;                               // J'(0)
 };
-// Is the sparse walk valid for an (exclusive) upper bound `bound` on the values looked for?  (all lanes agree)
-__device__ __forceinline__ bool sparse_usable(const SparseView& sv, const MatView& mv, double bound) {
-  return sv.pool && mv.mode == 0 && sv.s_cursor[1] == 0ull && mv.lambda_value >= 0.0 && (sv.jp0 & 0x7fffu) != 0 && (sv.jp0 & 0x8000u) == 0 &&
-         bound <= (double)h2f(sv.jp0);
+// Can S be used at all?  (all lanes agree)
+__device__ __forceinline__ bool sparse_usable(const SparseView& sv, const MatView& mv) {
+  return sv.pool && mv.mode == 0 && sv.s_cursor[1] == 0ull && mv.lambda_value >= 0.0 && (sv.jp0 & 0x7fffu) != 0 && (sv.jp0 & 0x7fffu) < 0x7c00u &&
+         (sv.jp0 & 0x8000u) == 0;
 }
 
 // eps rule, the one full pass, on S: exact float64 keys of the strict-upper non-zero elements whose surrogate is < *thr -> buf
-// (cursor[0]); cursor[1] += exact zeros.  When S cannot answer (threshold at or above J'(0), overflowed pool, exotic lambda) the
-// kernel only raises cursor[2] and the dense pass that is queued behind it (gate = cursor + 2) does the work.
+// (cursor[0]); cursor[1] += exact zeros.  A row is walked through S when no column outside S can be a candidate: the surrogate of such
+// a column is >= J'(0) + half(v_i + vmin) * lambda in the very float operations the dense pass uses, so the test is exact.  Rows that
+// fail it (and every row when S is unusable) get rowmask = 1 and raise cursor[2]: the dense pass queued behind this launch does them.
 __global__ __launch_bounds__(256) void eps_compact_sparse_kernel(MatView mv, SparseView sv, const unsigned long long* __restrict__ thr3,
                                                                  unsigned long long* __restrict__ buf, unsigned long long cap,
-                                                                 unsigned long long* __restrict__ cursor) {
+                                                                 unsigned long long* __restrict__ cursor, unsigned char* __restrict__ rowmask) {
   __shared__ unsigned long long sbuf[4][STAGE_CAP];
   const int lane = lane_id();
   const float thr = __uint_as_float((unsigned)thr3[0]);
-  // the surrogate is within 4e-7 * (1 + |x|) of the exact value: leave that margin below J'(0)
-  if (!(thr > 0.f) || !sparse_usable(sv, mv, (double)thr * 1.000002 + 2e-6)) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) cursor[2] = 1ull;
-    return;
-  }
+  const bool usable = thr > 0.f && sparse_usable(sv, mv);
+  const hbits vmin = usable ? (hbits)*sv.vmin : (hbits)0;
   WaveStage<unsigned long long> st{sbuf[threadIdx.x >> 6], 0};
   const float lam32 = (float)mv.lambda_value;
   unsigned long long zeros = 0;
+  bool anydense = false;
   for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
     const int gi = mv.row0 + il;
     const hbits vi = mv.v[gi];
+    const bool rowok = usable && (h2f(sv.jp0) + h2f(h_add(vmin, vi)) * lam32 >= thr);
+    if (lane == 0) rowmask[il] = rowok ? 0 : 1;
+    if (!rowok) { anydense = true; continue; }
     for (int sg = 0; sg < sv.nseg; sg++) {
       const int64_t off = sv.seg_off[(int64_t)il * sv.nseg + sg];
       const int len = sv.seg_len[(int64_t)il * sv.nseg + sg];
-      for (int q0 = 0; q0 < len; q0 += 64) {
-        const int q = q0 + lane;
-        unsigned long long key = ~0ULL;
-        if (q < len) {
-          const uint32_t e = sv.pool[off + q];
-          const int k = (int)(e & 0x1ffffu);
-          const hbits jp = (hbits)(e >> 17);
-          if (k > gi) {
-            const hbits s = h_add(mv.v[k], vi);
-            const float sur = h2f(jp) + h2f(s) * lam32;
-            if (sur < thr) {
-              const double d = final_dist_value(jp, vi, mv.v[k], mv.lambda_value);
+      // SBATCH entries per lane in flight: the packed words first, then the gathers of v[k] they address (a segment is a few hundred
+      // entries: one entry per lane and trip would make the row a chain of L2 round trips)
+      for (int q0 = 0; q0 < len; q0 += 64 * SBATCH) {
+        uint32_t e[SBATCH]; hbits vk[SBATCH];
+#pragma unroll
+        for (int u = 0; u < SBATCH; u++) { const int q = q0 + u * 64 + lane; e[u] = sv.pool[off + (q < len ? q : len - 1)]; }
+#pragma unroll
+        for (int u = 0; u < SBATCH; u++) vk[u] = mv.v[e[u] & 0x1ffffu];
+#pragma unroll
+        for (int u = 0; u < SBATCH; u++) {
+          const int q = q0 + u * 64 + lane;
+          if (q0 + u * 64 >= len) break;
+          unsigned long long key = ~0ULL;
+          const int k = (int)(e[u] & 0x1ffffu);
+          if (q < len && k > gi) {
+            const hbits jp = (hbits)(e[u] >> 17);
+            const float sur = h2f(jp) + h2f(h_add(vk[u], vi)) * lam32;
+            if (sur < thr) {           // (an exact zero has surrogate 0 < thr: it is always classified here)
+              const double d = final_dist_value(jp, vi, vk[u], mv.lambda_value);
               if (d != 0.0) key = (unsigned long long)__double_as_longlong(d); else zeros++;
-            } else if ((jp & 0x7fffu) == 0 && ((s & 0x7fffu) == 0 || mv.lambda_value == 0.0)) zeros++;     // (an exact zero has surrogate 0 < thr: never here)
+            }
           }
-        }
-        const uint64_t bm = __ballot(key != ~0ULL);
-        if (bm) {
-          if (key != ~0ULL) st.buf[st.n + __popcll(bm & lanemask_lt())] = key;
-          st.n += __popcll(bm);
-          if (st.n > STAGE_CAP - 64) st.flush(buf, cap, cursor, lane);
+          const uint64_t bm = __ballot(key != ~0ULL);
+          if (bm) {
+            if (key != ~0ULL) st.buf[st.n + __popcll(bm & lanemask_lt())] = key;
+            st.n += __popcll(bm);
+            if (st.n > STAGE_CAP - 64) st.flush(buf, cap, cursor, lane);
+          }
         }
       }
     }
@@ -853,41 +873,56 @@ __global__ __launch_bounds__(256) void eps_compact_sparse_kernel(MatView mv, Spa
   st.flush(buf, cap, cursor, lane);
   for (int sh = 1; sh < 64; sh <<= 1) zeros += (unsigned long long)__shfl_xor((long long)zeros, sh, 64);
   if (lane == 0 && zeros) atomicAdd(&cursor[1], zeros);
+  if (lane == 0 && anydense) cursor[2] = 1ull;
 }
 
-// region query on S: valid while eps < f64(J'(0)) (the host checks that and the pool's overflow word before it chooses this kernel)
+// region query on S: row i is walked through S when floor_i = f64(J'(0)) + f64(half(v_i + vmin)) * lambda > eps (no column outside S can
+// be a neighbour then); other rows (all rows when S is unusable) get rowmask = 1 and raise cursor[1] for the dense pass behind this launch
 __global__ __launch_bounds__(256) void region_query_sparse_kernel(MatView mv, SparseView sv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
-                                                                  unsigned long long cap, unsigned long long* __restrict__ cursor) {
+                                                                  unsigned long long cap, unsigned long long* __restrict__ cursor,
+                                                                  unsigned char* __restrict__ rowmask) {
   __shared__ Edge sbuf[4][STAGE_CAP];
   const int lane = lane_id();
   WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
   Edge* eout = reinterpret_cast<Edge*>(edges);
+  const bool usable = sparse_usable(sv, mv);
+  const hbits vmin = usable ? (hbits)*sv.vmin : (hbits)0;
+  bool anydense = false;
   for (int il = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)); il < mv.nrows; il += (int)gridDim.x * 4) {
     const int gi = mv.row0 + il;
     const hbits vi = mv.v[gi];
+    const bool rowok = usable && final_dist_value(sv.jp0, vi, vmin, mv.lambda_value) > eps;
+    if (lane == 0) rowmask[il] = rowok ? 0 : 1;
+    if (!rowok) { anydense = true; continue; }
     int rowcnt = 0;
     for (int sg = 0; sg < sv.nseg; sg++) {
       const int64_t off = sv.seg_off[(int64_t)il * sv.nseg + sg];
       const int len = sv.seg_len[(int64_t)il * sv.nseg + sg];
-      for (int q0 = 0; q0 < len; q0 += 64) {
-        const int q = q0 + lane;
-        bool hit = false; int k = 0;
-        if (q < len) {
-          const uint32_t e = sv.pool[off + q];
-          k = (int)(e & 0x1ffffu);
-          hit = final_dist_value((hbits)(e >> 17), vi, mv.v[k], mv.lambda_value) <= eps;     // exact, rerank.py:122
-        }
-        const uint64_t bm = __ballot(hit);
-        if (bm) {
-          if (hit) { Edge ed; ed.i = gi; ed.k = k; st.buf[st.n + __popcll(bm & lanemask_lt())] = ed; }
-          st.n += __popcll(bm); rowcnt += __popcll(bm);
-          if (st.n > STAGE_CAP - 64) st.flush(eout, cap, cursor, lane);
+      for (int q0 = 0; q0 < len; q0 += 64 * SBATCH) {
+        uint32_t e[SBATCH]; hbits vk[SBATCH];
+#pragma unroll
+        for (int u = 0; u < SBATCH; u++) { const int q = q0 + u * 64 + lane; e[u] = sv.pool[off + (q < len ? q : len - 1)]; }
+#pragma unroll
+        for (int u = 0; u < SBATCH; u++) vk[u] = mv.v[e[u] & 0x1ffffu];
+#pragma unroll
+        for (int u = 0; u < SBATCH; u++) {
+          const int q = q0 + u * 64 + lane;
+          if (q0 + u * 64 >= len) break;
+          const int k = (int)(e[u] & 0x1ffffu);
+          const bool hit = q < len && final_dist_value((hbits)(e[u] >> 17), vi, vk[u], mv.lambda_value) <= eps;     // exact, rerank.py:122
+          const uint64_t bm = __ballot(hit);
+          if (bm) {
+            if (hit) { Edge ed; ed.i = gi; ed.k = k; st.buf[st.n + __popcll(bm & lanemask_lt())] = ed; }
+            st.n += __popcll(bm); rowcnt += __popcll(bm);
+            if (st.n > STAGE_CAP - 64) st.flush(eout, cap, cursor, lane);
+          }
         }
       }
     }
     if (lane == 0) cnt[il] = rowcnt;
   }
   st.flush(eout, cap, cursor, lane);
+  if (lane == 0 && anydense) cursor[1] = 1ull;
 }
 
 // ------------------------------------------------------------------ K12 union-find
@@ -1010,7 +1045,7 @@ extern "C" int ssg_eps_sample_hist(const void* M, const uint16_t* v, int N, int 
   int rc = check_view("ssg_eps_sample_hist", M, v, N, row0, nrows, mode); if (rc) return rc;
   if (row_stride < 1) { ssg_set_error("ssg_eps_sample_hist: row_stride must be >= 1"); return SSG_ERR_INVALID; }
   const int nsamp = (nrows + row_stride - 1) / row_stride;
-#define SSG_SH(MD) hipLaunchKernelGGL(eps_sample_hist_kernel<MD>, dim3(stream_grid(nsamp)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
+#define SSG_SH(MD) hipLaunchKernelGGL(eps_sample_hist_kernel<MD>, dim3(stream_grid(nsamp * SPARTS)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
                      row_stride, (const unsigned long long*)refine, (unsigned long long*)hist)
   if (mode == 0) SSG_SH(0); else if (mode == 1) SSG_SH(1); else SSG_SH(2);
 #undef SSG_SH
@@ -1032,32 +1067,55 @@ extern "C" int ssg_eps_compact_below(const void* M, const uint16_t* v, int N, in
                                      const uint64_t* thr3, uint64_t* buf, uint64_t cap, uint64_t* cursor2, hipStream_t stream) {
   int rc = check_view("ssg_eps_compact_below", M, v, N, row0, nrows, mode); if (rc) return rc;
 #define SSG_CT(MD) hipLaunchKernelGGL(eps_compact_thr_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), \
-                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor2, (const unsigned long long*)nullptr)
+                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor2, (const unsigned long long*)nullptr, (const unsigned char*)nullptr)
   if (mode == 0) SSG_CT(0); else if (mode == 1) SSG_CT(1); else SSG_CT(2);
 #undef SSG_CT
   SSG_LAUNCH_CHECK("eps_compact_thr_kernel");
   return SSG_OK;
 }
 
-static SparseView make_sparse(const uint32_t* pool, const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, uint16_t jp0) {
-  SparseView sv; sv.pool = pool; sv.seg_off = seg_off; sv.seg_len = seg_len; sv.nseg = nseg; sv.s_cursor = (const unsigned long long*)s_cursor; sv.jp0 = jp0;
+static SparseView make_sparse(const uint32_t* pool, const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
+                              uint16_t jp0) {
+  SparseView sv; sv.pool = pool; sv.seg_off = seg_off; sv.seg_len = seg_len; sv.nseg = nseg; sv.s_cursor = (const unsigned long long*)s_cursor; sv.vmin = vmin; sv.jp0 = jp0;
   return sv;
 }
 
 // The same pass through the sparse copy S of J' (ssg_jaccard_rows2): cursor3 = {keys collected, exact zeros, dense pass needed}, zeroed by
-// the caller.  Two launches: the walk over S, which either does the work or raises cursor3[2] (threshold at or above J'(0), S
-// overflowed, lambda < 0), and the dense pass gated on that word -- no host decision, no read-back in between.
+// the caller; vmin = half bits of min(v) (ssg_half_min); rowmask = nrows bytes of workspace.  Two launches: the walk over S, which takes
+// every row whose floor J'(0) + lambda * half(v_i + vmin) lies at or above the threshold and flags the others (all of them when S
+// overflowed or lambda < 0), and the dense pass over the flagged rows, gated on cursor3[2] -- no host decision, no read-back in between.
 extern "C" int ssg_eps_compact_below_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, const uint64_t* thr3,
                                        uint64_t* buf, uint64_t cap, uint64_t* cursor3, const uint32_t* s_pool, const int64_t* seg_off,
-                                       const int32_t* seg_len, int nseg, const uint64_t* s_cursor, uint16_t jp0_half, hipStream_t stream) {
+                                       const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin, uint16_t jp0_half,
+                                       uint8_t* rowmask, hipStream_t stream) {
   int rc = check_view("ssg_eps_compact_below_s", M, v, N, row0, nrows, 0); if (rc) return rc;
-  if (!s_pool || !seg_off || !seg_len || nseg <= 0 || !s_cursor) { ssg_set_error("ssg_eps_compact_below_s: no sparse copy"); return SSG_ERR_INVALID; }
+  if (!s_pool || !seg_off || !seg_len || nseg <= 0 || !s_cursor || !vmin || !rowmask) { ssg_set_error("ssg_eps_compact_below_s: no sparse copy"); return SSG_ERR_INVALID; }
   const MatView mv = make_view(M, v, N, row0, nrows, 0, lambda_value);
-  hipLaunchKernelGGL(eps_compact_sparse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, make_sparse(s_pool, seg_off, seg_len, nseg, s_cursor, jp0_half),
-                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor3);
+  hipLaunchKernelGGL(eps_compact_sparse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, make_sparse(s_pool, seg_off, seg_len, nseg, s_cursor, vmin, jp0_half),
+                     (const unsigned long long*)thr3, (unsigned long long*)buf, (unsigned long long)cap, (unsigned long long*)cursor3, rowmask);
   hipLaunchKernelGGL(eps_compact_thr_kernel<0>, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, (const unsigned long long*)thr3, (unsigned long long*)buf,
-                     (unsigned long long)cap, (unsigned long long*)cursor3, (const unsigned long long*)(cursor3 + 2));
+                     (unsigned long long)cap, (unsigned long long*)cursor3, (const unsigned long long*)(cursor3 + 2), (const unsigned char*)rowmask);
   SSG_LAUNCH_CHECK("eps_compact_sparse_kernel");
+  return SSG_OK;
+}
+
+namespace ssg {
+// smallest of N non-negative halves (bit order == value order), one workgroup
+__global__ __launch_bounds__(1024) void half_min_kernel(const hbits* __restrict__ v, int N, uint32_t* __restrict__ out) {
+  __shared__ unsigned smin[16];
+  unsigned m = 0xffffu;
+  for (int i = (int)threadIdx.x; i < N; i += 1024) { const unsigned x = v[i]; m = x < m ? x : m; }
+  for (int sh = 1; sh < 64; sh <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, sh, 64); m = o < m ? o : m; }
+  if ((threadIdx.x & 63) == 0) smin[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) { for (int w = 1; w < 16; w++) m = smin[w] < m ? smin[w] : m; *out = m; }
+}
+}  // namespace ssg
+// *out_bits = min_k v[k] as half bits (v >= 0: the source vector of rerank.py:38-40); the row floors of the sparse passes need it
+extern "C" int ssg_half_min(const uint16_t* v, int N, uint32_t* out_bits, hipStream_t stream) {
+  if (!v || N <= 0 || !out_bits) { ssg_set_error("ssg_half_min: bad arguments"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(ssg::half_min_kernel, dim3(1), dim3(1024), 0, stream, v, N, out_bits);
+  SSG_LAUNCH_CHECK("half_min_kernel");
   return SSG_OK;
 }
 
@@ -1174,29 +1232,27 @@ extern "C" int ssg_region_query(const void* M, const uint16_t* v, int N, int row
                                 int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
   int rc = check_view("ssg_region_query", M, v, N, row0, nrows, mode); if (rc) return rc;
 #define SSG_RQ(MD) hipLaunchKernelGGL(region_query_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), eps, \
-                     cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor)
+                     cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor, (const unsigned long long*)nullptr, (const unsigned char*)nullptr)
   if (mode == 0) SSG_RQ(0); else if (mode == 1) SSG_RQ(1); else SSG_RQ(2);
 #undef SSG_RQ
   SSG_LAUNCH_CHECK("region_query_kernel");
   return SSG_OK;
 }
 
-// Region query through the sparse copy S of J' -- the caller has checked eps < f64(J'(0)) and that S did not overflow
-// (ssg_jaccard_rows2's s_cursor[1] == 0): then no column outside S can be a neighbour.  Same outputs as ssg_region_query.
-extern "C" int ssg_region_query_s(const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
-                                  const int64_t* seg_off, const int32_t* seg_len, int nseg, uint16_t jp0_half, int32_t* cnt, int32_t* edges,
-                                  uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
-  if (!v || !s_pool || !seg_off || !seg_len || nseg <= 0 || N <= 0 || nrows <= 0 || row0 < 0 || row0 + nrows > N) {
-    ssg_set_error("ssg_region_query_s: bad arguments (N=%d row0=%d nrows=%d)", N, row0, nrows); return SSG_ERR_INVALID;
-  }
-  const float jp0 = (float)__builtin_bit_cast(_Float16, jp0_half);
-  if (!(lambda_value >= 0.0) || !(eps < (double)jp0) || (jp0_half & 0x8000u)) {
-    ssg_set_error("ssg_region_query_s: eps = %g is not below J'(0) = %g (or lambda < 0): the dense region query must be used", eps, (double)jp0);
-    return SSG_ERR_INVALID;
-  }
-  const MatView mv = make_view(s_pool, v, N, row0, nrows, 0, lambda_value);
-  hipLaunchKernelGGL(region_query_sparse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, make_sparse(s_pool, seg_off, seg_len, nseg, nullptr, jp0_half), eps,
-                     cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor);
+// Region query through the sparse copy S of J': cursor2 = {edges counted, dense pass needed} zeroed by the caller, rowmask = nrows bytes
+// of workspace.  Row i goes through S when J'(0) + lambda * half(v_i + vmin) > eps; the other rows (all of them when S overflowed) are
+// flagged and done by the dense pass queued behind, gated on cursor2[1].  Same outputs as ssg_region_query.
+extern "C" int ssg_region_query_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
+                                  const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
+                                  uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
+                                  hipStream_t stream) {
+  int rc = check_view("ssg_region_query_s", M, v, N, row0, nrows, 0); if (rc) return rc;
+  if (!s_pool || !seg_off || !seg_len || nseg <= 0 || !s_cursor || !vmin || !rowmask) { ssg_set_error("ssg_region_query_s: no sparse copy"); return SSG_ERR_INVALID; }
+  const MatView mv = make_view(M, v, N, row0, nrows, 0, lambda_value);
+  hipLaunchKernelGGL(region_query_sparse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, make_sparse(s_pool, seg_off, seg_len, nseg, s_cursor, vmin, jp0_half),
+                     eps, cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor2, rowmask);
+  hipLaunchKernelGGL(region_query_kernel<0>, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, eps, cnt, edges, (unsigned long long)cap_edges,
+                     (unsigned long long*)cursor2, (const unsigned long long*)(cursor2 + 1), (const unsigned char*)rowmask);
   SSG_LAUNCH_CHECK("region_query_sparse_kernel");
   return SSG_OK;
 }

@@ -373,10 +373,19 @@ __global__ __launch_bounds__(64) void jaccard_rows2_kernel(const int32_t* __rest
       };
       if (head == 0) {
         const int nvec = cw >> 3;
-        for (int q = lane; q < nvec; q += 64) {
-          const uint4 x = *reinterpret_cast<const uint4*>(t + q * 8);
-          *reinterpret_cast<uint4*>(t + q * 8) = make_uint4(0, 0, 0, 0);
-          *reinterpret_cast<uint4*>(out + q * 8) = make_uint4(merge(x.x), merge(x.y), merge(x.z), merge(x.w));
+        // four LDS vectors per lane in flight (one read -> merge -> store per trip would leave every trip waiting on its own LDS read)
+        for (int q0 = 0; q0 < nvec; q0 += 256) {
+          uint4 x[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int q = q0 + u * 64 + lane; if (q < nvec) x[u] = *reinterpret_cast<const uint4*>(t + q * 8); }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int q = q0 + u * 64 + lane;
+            if (q < nvec) {
+              *reinterpret_cast<uint4*>(t + q * 8) = make_uint4(0, 0, 0, 0);
+              *reinterpret_cast<uint4*>(out + q * 8) = make_uint4(merge(x[u].x), merge(x[u].y), merge(x[u].z), merge(x[u].w));
+            }
+          }
         }
         for (int x = (nvec << 3) + lane; x < cw; x += 64) { const hbits tv = t[x]; t[x] = 0; out[x] = (tv & 0x8000u) ? (hbits)(tv & 0x7fffu) : jp0; }
       } else {

@@ -58,28 +58,48 @@ __global__ __launch_bounds__(256) void krecip_kernel(const hbits* __restrict__ D
   const int i = row0 + il;
   const uint64_t lt = lanemask_lt();
 
+  // The rank lists are L2-resident, but every read of one is a ~1 us round trip and the walk below is a chain of them: the reads are
+  // issued EIGHT AT A TIME (clamped index, unconditional) so that a list costs ceil(len / 8) round trips instead of len (round 4: the
+  // one-load-per-iteration loops made this kernel 0.23 ms of pure latency at N = 16 000).
+  auto holds = [&](const int32_t* __restrict__ list, int len, int what) -> bool {     // is `what` among list[0 .. len)?
+    bool h = false;
+    for (int b0 = 0; b0 < len; b0 += 8) {
+      int x[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) x[u] = list[min(b0 + u, len - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) h |= (x[u] == what);
+    }
+    return h;
+  };
   // (a) k-reciprocal neighbours  (rerank.py:76-79)
   const int f = lane < K1 ? rank[(int64_t)i * K + lane] : -1;
-  bool hit = false;
-  if (lane < K1) {
-    const int32_t* bw = rank + (int64_t)f * K;
-    for (int b = 0; b < K1; b++) hit |= (bw[b] == i);
-  }
+  const bool hit = lane < K1 && holds(rank + (int64_t)f * K, K1, i);
   const uint64_t rmask = __ballot(hit);
   const int nrec = __popcll(rmask);
   if (hit) { const int p = __popcll(rmask & lt); rec[p] = f; expn[p] = f; }
   int ne = nrec;
   wave_sync();
 
-  // (b) 1/2-k expansion  (rerank.py:81-88)
+  // (b) 1/2-k expansion  (rerank.py:81-88).  All (candidate, neighbour) pairs at once: first every candidate's first kh neighbours
+  // (one round trip), then for every such neighbour whether the candidate is among ITS first kh (two round trips for kh <= 16) -- the
+  // per-candidate decisions that follow only touch LDS.  `uniq` / `flag` are free until step (c): cfs = uniq, chf = flag.
+  int32_t* cfs = uniq;
+  int32_t* chf = flag;
+  const int npair = nrec * kh;
+  for (int idx = lane; idx < npair; idx += 64) {
+    const int a = idx / kh, l = idx - a * kh;
+    cfs[idx] = rank[(int64_t)rec[a] * K + l];
+  }
+  wave_sync();
+  for (int idx = lane; idx < npair; idx += 64) {
+    const int a = idx / kh;
+    chf[idx] = holds(rank + (int64_t)cfs[idx] * K, kh, rec[a]) ? 1 : 0;
+  }
+  wave_sync();
   for (int a = 0; a < nrec; a++) {
-    const int cand = rec[a];
-    const int cf = lane < kh ? rank[(int64_t)cand * K + lane] : -1;
-    bool chit = false;
-    if (lane < kh) {
-      const int32_t* cb = rank + (int64_t)cf * K;
-      for (int c = 0; c < kh; c++) chit |= (cb[c] == cand);
-    }
+    const int cf = lane < kh ? cfs[a * kh + lane] : -1;
+    const bool chit = lane < kh && chf[a * kh + lane] != 0;
     const uint64_t cmask = __ballot(chit);
     const int nc = __popcll(cmask);
     bool inrec = false;
@@ -163,20 +183,40 @@ __global__ __launch_bounds__(256) void query_expand_kernel(const int32_t* __rest
   auto L_val = [&](int r) { return reinterpret_cast<hbits*>(wbase + per_list * r + (size_t)capL * 4 + (size_t)(capL + 1) * 4); };
   int32_t* nn = reinterpret_cast<int32_t*>(wbase + per_list * kk);   // list lengths
 
-  // stage the kk source rows (V rows of the first k2 ranked neighbours, rerank.py:97)
+  // stage the kk source rows (V rows of the first k2 ranked neighbours, rerank.py:97): sources and lengths of all lists first (two
+  // round trips for the whole row instead of two per list), then the entries
   int nmax = 0;
-  for (int r = 0; r < kk; r++) {
-    const int src = rank[(int64_t)i * K + r];
-    int n = v_nnz[src];
-    nmax = n > nmax ? n : nmax;
-    if (n > capL) {                      // a guessed max_nnz was too small: flag it (the caller redoes the step), keep the row in bounds
-      if (lane == 0 && overflow) atomicMax(overflow, n);
-      n = capL;
+  {
+    const int srcl = lane < kk ? rank[(int64_t)i * K + lane] : 0;
+    int nl = lane < kk ? v_nnz[srcl] : 0;
+    int m = nl;
+    for (int sh = 1; sh < 64; sh <<= 1) m = max(m, __shfl_xor(m, sh, 64));
+    nmax = m;
+    if (nl > capL) {                     // a guessed max_nnz was too small: flag it (the caller redoes the step), keep the row in bounds
+      if (overflow) atomicMax(overflow, nl);
+      nl = capL;
     }
-    if (lane == 0) nn[r] = n;
-    for (int p = lane; p < n; p += 64) {
-      L_idx(r)[p] = v_idx[(int64_t)src * capV + p];
-      L_val(r)[p] = v_val[(int64_t)src * capV + p];
+    if (lane < kk) nn[lane] = nl;
+    // the entries of ALL lists as one flat index space, four per lane in flight (list by list, every list paid its own round trip)
+    int incl = nl;
+    for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
+    const int total = __shfl(incl, kk - 1, 64);
+    for (int f0 = 0; f0 < total; f0 += 256) {
+      int rr[4], pp[4], ci[4]; hbits cv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int f = f0 + u * 64 + lane;
+        int r = 0;                                   // list holding flat entry f: the first r with f < incl[r]
+        for (int q = 0; q < kk; q++) r += (f >= __shfl(incl, q, 64)) ? 1 : 0;
+        r = r < kk ? r : kk - 1;
+        const int start = __shfl(incl, r, 64) - __shfl(nl, r, 64);
+        rr[u] = r; pp[u] = f - start;
+        const int64_t a = (int64_t)__shfl(srcl, r, 64) * capV + (f < total ? pp[u] : 0);
+        ci[u] = v_idx[a]; cv[u] = v_val[a];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (f0 + u * 64 + lane < total) { L_idx(rr[u])[pp[u]] = ci[u]; L_val(rr[u])[pp[u]] = cv[u]; }
     }
   }
   // overflow[1] = longest V row met so far (feeds the caller's next guess); a plain read first: after the first waves almost no atomics

@@ -106,7 +106,8 @@ __global__ __launch_bounds__(256) void triplet_grad_weights_kernel(const float* 
   float acc = 0.f;
   for (int j = lane; j < ld; j += 64) {
     float s = 0.f;
-    if (j < n) {
+    if (j < n && j != i) {     // the diagonal multiplies x_i - x_i = 0: left out, so that a float32 residue in sq[i,i] (|x|^2 + |x|^2 - 2 x.x is not
+                               // exactly 0) cannot put a huge weight 1 / dist[i,i] into rowsum and S x, where it would only cancel approximately
       const int64_t a = (int64_t)i * n + j, b = (int64_t)j * n + i;
       const float wij = sq[a] >= lo ? g[a] / dist[a] : 0.f;
       const float wji = sq[b] >= lo ? g[b] / dist[b] : 0.f;

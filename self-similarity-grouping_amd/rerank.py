@@ -342,9 +342,11 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     if os.environ.get("SSG_SPARSE", "1") != "0":
         nseg = int(L.ssg_jaccard_segments(N))
         s_cap = int(nrows) * int(min(N, int(os.environ.get("SSG_SPARSE_ROW_ENTRIES", "1024"))))
+        vmin = torch.empty(1, dtype=torch.int32, device=dev)
+        check(L.ssg_half_min(ptr(v), N, ptr(vmin), st), "ssg_half_min")      # the row floors J'(0) + lambda * half(v_i + min v) of the sparse passes
         sparse = dict(pool=torch.empty(max(s_cap, 1), dtype=torch.int32, device=dev), cap=s_cap, cursor=torch.zeros(2, dtype=torch.int64, device=dev),
                       seg_off=torch.empty(nrows * nseg, dtype=torch.int64, device=dev), seg_len=torch.empty(nrows * nseg, dtype=torch.int32, device=dev),
-                      nseg=nseg, jp0=int(om))
+                      nseg=nseg, jp0=int(om), vmin=vmin, rowmask=torch.empty(nrows, dtype=torch.uint8, device=dev))
 
     def tail(mx, over):
         """local query expansion -> inverted index -> Jaccard rows into Jp, with LDS / row capacities sized for V rows of at most `mx`

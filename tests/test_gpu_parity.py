@@ -780,9 +780,18 @@ def test_jaccard_second_generation_and_sparse_copy(dev, ora, monkeypatch):
         l1big = cluster.DBSCAN(eps=big, min_samples=4, metric="precomputed").fit_predict(h1) if N <= 6000 else None
         e1half = cluster.eps_rule(h1, 0.5) if N <= 6000 else None
         monkeypatch.delenv("SSG_SPARSE")
+        if name == "wide":
+            # rows with more than 3072 touched columns (the LDS list overflows: dense patch pass): the default pool (1024 entries per row)
+            # cannot hold them -- S is marked unusable and the consumers go dense; a pool of N entries per row holds everything
+            h0 = rerank.re_ranking_device(s_d, t_d, **kw)
+            assert torch.equal(h1.M.view(torch.int16), h0.M.view(torch.int16)) and not h0.sparse_ok
+            assert cluster.eps_rule(h0, 1.6e-3) == e1
+            assert np.array_equal(cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h0), l1)
+            monkeypatch.setenv("SSG_SPARSE_ROW_ENTRIES", str(N))
         h2 = rerank.re_ranking_device(s_d, t_d, **kw)
+        monkeypatch.delenv("SSG_SPARSE_ROW_ENTRIES", raising=False)
         assert torch.equal(h1.M.view(torch.int16), h2.M.view(torch.int16)), name
-        assert h2.sparse_ok
+        assert h2.sparse_ok, name
         _check_sparse_copy(h2, N)
         assert cluster.eps_rule(h2, 1.6e-3) == e1, name
         assert np.array_equal(cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h2), l1), name

@@ -19,8 +19,12 @@ def main():
     ap.add_argument("--Ns", type=int, default=12936)
     ap.add_argument("--d", type=int, default=2048)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--track", choices=("separable", "hard"), default="separable")
+    ap.add_argument("--lam", type=float, default=0.1)
     a = ap.parse_args()
-    from conftest import clustered
+    from conftest import clustered, hard_clustered
+    if a.track == "hard":
+        clustered = hard_clustered      # noqa: F811  (bench.py's default track)
     from ssg_amd import rerank, cluster, _lib
     dev = torch.device("cuda", 0)
     tgt = torch.from_numpy(clustered(a.N, a.d, 1)).to(dev)
@@ -50,7 +54,7 @@ def main():
     for rep in range(a.reps):
         times.clear()
         torch.cuda.synchronize(); t0 = time.time()
-        h = rerank.re_ranking_device(src, tgt, lambda_value=0.1, validate=False)
+        h = rerank.re_ranking_device(src, tgt, lambda_value=a.lam, validate=False)
         torch.cuda.synchronize(); t1 = time.time()
         eps, cnt, top = cluster.eps_rule(h, 1.6e-3)
         torch.cuda.synchronize(); t2 = time.time()
