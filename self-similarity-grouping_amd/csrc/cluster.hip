@@ -593,14 +593,29 @@ __global__ __launch_bounds__(1024) void bitonic_local_kernel(unsigned long long*
   }
   a[g0 + t] = s[t]; a[g0 + t + 1024] = s[t + 1024];
 }
-__global__ void bitonic_global_kernel(unsigned long long* __restrict__ a, unsigned long long n, unsigned long long k, unsigned long long j) {
+// NS consecutive global stages (strides j, j/2, .. j >> (NS-1), all >= SORT_CH) of merge level k in ONE launch: a thread holds the 2^NS
+// elements whose indices differ only in those stride bits, so every compare-exchange of the NS stages stays inside its registers
+// (round 4: one launch per stage was 36 launches of ~3 us for 2^19 keys; three stages per launch make it 15).  k >= 2j, so the
+// sort direction is the same for all of a thread's elements.
+template <int NS>
+__global__ __launch_bounds__(256) void bitonic_global_kernel(unsigned long long* __restrict__ a, unsigned long long n, unsigned long long k, unsigned long long j) {
+  constexpr int NE = 1 << NS;
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n / 2) return;
-  const unsigned long long i = (t / j) * (2 * j) + (t % j);
-  const bool up = ((i & k) == 0);
-  unsigned long long x = a[i], y = a[i + j];
-  cswap(x, y, up);
-  a[i] = x; a[i + j] = y;
+  if (t >= n / NE) return;
+  const unsigned long long jl = j >> (NS - 1);                  // smallest stride of this launch
+  const unsigned long long base = (t / jl) * (NE * jl) + (t % jl);
+  const bool up = ((base & k) == 0);
+  unsigned long long e[NE];
+#pragma unroll
+  for (int b = 0; b < NE; b++) e[b] = a[base + (unsigned long long)b * jl];
+#pragma unroll
+  for (int s = NS - 1; s >= 0; s--) {                           // stride jl << s
+#pragma unroll
+    for (int b = 0; b < NE; b++)
+      if (!(b & (1 << s))) cswap(e[b], e[b | (1 << s)], up);
+  }
+#pragma unroll
+  for (int b = 0; b < NE; b++) a[base + (unsigned long long)b * jl] = e[b];
 }
 
 // ------------------------------------------------------------------ numpy pairwise mean
@@ -1125,8 +1140,17 @@ extern "C" int ssg_sort_u64(uint64_t* buf, uint64_t n, hipStream_t stream) {
   unsigned long long* a = (unsigned long long*)buf;
   hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(n / SORT_CH)), dim3(1024), 0, stream, a, 2ULL, (unsigned long long)SORT_CH);
   for (unsigned long long k = 2ULL * SORT_CH; k <= n; k <<= 1) {
-    for (unsigned long long j = k >> 1; j >= (unsigned long long)SORT_CH; j >>= 1)
-      hipLaunchKernelGGL(bitonic_global_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, a, (unsigned long long)n, k, j);
+    unsigned long long j = k >> 1;
+    while (j >= (unsigned long long)SORT_CH) {                  // global stages j, j/2, ... SORT_CH: three per launch while they last
+      int ns = 0;
+      for (unsigned long long q = j; q >= (unsigned long long)SORT_CH && ns < 3; q >>= 1) ns++;
+      const unsigned long long thr = n >> ns;
+      const unsigned blocks = (unsigned)((thr + 255) / 256);
+      if (ns == 3) hipLaunchKernelGGL(bitonic_global_kernel<3>, dim3(blocks), dim3(256), 0, stream, a, (unsigned long long)n, k, j);
+      else if (ns == 2) hipLaunchKernelGGL(bitonic_global_kernel<2>, dim3(blocks), dim3(256), 0, stream, a, (unsigned long long)n, k, j);
+      else hipLaunchKernelGGL(bitonic_global_kernel<1>, dim3(blocks), dim3(256), 0, stream, a, (unsigned long long)n, k, j);
+      j >>= ns;
+    }
     hipLaunchKernelGGL(bitonic_local_kernel, dim3((unsigned)(n / SORT_CH)), dim3(1024), 0, stream, a, k, k);
   }
   SSG_LAUNCH_CHECK("bitonic sort");

@@ -46,14 +46,15 @@ __global__ __launch_bounds__(256) void krecip_kernel(const hbits* __restrict__ D
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
   const int il = (int)blockIdx.x * 4 + wave;   // row within this row block
-  const size_t per_wave = 64 * 4 + (size_t)cap * 18;
+  const int capp = (cap + 7) & ~3;              // array pitch: room for the 4-entry vector reads of step (c) past the last entry
+  const size_t per_wave = 64 * 4 + (size_t)capp * 18;
   unsigned char* wbase = smem + (size_t)wave * ((per_wave + 15) & ~(size_t)15);
   int32_t* rec = reinterpret_cast<int32_t*>(wbase);
   int32_t* expn = rec + 64;
-  int32_t* flag = expn + cap;
-  int32_t* uniq = flag + cap;
-  float* wf = reinterpret_cast<float*>(uniq + cap);
-  hbits* wh = reinterpret_cast<hbits*>(wf + cap);
+  int32_t* flag = expn + capp;
+  int32_t* uniq = flag + capp;
+  float* wf = reinterpret_cast<float*>(uniq + capp);
+  hbits* wh = reinterpret_cast<hbits*>(wf + capp);
   if (il >= nrows) return;
   const int i = row0 + il;
   const uint64_t lt = lanemask_lt();
@@ -97,13 +98,15 @@ __global__ __launch_bounds__(256) void krecip_kernel(const hbits* __restrict__ D
     chf[idx] = holds(rank + (int64_t)cfs[idx] * K, kh, rec[a]) ? 1 : 0;
   }
   wave_sync();
+  const int recl = lane < nrec ? rec[lane] : -1;        // lane q holds rec[q] (nrec <= K1 <= 64): membership tests read it with v_readlane
   for (int a = 0; a < nrec; a++) {
     const int cf = lane < kh ? cfs[a * kh + lane] : -1;
     const bool chit = lane < kh && chf[a * kh + lane] != 0;
     const uint64_t cmask = __ballot(chit);
     const int nc = __popcll(cmask);
     bool inrec = false;
-    if (chit) for (int q = 0; q < nrec; q++) inrec |= (rec[q] == cf);
+    for (int q = 0; q < nrec; q++) inrec |= (__builtin_amdgcn_readlane(recl, q) == cf);
+    inrec &= chit;
     const int inter = __popcll(__ballot(inrec));
     if ((double)inter > (2.0 / 3.0) * (double)nc) {   // len(intersect1d) > 2/3*len(candidate set)
       if (chit) expn[ne + __popcll(cmask & lt)] = cf;
@@ -112,26 +115,46 @@ __global__ __launch_bounds__(256) void krecip_kernel(const hbits* __restrict__ D
   }
   wave_sync();
 
-  // (c) np.unique: sorted distinct columns  (rerank.py:90)
-  for (int p = lane; p < ne; p += 64) {
-    const int x = expn[p];
-    bool first = true;
-    for (int q = 0; q < p; q++) first &= (expn[q] != x);
-    flag[p] = first ? 1 : 0;
+  // (c) np.unique: sorted distinct columns  (rerank.py:90).  Counting sort by comparison, on 4-entry LDS vectors: an entry is kept when
+  // no EARLIER entry equals it; a kept entry's position is the number of kept entries smaller than it.  (Round 4: the one-entry-per-trip
+  // loops of the first version were ~1500 dependent LDS reads per lane -- 100 us per row, the whole kernel's time.)
+  const int ne4 = (ne + 3) & ~3;
+  if (lane < ne4 - ne) expn[ne + lane] = 0x7fffffff;       // sentinels up to the vector boundary (never equal to / smaller than a column)
+  wave_sync();
+  for (int p0 = 0; p0 < ne; p0 += 64) {
+    const int p = p0 + lane;
+    const int x = p < ne ? expn[p] : 0x7fffffff;
+    bool dup = false;
+    const int qend = min(p0 + 64, ne4);                      // entries at or after p never count: masked below
+    for (int q0 = 0; q0 < qend; q0 += 16) {                  // four vectors in flight (reads past qend stay inside the padded array: masked by q < p)
+      int4 e[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) e[u] = *reinterpret_cast<const int4*>(expn + min(q0 + 4 * u, ne4 - 4));
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int q = min(q0 + 4 * u, ne4 - 4);
+        dup |= (q < p && e[u].x == x) | (q + 1 < p && e[u].y == x) | (q + 2 < p && e[u].z == x) | (q + 3 < p && e[u].w == x);
+      }
+    }
+    if (p < ne4) flag[p] = (p < ne && !dup) ? x : 0x7fffffff;   // kept entries keep their column, duplicates and padding become +inf
   }
   wave_sync();
   int nu = 0;
   for (int p0 = 0; p0 < ne; p0 += 64) {
     const int p = p0 + lane;
-    bool isf = false;
-    if (p < ne && flag[p]) {
-      isf = true;
-      const int x = expn[p];
-      int pos = 0;
-      for (int q = 0; q < ne; q++) pos += (flag[q] && expn[q] < x);
-      uniq[pos] = x;
+    const int x = p < ne ? flag[p] : 0x7fffffff;
+    const bool kept = x != 0x7fffffff;
+    int pos = 0;
+    for (int q0 = 0; q0 < ne4; q0 += 16) {
+      int4 e[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) e[u] = *reinterpret_cast<const int4*>(flag + min(q0 + 4 * u, ne4 - 4));
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (q0 + 4 * u < ne4) pos += (e[u].x < x) + (e[u].y < x) + (e[u].z < x) + (e[u].w < x);
     }
-    nu += __popcll(__ballot(isf));
+    if (kept) uniq[pos] = x;
+    nu += __popcll(__ballot(kept));
   }
   wave_sync();
 
@@ -206,12 +229,15 @@ __global__ __launch_bounds__(256) void query_expand_kernel(const int32_t* __rest
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int f = f0 + u * 64 + lane;
-        int r = 0;                                   // list holding flat entry f: the first r with f < incl[r]
-        for (int q = 0; q < kk; q++) r += (f >= __shfl(incl, q, 64)) ? 1 : 0;
-        r = r < kk ? r : kk - 1;
-        const int start = __shfl(incl, r, 64) - __shfl(nl, r, 64);
+        // list holding flat entry f: the last list whose start is <= f (list lengths / sources are wave-uniform per list: v_readlane,
+        // not the LDS crossbar)
+        int r = 0, start = 0, src = __builtin_amdgcn_readlane(srcl, 0);
+        for (int q = 1; q < kk; q++) {
+          const int sq = __builtin_amdgcn_readlane(incl, q - 1);
+          if (f >= sq) { r = q; start = sq; src = __builtin_amdgcn_readlane(srcl, q); }
+        }
         rr[u] = r; pp[u] = f - start;
-        const int64_t a = (int64_t)__shfl(srcl, r, 64) * capV + (f < total ? pp[u] : 0);
+        const int64_t a = (int64_t)src * capV + (f < total ? pp[u] : 0);
         ci[u] = v_idx[a]; cv[u] = v_val[a];
       }
 #pragma unroll
@@ -292,7 +318,7 @@ extern "C" int ssg_krecip(const uint16_t* D, const uint32_t* rowmax, const int32
     ssg_set_error("ssg_krecip: need k1+1 <= 64 and cap >= %d (got %d)", K1 + K1 * kh, cap);
     return SSG_ERR_INVALID;
   }
-  const size_t per_wave = ((64 * 4 + (size_t)cap * 18) + 15) & ~(size_t)15;
+  const size_t per_wave = ((64 * 4 + (size_t)((cap + 7) & ~3) * 18) + 15) & ~(size_t)15;
   const size_t lds = per_wave * 4;
   if (lds > 160 * 1024) { ssg_set_error("ssg_krecip: k1=%d needs %zu B LDS", k1, lds); return SSG_ERR_INVALID; }
   if (lds > 64 * 1024) SSG_HIP(hipFuncSetAttribute((const void*)krecip_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -257,28 +257,48 @@ __global__ __launch_bounds__(256) void range_stats_kernel(const float* __restric
   const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
   unsigned best[4] = {0u, 0u, 0u, 0u};
   const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | (b ? reinterpret_cast<uintptr_t>(b) : 0)) & 15) == 0;
-  for (int row = wave; row < rows_a + rows_b; row += nwaves) {
-    const bool second = row >= rows_a;
-    const float* x = second ? b + (int64_t)(row - rows_a) * d : a + (int64_t)row * d;
-    unsigned mx = 0u; float s = 0.f;
+  const int rows = rows_a + rows_b;
+  // four rows per trip: their loads are all in flight before the first reduction (one row per trip left the wave waiting on its own
+  // 8 KB and on twelve dependent cross-lane steps per row)
+  for (int r0 = wave * 4; r0 < rows; r0 += nwaves * 4) {
+    unsigned mx[4] = {0u, 0u, 0u, 0u}; float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xp[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int row = min(r0 + u, rows - 1); xp[u] = row >= rows_a ? b + (int64_t)(row - rows_a) * d : a + (int64_t)row * d; }
     if (vec) {
       for (int c = lane * 4; c < d; c += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + c);
-        const float e[4] = {v.x, v.y, v.z, v.w};
+        float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const unsigned bits = __float_as_uint(e[u]) & 0x7fffffffu; mx = bits > mx ? bits : mx; s += e[u] * e[u]; }
+        for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(xp[u] + c);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int t = 0; t < 4; t++) { const unsigned bits = __float_as_uint(e[t]) & 0x7fffffffu; mx[u] = bits > mx[u] ? bits : mx[u]; sq[u] += e[t] * e[t]; }
+        }
       }
     } else {
-      for (int c = lane; c < d; c += 64) { const float v = x[c]; const unsigned bits = __float_as_uint(v) & 0x7fffffffu; mx = bits > mx ? bits : mx; s += v * v; }
+      for (int c = lane; c < d; c += 64) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const float v = xp[u][c]; const unsigned bits = __float_as_uint(v) & 0x7fffffffu; mx[u] = bits > mx[u] ? bits : mx[u]; sq[u] += v * v; }
+      }
     }
     for (int sh = 1; sh < 64; sh <<= 1) {
-      const unsigned o = (unsigned)__shfl_xor((int)mx, sh, 64);
-      mx = o > mx ? o : mx;
-      s += __shfl_xor(s, sh, 64);
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const unsigned o = (unsigned)__shfl_xor((int)mx[u], sh, 64);
+        mx[u] = o > mx[u] ? o : mx[u];
+        sq[u] += __shfl_xor(sq[u], sh, 64);
+      }
     }
-    const unsigned nb = __float_as_uint(sqrtf(s) * 1.00001f) & 0x7fffffffu;
-    unsigned& bm = best[second ? 1 : 0]; bm = mx > bm ? mx : bm;
-    unsigned& bn = best[second ? 3 : 2]; bn = nb > bn ? nb : bn;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (r0 + u >= rows) break;
+      const bool second = r0 + u >= rows_a;
+      const unsigned nb = __float_as_uint(sqrtf(sq[u]) * 1.00001f) & 0x7fffffffu;
+      unsigned& bm = best[second ? 1 : 0]; bm = mx[u] > bm ? mx[u] : bm;
+      unsigned& bn = best[second ? 3 : 2]; bn = nb > bn ? nb : bn;
+    }
   }
   if (lane == 0) {
 #pragma unroll
@@ -296,7 +316,7 @@ extern "C" int ssg_range_stats_f32(const float* a, int rows_a, const float* b, i
   if (!a || rows_a <= 0 || d <= 0 || rows_b < 0 || (rows_b > 0 && !b) || !out4) { ssg_set_error("ssg_range_stats_f32: bad arguments"); return SSG_ERR_INVALID; }
   SSG_HIP(hipMemsetAsync(out4, 0, 4 * sizeof(float), stream));
   const int rows = rows_a + rows_b;
-  const int blocks = std::min((rows + 3) / 4, 2048);            // 8192 persistent waves: 32 per CU
+  const int blocks = std::min((rows + 15) / 16, 2048);          // persistent waves (at most 32 per CU), four rows per trip
   hipLaunchKernelGGL(range_stats_kernel, dim3(blocks), dim3(256), 0, stream, a, rows_a, b, rows_b, d, reinterpret_cast<unsigned*>(out4));
   SSG_LAUNCH_CHECK("range_stats_kernel");
   return SSG_OK;

@@ -251,15 +251,28 @@ __device__ __forceinline__ int partition(const Arena& A, Ctl* sh, const Masks& m
       for (int u = 0; u < 4; u++) e[u] = A.get(min(s0 + ((w + u) << 6) + lane, s1));
       uint64_t lm[4], rm[4];
       uint32_t cc[4];
+      // all four words inside the scan region (every group but the last of a partition): no validity masks -- they cost nine scalar
+      // instructions per word on the CU's one scalar unit, which this kernel keeps busier than its vector units
+      if (((w + 4) << 6) <= nscan) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int rem = nscan - ((w + u) << 6);                         // scan positions left from this word on (uniform)
-        const uint64_t vm = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
-        const uint32_t x = eraw(e[u]);
-        lm[u] = __builtin_amdgcn_uicmp(x, tlo, 35) & vm;                // ICMP_UGE
-        rm[u] = __builtin_amdgcn_uicmp(x, thi, 37) & vm;                // ICMP_ULE
-        runL += (uint32_t)__popcll(lm[u]); runR += (uint32_t)__popcll(rm[u]);
-        cc[u] = runL | (runR << 16);
+        for (int u = 0; u < 4; u++) {
+          const uint32_t x = eraw(e[u]);
+          lm[u] = __builtin_amdgcn_uicmp(x, tlo, 35);                     // ICMP_UGE
+          rm[u] = __builtin_amdgcn_uicmp(x, thi, 37);                     // ICMP_ULE
+          runL += (uint32_t)__popcll(lm[u]); runR += (uint32_t)__popcll(rm[u]);
+          cc[u] = runL | (runR << 16);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int rem = nscan - ((w + u) << 6);                         // scan positions left from this word on (uniform)
+          const uint64_t vm = rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
+          const uint32_t x = eraw(e[u]);
+          lm[u] = __builtin_amdgcn_uicmp(x, tlo, 35) & vm;                // ICMP_UGE
+          rm[u] = __builtin_amdgcn_uicmp(x, thi, 37) & vm;                // ICMP_ULE
+          runL += (uint32_t)__popcll(lm[u]); runR += (uint32_t)__popcll(rm[u]);
+          cc[u] = runL | (runR << 16);
+        }
       }
       if (lane == 0) {     // the arrays are padded to a multiple of four words
         uint4* q = reinterpret_cast<uint4*>(mk.L + w);

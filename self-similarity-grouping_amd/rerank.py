@@ -83,7 +83,7 @@ class DistHandle:
             self._pending = None
             self.sparse_ok = self.sparse is not None and len(values) >= 6 and int(values[5]) == 0
             if seen > 0 and self._k1 is not None:
-                _QE_GUESS[self._k1] = max(32, ((seen * 3 // 2) + 15) // 16 * 16)
+                _QE_GUESS[self._k1] = max(32, ((seen * 5 // 4) + 7) // 8 * 8)       # + 25 %: the LDS staging (and the occupancy) follows the guess
             if over and self._redo is not None:
                 self._redo()
                 redone = True
@@ -385,7 +385,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
             tables.update(q_idx=q_idx, q_val=q_val, q_nnz=q_nnz, colptr=colptr, inv_row=inv_row, inv_val=inv_val)
 
     # ---- local query expansion (rerank.py:94-99) .. Jaccard rows.  The LDS staging and the row capacity of V_qe follow the longest V
-    # row.  One GPU: run on a GUESS (the longest row of the previous call + 50 %, 96 at first) and let the kernel report a longer row
+    # row.  One GPU: run on a GUESS (the longest row of the previous call + 25 %, 64 at first) and let the kernel report a longer row
     # through the status words that the consumer reads anyway (`validate`); a miss redoes this tail with the exact bound (rare; the
     # result is the same either way).  Sharded rows: every rank must take the same branch, so the gathered v_nnz is read back (one
     # blocking read, no collective of its own).
@@ -393,7 +393,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     if k2 == 1:
         tail(capV, None)
     elif group is None and os.environ.get("SSG_QE_GUESS", "1") != "0":
-        guess = min(capV, _QE_GUESS.get(k1, 96))
+        guess = min(capV, _QE_GUESS.get(k1, 64))
         tail(guess, status[2:4])
         redo = lambda: tail(capV, None)            # noqa: E731  (keeps the small tables alive, not D)
     else:
@@ -413,7 +413,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     return h
 
 
-_QE_GUESS = {}      # k1 -> guessed longest V row for the next call (the longest row of the last call + 50 %, a multiple of 16)
+_QE_GUESS = {}      # k1 -> guessed longest V row for the next call (the longest row of the last call + 25 %, a multiple of 8)
 
 
 def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.2, MemorySave=False, Minibatch=2000, no_rerank=False,

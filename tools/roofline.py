@@ -10,9 +10,10 @@ PEAK_INT8_MFMA_TOPS = 5033.2  # dense int8 matrix peak (v_mfma_i32_32x32x32_i8 =
 PEAK_FP64_MFMA_TF = 78.6      # SURVEY.md 8d / BASELINE.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 
-K5_K12 = ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_eps_hist",
-          "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_refine_threshold", "ssg_eps_compact_below", "ssg_fill_u64",
-          "ssg_sort_u64", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_dbscan_cc", "ssg_dbscan_cc_dev")
+K5_K12 = ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_jaccard_rows2", "ssg_half_min",
+          "ssg_eps_hist", "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_refine_threshold", "ssg_eps_compact_below",
+          "ssg_eps_compact_below_s", "ssg_fill_u64", "ssg_sort_u64", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_region_query_s", "ssg_dbscan_cc",
+          "ssg_dbscan_cc_dev")
 
 
 class KernelTimer:
@@ -51,10 +52,15 @@ def grouping_roofline(tot, N, nrows, Ns, world, steps, d=2048):
                          ("ssg_topk_rank_introsort", nn2, "reads D (2*N^2 B); replays numpy's unstable introsort argsort per row (reference tie order, "
                           "default): VALU/latency-bound emulation of a sequential algorithm, listed against the same bytes"),
                          ("ssg_jaccard_rows", nn2, "writes J' (2*N^2 B)"),
+                         ("ssg_jaccard_rows2", nn2, "writes J' (2*N^2 B), every line once, + the sparse copy S of the touched columns (round 4)"),
                          ("ssg_eps_hist", nn2 / 2, "radix-select fallback of the eps rule: reads upper triangle of J' (N^2 B) per level"),
                          ("ssg_eps_compact", nn2 / 2, "radix-select fallback: reads upper triangle of J' (N^2 B)"),
                          ("ssg_eps_compact_below", nn2 / 2, "eps rule, the one full pass of the sampled-threshold path: reads upper triangle of J' (N^2 B)"),
-                         ("ssg_region_query", nn2, "reads J' (2*N^2 B)")):
+                         ("ssg_eps_compact_below_s", nn2 / 2, "eps rule, the one full pass, through the sparse copy S of J' where the threshold lies below the row's floor "
+                          "(dense scan of the other rows): listed against the N^2 B of the upper triangle it replaces"),
+                         ("ssg_region_query", nn2, "reads J' (2*N^2 B)"),
+                         ("ssg_region_query_s", nn2, "region query through the sparse copy S of J' where eps lies below the row's floor (dense scan of the other rows): "
+                          "listed against the 2*N^2 B it replaces")):
         if k in tot:
             n, ms = tot[k]
             gbs = byt * n / (ms * 1e-3) / 1e9
