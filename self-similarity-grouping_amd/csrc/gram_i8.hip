@@ -80,6 +80,41 @@ __device__ __forceinline__ void gi_multiply(const unsigned char* As, const unsig
   }
 }
 
+// ---- round 4: the epilogue's sqrt -> half in integer arithmetic.
+// The reference's value is d2h(sqrt_f64(d2)) with d2 = U * 2^-48 exact (U = the int64 above).  For d2 < 4 that double rounding equals
+// the DIRECT round-to-nearest-even of the exact square root: a half midpoint m is a multiple of 2^-25, m^2 of 2^-50, so unless
+// d2 == m^2 exactly |sqrt(d2) - m| >= 2^-50 / (2 m) > 2^-53 * m -- the float64 rounding of the root cannot reach or cross m.  And the
+// direct rounding needs no square root beyond a candidate: take h = half(sqrtf((float)U * 2^-48)) (within one half ulp of the answer
+// by a wide margin: a relative error of 1e-4 in that root still gives the same result) and compare 4 U with the squares of the two
+// midpoints around h, all in int64 (Mi < 2^27, Mi^2 < 2^54): above the upper midpoint -> h + 1, below the lower -> h - 1, exactly on
+// one -> the even neighbour.  Checked against numpy on 3.6 M values incl. every midpoint square +-3 (tools: DESIGN.md section 9).
+// ~45 integer / float32 instructions instead of ~150 float64 ones (int64 -> float64, sqrt, the branchy direct double -> half).
+__device__ __forceinline__ long long half_units24(unsigned h) {      // value of the non-negative half h in units of 2^-24
+  const unsigned e = h >> 10, m = h & 1023u;
+  return e == 0 ? (long long)m : (long long)((unsigned long long)(1024u | m) << (e - 1));
+}
+__device__ __forceinline__ hbits sqrt_units48_to_half(long long u) {  // 0 <= u < 2^50
+  const float x = (float)u * 3.5527136788005009e-15f;                 // 2^-48: exact scaling, the conversion rounds (candidate only)
+  unsigned h = (unsigned)f2h(__builtin_amdgcn_sqrtf(x));
+  const long long vh = half_units24(h);
+  const long long mu = vh + half_units24(h + 1u), ml = (h ? half_units24(h - 1u) : 0) + vh;
+  const long long x4 = u << 2, mu2 = mu * mu, ml2 = ml * ml;
+  const bool odd = (h & 1u) != 0;
+  const bool inc = x4 > mu2 || (x4 == mu2 && odd);
+  const bool dec = h != 0 && (x4 < ml2 || (x4 == ml2 && odd));
+  return (hbits)(h + (inc ? 1u : 0u) - (dec ? 1u : 0u));
+}
+// max over the 32 lanes of each half-wave (valid in lanes 0 and 32): four DPP steps inside the 16-lane rows + one cross-row exchange
+__device__ __forceinline__ unsigned halfwave_max(unsigned v) {
+  unsigned o;
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); v = v > o ? v : o;     // quad_perm [1,0,3,2]
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false); v = v > o ? v : o;     // quad_perm [2,3,0,1]
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false); v = v > o ? v : o;    // row_ror:4
+  o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false); v = v > o ? v : o;    // row_ror:8
+  o = (unsigned)__shfl_xor((int)v, 16, 64); v = v > o ? v : o;
+  return v;
+}
+
 // D[i,j] = half(half(sqrt(d2))^2) for rows [rowA0, rowA0+M) x all N columns, atomicMax rowmax.  EA = encoded rows of the
 // row block, EB = encoded rows of the whole set.  symmetric: only tiles on/above the diagonal are launched, mirrored on store.
 template <int NL, int KB2>
@@ -207,18 +242,21 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
       for (int w = NACC - 1; w >= 0; w--) dot = dot * 256 + (long long)acc[w][r];
       long long d2i = nA[li] + nj - 2 * dot;           // exact squared distance in units of 2^-48
       if (d2i < 0 || rowA0 + li == gj) d2i = 0;         // cannot be negative; cdist(x, x) diagonal is exactly 0
-      const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
-      const double sq = sqrt(s);
-      const hbits hh = d2h(sq);                         // cdist(...).astype(float16)   rerank.py:61
-      // np.power(half, 2) rerank.py:62; MemorySave branch (:49-59): np.power(cdist, 2).astype(float16), one rounding
-      dd = (symmetric & 2) ? d2h(sq * sq) : h_mul(hh, hh);
+      if (d2i < (1LL << 50) && !(symmetric & 2)) {
+        const hbits hh = sqrt_units48_to_half(d2i);      // == d2h(sqrt((double)d2i * 2^-48)) for d2 < 4: every L2-normalised pair
+        dd = h_mul(hh, hh);                              // np.power(half, 2) rerank.py:62
+      } else {
+        const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
+        const double sq = sqrt(s);
+        const hbits hh = d2h(sq);                         // cdist(...).astype(float16)   rerank.py:61
+        // np.power(half, 2) rerank.py:62; MemorySave branch (:49-59): np.power(cdist, 2).astype(float16), one rounding
+        dd = (symmetric & 2) ? d2h(sq * sq) : h_mul(hh, hh);
+      }
       D[(int64_t)li * N + gj] = (hbits)dd;
       cmax = cmax > dd ? cmax : dd;
     }
     if (mirror) patch[l32 * MP + il] = (hbits)dd;
-    unsigned red = dd;                                  // row maximum over the 32 columns of this half-wave
-#pragma unroll
-    for (int sh = 1; sh < 32; sh <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)red, sh, 64); red = red > o ? red : o; }
+    const unsigned red = halfwave_max(dd);              // row maximum over the 32 columns of this half-wave
     if (l32 == 0 && li < M) atomicMax(&rowmax[li], red);
   }
   if (mirror) {
