@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round-4 closing run: the whole GPU suite, smoke(), and the bench line of the final build (with the CPU baseline and the PMC traffic figure)
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r04z; mkdir -p $O
+cd $R
+timeout 1500 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; tail -4 $O/tests.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+timeout 900 python bench.py --steps 2 --warmup 1 > $O/bench_final.json 2> $O/bench_final.err; tail -2 $O/bench_final.err; cut -c1-300 $O/bench_final.json
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/prof_err.log
+cd $R
+python tools/prof_summary.py $(find gpurun_out/r04z/prof -name "*results.db" | head -1) gpurun_out/r04z/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
