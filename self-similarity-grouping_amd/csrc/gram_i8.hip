@@ -121,7 +121,7 @@ template <int NL, int KB2>
 __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ EA, const int8_t* __restrict__ EB,
                                                          const long long* __restrict__ nA, const long long* __restrict__ nB, int M, int N, int nkb,
                                                          int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric,
-                                                         const int* __restrict__ flag) {
+                                                         const int* __restrict__ flag, int sb) {
   if (*flag) return;     // a feature did not fit NL digits: the caller falls back to the fp64 kernel
   constexpr int BLK = 32 * NL;          // bytes of one k block of one row
   constexpr int SB = KB2 * BLK;         // bytes of one stage row: KB2 consecutive k blocks (one barrier per KB2 * NL^2 MFMAs)
@@ -132,7 +132,24 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * PITCH];
   const int tiles_n = (N + GI_T - 1) / GI_T, tiles_m = (M + GI_T - 1) / GI_T;
   int tm, tn;
-  if (symmetric & 1) {
+  if ((symmetric & 1) && sb > 0) {
+    // round 4: the upper triangle in SUPER-BLOCKS of sb x sb tiles, each XCD working through whole super-blocks.  In the row-major
+    // order below, the ~96 tiles an XCD runs at a time are consecutive columns of ONE tile row: they share the A panel, but every tile
+    // pulls its own B panel (393 KB of digit planes) through the fabric -- 12.6 GB per launch for 98 MB of planes, at the ~4.8 TB/s the
+    // L2 <-> fabric path gives, which is the kernel's time.  The tiles of a super-block need sb A panels + sb B panels, and they walk
+    // k together, so the L2 holds the current window of each: 2 sb panel streams per sb^2 tiles instead of sb^2 + sb.  Measured (PMC
+    // FETCH_SIZE, sb = 10): 12.6 -> 6.5 GB out of the L2s per launch -- and the SAME time within the box-to-box spread (2.6-2.7 ms): the
+    // fabric is not what holds this kernel at 47 % matrix-pipe busy either.
+    const int T = tiles_n, nb = (T + sb - 1) / sb;
+    const int t = xcd_remap((int)blockIdx.x, nb * (nb + 1) / 2 * sb * sb);
+    const int blk = t / (sb * sb), within = t - blk * (sb * sb);
+    int r = (int)(((2.0 * nb + 1.0) - sqrt((2.0 * nb + 1.0) * (2.0 * nb + 1.0) - 8.0 * (double)blk)) * 0.5);
+    while (r > 0 && r * nb - r * (r - 1) / 2 > blk) r--;
+    while ((r + 1) * nb - (r + 1) * r / 2 <= blk) r++;
+    const int c = r + (blk - (r * nb - r * (r - 1) / 2));
+    tm = r * sb + within / sb; tn = c * sb + within % sb;
+    if (tm >= T || tn >= T || tn < tm) return;            // outside the matrix / below the diagonal (diagonal super-blocks only)
+  } else if (symmetric & 1) {
     const int T = tiles_n;
     const int t = xcd_remap((int)blockIdx.x, T * (T + 1) / 2);
     int r = (int)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
@@ -316,12 +333,16 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
   hipLaunchKernelGGL(fill_u32_kernel, dim3((nrows + 255) / 256), dim3(256), 0, stream, rowmax, nrows, 0u);
   const int symmetric = (row0 == 0 && nrows == N) ? 1 : 0;
   const int T = (N + GI_T - 1) / GI_T;
-  const int64_t tiles = symmetric ? (int64_t)T * (T + 1) / 2 : (int64_t)((nrows + GI_T - 1) / GI_T) * T;
+  static int sbv = -1;
+  if (sbv < 0) { const char* e_ = getenv("SSG_I8_SB"); sbv = e_ ? atoi(e_) : 6; if (sbv < 0 || sbv > 64) sbv = 0; }      // super-block edge in tiles (0: row-major order); measured at N = 16 000: 0 / 6 / 8 / 10 / 12 / 16 / 24 -> 2.68 / 2.60 / 2.76 / 2.72 / 2.70 / 2.82 / 3.14 ms
+  const int sb = symmetric ? sbv : 0;
+  const int64_t nbk = sb ? (T + sb - 1) / sb : 0;
+  const int64_t tiles = symmetric ? (sb ? nbk * (nbk + 1) / 2 * sb * sb : (int64_t)T * (T + 1) / 2) : (int64_t)((nrows + GI_T - 1) / GI_T) * T;
   if (tiles > 0x7fffffff) { ssg_set_error("ssg_sqdist_self_i8: too many tiles"); return SSG_ERR_INVALID; }
   const int8_t* e = (const int8_t*)E;
   const int64_t rowbytes = (int64_t)nkb * 32 * ndigits;
 #define SSG_GI_LAUNCH(NL_, KB_) hipLaunchKernelGGL((gram_i8_kernel<NL_, KB_>), dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, \
-    (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric | (memory_save ? 2 : 0), flag)
+    (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric | (memory_save ? 2 : 0), flag, sb)
   static int kb2 = -1;
   if (kb2 < 0) { const char* e_ = getenv("SSG_I8_KB2"); kb2 = e_ ? atoi(e_) : 1; }   // measured: 1 block per stage (3 waves/SIMD) 2.64 ms, 2 blocks (2 waves/SIMD) 2.9 ms at N=16000
   const bool two = kb2 == 2 && (nkb % 2) == 0;     // two k blocks per LDS stage: half the barriers, but 190 VGPRs
