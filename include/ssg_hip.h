@@ -62,7 +62,8 @@ int ssg_sqdist_self_f16(const float* x, const double* norms, int N, int d, int r
  * [-1, 1] (L2-normalised embeddings) feat*2^24 is an integer and scipy's float64 squared distance is exact, so
  * d2*2^48 = |X_i|^2 + |X_j|^2 - 2<X_i,X_j> in int64, with the dot product on v_mfma_i32_32x32x32_i8 over ndigits balanced
  * radix-256 digits (3: |feat| <= 0.498, 9 digit products; 4: |feat| <= 1, 16), gives the identical value.
- * ssg_gram_i8_encode writes the digits (ssg_gram_i8_encoded_bytes bytes) and the exact int64 norms and sets *flag when a
+ * ssg_gram_i8_encode writes the digits (ssg_gram_i8_encoded_bytes bytes: whole 64-row panels, layout [row / 64][k block][row % 64]
+ * [digit][32] since round 4 -- opaque to the caller, consumed by ssg_sqdist_self_i8 only) and the exact int64 norms and sets *flag when a
  * feature does not fit (caller zeroes *flag first and falls back to ssg_sqdist_self_f16 when it is set;
  * ssg_sqdist_self_i8 itself does nothing in that case).  d <= 16384. */
 size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits);

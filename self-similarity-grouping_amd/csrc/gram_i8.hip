@@ -29,8 +29,11 @@ constexpr int GI_T = 64;          // workgroup tile (4 waves, 32x32 outputs each
                                   // 128x128 tiles with 16 waves 2.7-2.9 ms, super-block tile order for L2 locality 2.8 ms,
                                   // two k blocks per stage 2.9 ms -- the kernel sits at 46 % MFMA busy either way
 
-// One wave per row: digits of feat*2^24 for every 32-wide k block, laid out [row][k block][digit][32 k] (32*NL bytes per
-// block: the layout both the global tile loads and the LDS fragment reads use), and the exact squared norm.
+// One wave per row: digits of feat*2^24 for every 32-wide k block, and the exact squared norm.  Layout (round 4): PANEL-major,
+// [row / 64][k block][row % 64][digit][32 k]: the 64 rows x 32 NL bytes a tile stages per k block are ONE contiguous 6 KB piece (NL = 3)
+// instead of 64 pieces of 96 bytes that are 6 KB apart and straddle 128-byte lines -- the texture addresser works through a wave's
+// load line by line, and with the row-major layout the global -> register staging alone cost 0.7 of the kernel's 2.7 ms (ablation:
+// tools/micro/gram_prof.hip with / without the loads).  Rows beyond n in the last panel are never written: the tile loads clamp to row n - 1.
 template <int NL>
 __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __restrict__ X, int n, int d, int nkb, int8_t* __restrict__ E,
                                                              long long* __restrict__ norms, int* __restrict__ flag) {
@@ -38,7 +41,8 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
   if (row >= n) return;
   const int lane = lane_id();
   const float* x = X + (int64_t)row * d;
-  int8_t* e = E + (int64_t)row * nkb * (32 * NL);
+  // panel-major: [row / 64][k block][row % 64][digit][32 k] (see gram_i8_kernel: a tile's stage is one contiguous 64 x 32 NL byte block)
+  int8_t* e = E + ((int64_t)(row / GI_T) * nkb * GI_T + (row % GI_T)) * (32 * NL);
   long long acc = 0;
   bool bad = false;
   for (int k0 = 0; k0 < nkb * 32; k0 += 64) {
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
     if (!(fabsf(v) <= 1.0f)) bad = true;                    // also catches NaN
     const int q = bad ? 0 : (int)(v * 16777216.0f);         // exact: half values <= 1 are multiples of 2^-24
     acc += (long long)q * (long long)q;
-    int8_t* p = e + (int64_t)(k >> 5) * (32 * NL) + (k & 31);
+    int8_t* p = e + (int64_t)(k >> 5) * (GI_T * 32 * NL) + (k & 31);
     int r = q;
 #pragma unroll
     for (int L = 0; L < NL; L++) {
@@ -168,8 +172,10 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
 #pragma unroll
   for (int p = 0; p < NCH; p++) {
     const int c = tid + 256 * p, mat = c / (GI_T * CPR), rem = c - mat * (GI_T * CPR), row = rem / CPR, ch = rem - row * CPR;
-    const int grow = mat ? min(tn * GI_T + row, N - 1) : min(tm * GI_T + row, M - 1);
-    gp[p] = reinterpret_cast<const uint4*>((mat ? EB : EA) + (int64_t)grow * nkb * BLK) + ch;
+    // global row of the whole set (A rows: the row block starts at rowA0; E is the ONE encoded table of all N rows, panel-major)
+    const int grow = mat ? min(tn * GI_T + row, N - 1) : rowA0 + min(tm * GI_T + row, M - 1);
+    constexpr int CPB = BLK / 16;                      // 16-byte chunks of one k block of one row; chunk ch of the stage row sits in k block ch / CPB
+    gp[p] = reinterpret_cast<const uint4*>(EB + ((int64_t)(grow / GI_T) * nkb * GI_T + (grow % GI_T)) * BLK) + (ch / CPB) * (GI_T * CPB) + ch % CPB;
     lo[p] = mat * (GI_T * PITCH) + row * PITCH + ch * 16;
   }
   v16i acc[NACC];
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
   pa0 = pa1 = pa2 = pa3 = pa4 = pa5 = pb0 = pb1 = pb2 = pb3 = pb4 = pb5 = make_uint4(0, 0, 0, 0);
 #define SSG_GL(S, ST)                                                                                 \
   {                                                                                                   \
-    const int so_ = (ST) * CPR;                                                                       \
+    const int so_ = (ST) * (GI_T * CPR);            /* a stage = KB2 k blocks of the panel, 64 rows each */ \
     p##S##0 = gp[0][so_]; if (NCH > 1) p##S##1 = gp[1][so_]; if (NCH > 2) p##S##2 = gp[2][so_];         \
     if (NCH > 3) p##S##3 = gp[3][so_]; if (NCH > 4) p##S##4 = gp[4][so_]; if (NCH > 5) p##S##5 = gp[5][so_]; \
   }
@@ -308,7 +314,9 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
 
 using namespace ssg;
 
-extern "C" size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits) { return (size_t)n * (size_t)((d + 31) / 32) * 32 * (size_t)ndigits; }
+extern "C" size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits) {       // whole 64-row panels
+  return (size_t)((n + GI_T - 1) / GI_T * GI_T) * (size_t)((d + 31) / 32) * 32 * (size_t)ndigits;
+}
 
 // Digits + exact squared norms of n rows.  ndigits = 3 (|feat| <= 0.498) or 4 (|feat| <= 1); *flag |= 1 when a half-rounded
 // feature does not fit.  E: ssg_gram_i8_encoded_bytes(n, d, ndigits) bytes, norms: n int64.  The caller zeroes *flag first.
@@ -340,8 +348,7 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
   const int64_t tiles = symmetric ? (sb ? nbk * (nbk + 1) / 2 * sb * sb : (int64_t)T * (T + 1) / 2) : (int64_t)((nrows + GI_T - 1) / GI_T) * T;
   if (tiles > 0x7fffffff) { ssg_set_error("ssg_sqdist_self_i8: too many tiles"); return SSG_ERR_INVALID; }
   const int8_t* e = (const int8_t*)E;
-  const int64_t rowbytes = (int64_t)nkb * 32 * ndigits;
-#define SSG_GI_LAUNCH(NL_, KB_) hipLaunchKernelGGL((gram_i8_kernel<NL_, KB_>), dim3((unsigned)tiles), dim3(256), 0, stream, e + row0 * rowbytes, e, \
+#define SSG_GI_LAUNCH(NL_, KB_) hipLaunchKernelGGL((gram_i8_kernel<NL_, KB_>), dim3((unsigned)tiles), dim3(256), 0, stream, e, e, \
     (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric | (memory_save ? 2 : 0), flag, sb)
   static int kb2 = -1;
   if (kb2 < 0) { const char* e_ = getenv("SSG_I8_KB2"); kb2 = e_ ? atoi(e_) : 1; }   // measured: 1 block per stage (3 waves/SIMD) 2.64 ms, 2 blocks (2 waves/SIMD) 2.9 ms at N=16000

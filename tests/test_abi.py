@@ -50,7 +50,7 @@ def test_argument_validation_without_gpu():
     assert L.ssg_gram_i8_encode(None, 4, 64, 5, None, None, None, None) == -1                                             # digits must be 3 or 4
     assert L.ssg_gram_i8_encode(None, 4, 20000, 3, None, None, None, None) == -1                                          # d > 16384 (int32 headroom)
     assert L.ssg_sqdist_self_i8(None, None, 8, 64, 3, 4, 8, 0, None, None, None, None) == -1                                 # row block outside N
-    assert L.ssg_gram_i8_encoded_bytes(10, 70, 3) == 10 * 3 * 32 * 3                                                      # 3 k blocks of 32, 3 digits
+    assert L.ssg_gram_i8_encoded_bytes(10, 70, 3) == 64 * 3 * 32 * 3                                                      # one 64-row panel, 3 k blocks of 32, 3 digits
     assert L.ssg_source_rowmin_filtered(None, None, 8, 100, 100, 64, 1e-3, 0.0, 0.0, None, None, None) == -1              # Ns_pad % 128
     assert L.ssg_rank_metrics(None, 4, 10, 8, None, None, None, None, 0, None, None, None, None) == -1                     # ld < n
     assert L.ssg_knn_sets(None, None, 10, 0, 10, 11, 64, None, None, None, None, None) == -1                              # K > N
