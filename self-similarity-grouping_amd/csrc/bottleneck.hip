@@ -68,7 +68,10 @@ struct Cfg {
 #ifndef SSG_BN_K1T
 #define SSG_BN_K1T 32
 #endif
-  static constexpr int K1T = NW == 8 ? SSG_BN_K1T : 16, KS1 = K1T / 16, CPR1 = 4 * KS1, RPP1 = NTHR / CPR1;
+#ifndef SSG_BN_K1T4
+#define SSG_BN_K1T4 32               // round 4: whole 128-byte lines per pixel row and k-tile for the 4-wave layer1 kernel too (16: 64-byte pieces,
+#endif                               // two texture-addresser line accesses per useful line): identity blocks 1.59 -> 1.53 ms, bit-identical
+  static constexpr int K1T = NW == 8 ? SSG_BN_K1T : SSG_BN_K1T4, KS1 = K1T / 16, CPR1 = 4 * KS1, RPP1 = NTHR / CPR1;
   static constexpr int XROWS = (NPIX1 + RPP1 - 1) / RPP1 * RPP1;   // x rows of a phase-1 stage, padded to whole passes (the padding loads return zeros)
   static constexpr int P1 = 80;                        // LDS pitch of a 64-byte k-tile row (pitch/16 odd: conflict-free b128)
   static constexpr int P1T = K1T * 4 + 16;             // ... of a phase-1 row (80 or 144 bytes)
