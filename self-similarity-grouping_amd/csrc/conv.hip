@@ -1189,7 +1189,16 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
   if (row >= rows) return;
   const int lane = lane_id();
   float s = 0.f;
-  for (int c = lane; c < d; c += 64) { const float v = x[(int64_t)row * d + c]; s += v * v; }
+  const float* xr = x + (int64_t)row * d;
+  // (the summation order -- lane c % 64 takes columns c, c + 64, ... in order, then the xor tree -- is part of the contract: the bound pass's
+  // tolerance and the float32 distance epilogues were derived for it; only the loads are batched, eight per lane in flight)
+  for (int c0 = lane; c0 < d; c0 += 512) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = xr[min(c0 + 64 * u, d - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (c0 + 64 * u < d) s += v[u] * v[u];
+  }
   for (int sh = 1; sh < 64; sh <<= 1) s += __shfl_xor(s, sh, 64);
   if (lane == 0) out[row] = s * scale;
 }
@@ -1231,125 +1240,6 @@ extern "C" int ssg_cosine_dist_f32(const float* x, const float* y, int m, int n,
   return (n % 128 == 0) ? launch_conv<128, 128, 64, 64, false>(p, stream) : launch_conv<128, 64, 64, 32, false>(p, stream);
 }
 
-namespace ssg {
-// Exact refinement of the source-term minimum: one wave per target row.  Granules (8 sources) whose float32
-// lower-bounded minimum can still beat the row's best are re-evaluated in float64 with the difference form
-// sum_k (x_k - y_k)^2 (like cdist), then half(sqrt(s)^2) as in reid/rerank.py:36-37.
-__global__ __launch_bounds__(256) void source_refine_kernel(const float* __restrict__ tgt, const float* __restrict__ src, const float* __restrict__ tilemin,
-                                                            int ld, int ngran, float tol, int nrows, int Ns, int d, unsigned* __restrict__ rowmin) {
-  const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-  if (row >= nrows) return;
-  const int lane = lane_id();
-  float gmin = INFINITY;
-  for (int t = lane; t < ngran; t += 64) gmin = fminf(gmin, tilemin[(int64_t)row * ld + t]);
-  for (int sh = 1; sh < 64; sh <<= 1) gmin = fminf(gmin, __shfl_xor(gmin, sh, 64));
-  const float bound = gmin + tol;
-  const float* x = tgt + (int64_t)row * d;
-  unsigned best = 0xffffffffu;
-  for (int t0 = 0; t0 < ngran; t0 += 64) {
-    const int t = t0 + lane;
-    uint64_t cand = __ballot(t < ngran && tilemin[(int64_t)row * ld + t] <= bound);
-    while (cand) {
-      const int tt = t0 + __ffsll((long long)cand) - 1;
-      cand &= cand - 1;
-      // 8 sources of the granule: lane group g = lane>>3 takes source tt*8+g, its 8 lanes split k
-      const int sidx = tt * 8 + (lane >> 3);
-      double acc = 0.0;
-      if (sidx < Ns) {
-        const float* y = src + (int64_t)sidx * d;
-        for (int k = (lane & 7) * 4; k < d; k += 32) {
-          const float4 xv = *reinterpret_cast<const float4*>(x + k), yv = *reinterpret_cast<const float4*>(y + k);
-          const double d0 = (double)xv.x - (double)yv.x, d1 = (double)xv.y - (double)yv.y, d2 = (double)xv.z - (double)yv.z, d3 = (double)xv.w - (double)yv.w;
-          acc += d0 * d0; acc += d1 * d1; acc += d2 * d2; acc += d3 * d3;
-        }
-      }
-      for (int sh = 1; sh < 8; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
-      if (sidx < Ns) {
-        const double dist = sqrt(acc);
-        const unsigned hb = d2h(dist * dist);     // np.power(cdist, 2).astype(float16)
-        best = best < hb ? best : hb;
-      }
-    }
-  }
-  for (int sh = 1; sh < 64; sh <<= 1) { const unsigned o = (unsigned)__shfl_xor((int)best, sh, 64); best = best < o ? best : o; }
-  if (lane == 0) rowmin[row] = best;
-}
-}  // namespace ssg
-
-// Source-term row minimum (reid/rerank.py:36-37,39) by filter-and-refine: a float32 MFMA pass bounds every
-// target-source distance (per row and 8-source granule), a float64 pass re-evaluates only the granules within `tol`
-// of the row's bound.  Same result as ssg_source_rowmin_f16 (exact min of the half-rounded float64 distances)
-// whenever tol >= the float32 error of the bound (callers pass 8*d*2^-24*max|x|*max|y| + margin).
-// tgt [nrows,d], src [Ns_pad,d] (rows >= Ns are padding), d % 32 == 0, Ns_pad % 128 == 0.
-// ws: nrows + Ns_pad + nrows*(Ns_pad/8) floats, plus (nrows + Ns_pad)*d floats when scale_t, scale_s > 0: the bound
-// pass then runs on the fp16 matrix cores over split-half copies of tgt*scale_t and src*scale_s (powers of two that
-// keep max|x|*scale < 65504); the caller's tol must cover that pass's error (3 products, 3d-term accumulation).
-static int source_rowmin_filtered_impl(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
-                                       int one_product, float* ws, uint32_t* rowmin, hipStream_t stream) {
-  if (nrows <= 0 || Ns <= 0 || Ns_pad < Ns || (Ns_pad % 128) || (d % 32) || (int64_t)nrows * d * 4 > 0x7fffffffLL) {
-    ssg_set_error("ssg_source_rowmin_filtered: bad shape nrows=%d Ns=%d Ns_pad=%d d=%d", nrows, Ns, Ns_pad, d);
-    return SSG_ERR_INVALID;
-  }
-  float* rowterm = ws; float* colterm = ws + nrows; float* tilemin = colterm + Ns_pad;
-  const int ntiles = Ns_pad / 8;   // 8-source granules
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
-  if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
-  const bool split = scale_t > 0.f && scale_s > 0.f;
-  if (split && one_product && (Ns_pad % 128) == 0 && (d % sbound::BK) == 0) {
-    // bound pass as a plain fp16 GEMM on half copies of the scaled operands (source_bound.hip): 2 bytes per element, 1 product
-    uintptr_t a = (uintptr_t)(tilemin + (int64_t)nrows * ntiles); a = (a + 15) & ~(uintptr_t)15;
-    _Float16* x16 = (_Float16*)a; _Float16* y16 = x16 + (int64_t)nrows * d;
-    hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, tgt, x16, (int64_t)nrows * d / 4, scale_t);
-    hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, src, y16, (int64_t)Ns_pad * d / 4, scale_s);
-    static int sb_dma = -1;                 // SSG_SB_DMA=0: the register-staged 128 x 128 kernel
-    if (sb_dma < 0) { const char* e = getenv("SSG_SB_DMA"); sb_dma = e ? atoi(e) : 1; }
-    if (sb_dma && (int64_t)nrows * d * 2 < 0x7fffffffLL && (int64_t)Ns_pad * d * 2 < 0x7fffffffLL) {     // (operands go through 2 GiB buffer resources)
-      const int tiles = ((nrows + sbound::TB - 1) / sbound::TB) * ((Ns_pad + sbound::TB - 1) / sbound::TB);
-      hipLaunchKernelGGL(sbound::source_bound_dma_kernel, dim3(tiles), dim3(512), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
-                         1.f / (scale_t * scale_s), tilemin, ntiles);
-    } else {
-      const int tiles = ((nrows + sbound::BM - 1) / sbound::BM) * (Ns_pad / sbound::BN);
-      hipLaunchKernelGGL(sbound::source_bound_kernel, dim3(tiles), dim3(256), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
-                         1.f / (scale_t * scale_s), tilemin, ntiles);
-    }
-    hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
-    SSG_LAUNCH_CHECK("source_bound / source_refine kernels");
-    return SSG_OK;
-  }
-  const float* gt = tgt; const float* gs = src;
-  if (split) {   // bound pass on the fp16 matrix cores: split-half copies of both operand sets (scaled into the half range)
-    float* ts = tilemin + (int64_t)nrows * ntiles; float* ss = ts + (int64_t)nrows * d;
-    hipLaunchKernelGGL(h8l8_encode_kernel, dim3(4096), dim3(256), 0, stream, tgt, ts, (int64_t)nrows * d / 8, scale_t);
-    hipLaunchKernelGGL(h8l8_encode_kernel, dim3(4096), dim3(256), 0, stream, src, ss, (int64_t)Ns_pad * d / 8, scale_s);
-    gt = ts; gs = ss;
-  }
-  ConvParams p;
-  p.in = gt; p.w = gs; p.bias = colterm; p.res = nullptr; p.out = nullptr;
-  p.B = nrows; p.H = 1; p.W = 1; p.Cin = d; p.Cout = Ns_pad; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.relu = 0; p.OH = 1; p.OW = 1;
-  p.M = nrows; p.Kpad = d; p.nk1 = d / 16; p.variant = 0; p.in_bytes = (unsigned)((int64_t)nrows * d * 4);
-  p.in2 = nullptr; p.H2 = p.W2 = p.Cin2 = 0; p.stride2 = 1; p.in2_bytes = 0; p.rowterm = rowterm; p.epi = 3; p.tilemin = tilemin; p.tmin_ld = ntiles; p.out_split = p.res_split = 0;
-  p.acc_scale = split ? 1.f / (scale_t * scale_s) : 1.f;
-  // 128x256 tiles when the padded source count allows: 3/4 of the global->LDS bytes of the 128x128 tile
-  int rc = split ? ((Ns_pad % 256) == 0 ? launch_conv_wide(p, stream) : launch_conv_bk<128, 128, 64, 64, false, 32, true>(p, stream))
-                 : launch_conv<128, 128, 64, 64, false>(p, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
-  SSG_LAUNCH_CHECK("source_refine_kernel");
-  return SSG_OK;
-}
-
-extern "C" int ssg_source_rowmin_filtered(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
-                                          float* ws, uint32_t* rowmin, hipStream_t stream) {
-  return source_rowmin_filtered_impl(tgt, src, nrows, Ns, Ns_pad, d, tol, scale_t, scale_s, 0, ws, rowmin, stream);
-}
-// the same with the bound pass on the hi halves only (one fp16 product per term instead of three: 1/3 of the matrix work); the
-// caller's tol must cover 2^-10 |x||y| per dot product on top of the accumulation error.  Needs scale_t, scale_s > 0 and
-// Ns_pad % 256 == 0, otherwise it runs the three-product pass.
-extern "C" int ssg_source_rowmin_filtered1(const float* tgt, const float* src, int nrows, int Ns, int Ns_pad, int d, float tol, float scale_t, float scale_s,
-                                           float* ws, uint32_t* rowmin, hipStream_t stream) {
-  return source_rowmin_filtered_impl(tgt, src, nrows, Ns, Ns_pad, d, tol, scale_t, scale_s, 1, ws, rowmin, stream);
-}
 
 extern "C" int ssg_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, int flip, hipStream_t stream) {
   if (B <= 0 || H <= 0 || W <= 0) { ssg_set_error("ssg_nchw_to_nhwc4: empty"); return SSG_ERR_INVALID; }
