@@ -1,11 +1,15 @@
 #!/bin/bash
-# Round-4 closing run: the whole GPU suite, smoke(), and the bench line of the final build (with the CPU baseline and the PMC traffic figure)
+# Round-4 closing run (through gpurun): PMC traffic of the embedding (the source of roofline.traffic, tied to the embedding sources by
+# their fingerprint), the bench line of the final build with the CPU baseline, its rocprofv3 kernel stats, the per-launch layer table.
+# The whole GPU suite + smoke() run first when FULL=1.
 set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r04z; mkdir -p $O
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; tail -4 $O/tests.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+if [ "$FULL" = "1" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q > $O/tests.log 2>&1; tail -4 $O/tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
+fi
 timeout 600 bash tools/pmc_embed.sh > $O/pmc_embed.log 2>&1; tail -2 $O/pmc_embed.log; cp $R/gpurun_out/r04_pmc_conv_traffic.json $R/gpurun_out/r04_pmc_conv_traffic.md $R/profiles/
 timeout 900 python bench.py --steps 2 --warmup 1 > $O/bench_final.json 2> $O/bench_final.err; tail -2 $O/bench_final.err; cut -c1-300 $O/bench_final.json
 cd /tmp && export TMPDIR=/tmp
