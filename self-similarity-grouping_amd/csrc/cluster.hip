@@ -213,6 +213,23 @@ struct WaveStage {
   }
 };
 
+// Final flush of a workgroup's four wave stages with ONE cursor atomic (the sparse passes end with a few dozen staged entries per wave:
+// a returning atomic per wave on one word -- ~90 per us -- was their whole run time, 5120 waves = 57 us).  Every thread of the block calls it.
+template <typename T>
+__device__ __forceinline__ void block_flush(WaveStage<T>& st, T* __restrict__ out, unsigned long long cap, unsigned long long* __restrict__ cursor) {
+  __shared__ unsigned long long bf_base;
+  __shared__ int bf_n[4];
+  const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+  if (lane == 0) bf_n[wave] = st.n;
+  __syncthreads();
+  if (threadIdx.x == 0) { const int tot = bf_n[0] + bf_n[1] + bf_n[2] + bf_n[3]; bf_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull; }
+  __syncthreads();
+  unsigned long long basep = bf_base;
+  for (int w = 0; w < wave; w++) basep += (unsigned long long)bf_n[w];
+  for (int x = lane; x < st.n; x += 64) if (basep + x < cap) out[basep + x] = st.buf[x];
+  st.n = 0;
+}
+
 // append every strict-upper non-zero key <= key_max to buf
 template <int MODE>
 __global__ __launch_bounds__(256) void eps_compact_kernel(MatView mv, unsigned long long key_max, unsigned long long* __restrict__ buf,
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void eps_compact_kernel(MatView mv, unsigned l
       }
     }
   }
-  st.flush(buf, cap, cursor, lane);
+  block_flush(st, buf, cap, cursor);
 }
 
 // ------------------------------------------------------------------ K10, fast path: sampled threshold + ONE full pass
@@ -558,7 +575,7 @@ __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const 
     }
     for (int c = c0; c < rs.nchunks; c++) generic_chunk(rs, c, gi, vi, nullptr);
   }
-  st.flush(buf, cap, cursor, lane);
+  block_flush(st, buf, cap, cursor);
   for (int sh = 1; sh < 64; sh <<= 1) zeros += (unsigned long long)__shfl_xor((long long)zeros, sh, 64);
   if (lane == 0 && zeros) atomicAdd(&cursor[1], zeros);
 }
@@ -805,7 +822,7 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
     }
     if (lane == 0) cnt[il] = rowcnt;
   }
-  st.flush(eout, cap, cursor, lane);
+  block_flush(st, eout, cap, cursor);
 }
 
 // ------------------------------------------------------------------ round 4: the sparse copy S of J' (jaccard.hip, second generation)
@@ -816,6 +833,7 @@ __global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double ep
 // row i -- a few hundred entries instead of N.  The decision is taken PER ROW on the device: rows whose floor is too low (and all
 // rows when S is incomplete) are flagged in a row mask and done by the dense pass queued behind the sparse one.
 constexpr int SBATCH = 4;
+constexpr int SPARSE_STAGE = 256;        // per-wave staging entries of the sparse passes (a row yields a handful of keys / edges)
 struct SparseView {
   const uint32_t* pool; const int64_t* seg_off; const int32_t* seg_len; int nseg;
   const unsigned long long* s_cursor;      // [1] != 0: a segment did not fit, S is unusable
@@ -835,7 +853,7 @@ __device__ __forceinline__ bool sparse_usable(const SparseView& sv, const MatVie
 __global__ __launch_bounds__(256) void eps_compact_sparse_kernel(MatView mv, SparseView sv, const unsigned long long* __restrict__ thr3,
                                                                  unsigned long long* __restrict__ buf, unsigned long long cap,
                                                                  unsigned long long* __restrict__ cursor, unsigned char* __restrict__ rowmask) {
-  __shared__ unsigned long long sbuf[4][STAGE_CAP];
+  __shared__ unsigned long long sbuf[4][SPARSE_STAGE];
   const int lane = lane_id();
   const float thr = __uint_as_float((unsigned)thr3[0]);
   const bool usable = thr > 0.f && sparse_usable(sv, mv);
@@ -879,13 +897,13 @@ __global__ __launch_bounds__(256) void eps_compact_sparse_kernel(MatView mv, Spa
           if (bm) {
             if (key != ~0ULL) st.buf[st.n + __popcll(bm & lanemask_lt())] = key;
             st.n += __popcll(bm);
-            if (st.n > STAGE_CAP - 64) st.flush(buf, cap, cursor, lane);
+            if (st.n > SPARSE_STAGE - 64) st.flush(buf, cap, cursor, lane);
           }
         }
       }
     }
   }
-  st.flush(buf, cap, cursor, lane);
+  block_flush(st, buf, cap, cursor);
   for (int sh = 1; sh < 64; sh <<= 1) zeros += (unsigned long long)__shfl_xor((long long)zeros, sh, 64);
   if (lane == 0 && zeros) atomicAdd(&cursor[1], zeros);
   if (lane == 0 && anydense) cursor[2] = 1ull;
@@ -896,7 +914,7 @@ __global__ __launch_bounds__(256) void eps_compact_sparse_kernel(MatView mv, Spa
 __global__ __launch_bounds__(256) void region_query_sparse_kernel(MatView mv, SparseView sv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
                                                                   unsigned long long cap, unsigned long long* __restrict__ cursor,
                                                                   unsigned char* __restrict__ rowmask) {
-  __shared__ Edge sbuf[4][STAGE_CAP];
+  __shared__ Edge sbuf[4][SPARSE_STAGE];
   const int lane = lane_id();
   WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
   Edge* eout = reinterpret_cast<Edge*>(edges);
@@ -929,14 +947,14 @@ __global__ __launch_bounds__(256) void region_query_sparse_kernel(MatView mv, Sp
           if (bm) {
             if (hit) { Edge ed; ed.i = gi; ed.k = k; st.buf[st.n + __popcll(bm & lanemask_lt())] = ed; }
             st.n += __popcll(bm); rowcnt += __popcll(bm);
-            if (st.n > STAGE_CAP - 64) st.flush(eout, cap, cursor, lane);
+            if (st.n > SPARSE_STAGE - 64) st.flush(eout, cap, cursor, lane);
           }
         }
       }
     }
     if (lane == 0) cnt[il] = rowcnt;
   }
-  st.flush(eout, cap, cursor, lane);
+  block_flush(st, eout, cap, cursor);
   if (lane == 0 && anydense) cursor[1] = 1ull;
 }
 
