@@ -809,6 +809,58 @@ def test_jaccard_second_generation_and_sparse_copy(dev, ora, monkeypatch):
         del h1, h2, h3
 
 
+def test_sparse_passes_mixed_rows_equal_dense(dev):
+    """round 4: the per-row decision of the sparse passes.  With a bound in the MIDDLE of the rows' floors J'(0) + lambda * half(v_i + min v)
+    about half of the rows are walked through the sparse copy S and the others are flagged for the dense pass queued behind: the eps
+    compaction (same key multiset, same zero count) and the region query (same neighbour counts, same edge set) must equal the dense
+    passes alone, for a bound below every floor (all rows sparse), in the middle (mixed) and above every floor (all rows dense)."""
+    from ssg_amd import rerank, _lib
+    from ssg_amd._lib import check, ptr, stream
+    L = _lib.lib(); st = stream()
+    tgt = hard_clustered(3000, 96, 21); src = hard_clustered(800, 96, 22, intra=0.7)
+    lam = 0.3
+    h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), lambda_value=lam)
+    sp = h.sparse
+    assert sp is not None and h.sparse_ok
+    N = h.N
+    v = h.v.cpu().numpy(); jp0 = np.uint16(sp["jp0"]).view(np.float16)
+    floors = jp0.astype(np.float64) + (v + v.min()).astype(np.float16).astype(np.float64) * lam        # f64(J'(0)) + f64(half(v_i + vmin)) * lambda
+    assert floors.max() > floors.min()
+    for name, bound in (("all sparse", float(floors.min()) * 0.98), ("mixed", float(np.median(floors))), ("all dense", float(floors.max()) * 1.02)):
+        # ---- eps compaction with a hand-made threshold
+        thr3 = torch.zeros(5, dtype=torch.int64, device=dev); thr3[0] = int(np.float32(bound).view(np.uint32))
+        cap = 1 << 23
+        outs = []
+        for sparse in (True, False):
+            buf = torch.empty(cap, dtype=torch.int64, device=dev); cur = torch.zeros(3, dtype=torch.int64, device=dev)
+            if sparse:
+                check(L.ssg_eps_compact_below_s(ptr(h.M), ptr(h.v), N, 0, N, lam, ptr(thr3), ptr(buf), cap, ptr(cur), ptr(sp["pool"]), ptr(sp["seg_off"]),
+                                                ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), st), "s")
+                ndense = int(sp["rowmask"].sum().item())
+            else:
+                check(L.ssg_eps_compact_below(ptr(h.M), ptr(h.v), N, 0, N, 0, lam, ptr(thr3), ptr(buf), cap, ptr(cur), st), "d")
+            got, zeros = int(cur[0].item()), int(cur[1].item())
+            assert got <= cap
+            outs.append((np.sort(buf[:got].cpu().numpy()), zeros))
+        assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1], name
+        assert (ndense == 0) if name == "all sparse" else (ndense == N) if name == "all dense" else (0 < ndense < N), (name, ndense)
+        # ---- region query with eps = the same bound
+        res = []
+        for sparse in (True, False):
+            ecap = 1 << 23
+            cnt = torch.empty(N, dtype=torch.int32, device=dev); edges = torch.empty((ecap, 2), dtype=torch.int32, device=dev); cur = torch.zeros(2, dtype=torch.int64, device=dev)
+            if sparse:
+                check(L.ssg_region_query_s(ptr(h.M), ptr(h.v), N, 0, N, lam, bound, ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]),
+                                           ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), ptr(cnt), ptr(edges), ecap, ptr(cur), st), "s")
+            else:
+                check(L.ssg_region_query(ptr(h.M), ptr(h.v), N, 0, N, 0, lam, bound, ptr(cnt), ptr(edges), ecap, ptr(cur), st), "d")
+            ne = int(cur[0].item())
+            assert ne <= ecap
+            e = edges[:ne].cpu().numpy().astype(np.int64)
+            res.append((cnt.cpu().numpy(), np.sort(e[:, 0] * N + e[:, 1])))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), name
+
+
 def test_pairwise_distance_dropin(dev):
     """reid/evaluators.py:63-85 (float32): both branches vs the torch CPU formula; 2e-5 absolute
     on distances of unit-norm features (fp32 GEMM accumulation order)."""
