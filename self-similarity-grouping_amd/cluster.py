@@ -108,7 +108,9 @@ def _eps_rule_sampled(L, h, rho, st):
         # and the block lengths of the candidate gather -- no all-reduce + read, no separate size exchange
         import torch.distributed as dist
         table = gather_rows(local.view(1, -1), h.group).tolist()                                                # host round trip 1
-        vals = table[dist.get_rank(h.group)]
+        vals = list(table[dist.get_rank(h.group)])
+        if npend >= 2:
+            vals[4] = max(int(r[4]) for r in table)      # a digit overflow on ANY rank raises on every rank (no rank left waiting in a collective)
         gots = [int(r[0]) for r in table]
         zeros_all, got_all, overflow = sum(int(r[1]) for r in table), sum(gots), int(any(g > n_cap for g in gots))
     else:
