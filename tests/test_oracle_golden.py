@@ -325,6 +325,58 @@ def test_jpeg_native_parser_matches_python(golden):
     assert pj._parse_batch_native([]).kept == []
 
 
+def test_jpeg_kernel_text_executed_on_host_matches_pillow(golden, tmp_path):
+    """The three kernels of csrc/jpeg.hip use no wave-level operation, so their SOURCE TEXT -- cut from the file, `__global__` /
+    `__device__` mapped to host functions (tools/fuzz/jpeg_device_fuzz.cpp, the libFuzzer harness built as a plain decoder, with ASan)
+    -- runs thread by thread on the CPU: native parser -> Huffman -> IDCT -> colour on exactly-sized buffers must give Pillow's bytes
+    for the committed files and for fresh ones (all chroma layouts, odd sizes, restart intervals, optimised tables); progressive files
+    are refused by the parser (exit 3).  A CPU-side pin of the device code; the `-m gpu` tests run the same text on the GPU."""
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("ROCm clang++ not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "self-similarity-grouping_amd", "csrc", "jpeg.hip")
+    inc = tmp_path / "inc"; inc.mkdir()
+    text, on = [], False
+    for line in open(src):
+        if line.startswith("namespace ssg {"):
+            on = True
+        if line.startswith("using namespace ssg;"):
+            break
+        if on:
+            text.append(line)
+    assert any("colour_kernel" in ln for ln in text) and any("huffman_kernel" in ln for ln in text)
+    (inc / "jpeg_kernels_cut.inc").write_text("".join(text))
+    exe = str(tmp_path / "jpeg_device_host")
+    r = subprocess.run([clang, "-x", "hip", "--offload-host-only", "-O1", "-DFZ_MAIN", "-fsanitize=address", "-Wno-option-ignored", "-I/opt/rocm/include",
+                        "-I" + str(inc), "-o", exe, os.path.join(root, "tools", "fuzz", "jpeg_device_fuzz.cpp"), "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def run(data):
+        fin, fout = tmp_path / "in.jpg", tmp_path / "out.rgb"
+        fin.write_bytes(data)
+        rc = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True)
+        assert rc.returncode in (0, 3, 4), rc.stderr[-2000:]          # anything else = a sanitizer report
+        return rc.returncode, (np.fromfile(str(fout), np.uint8) if rc.returncode == 0 else None)
+
+    g = golden("jpeg_cases.npz")
+    for i in range(int(g["count"])):
+        rc, px = run(g["file_%02d" % i].tobytes())
+        assert rc == 0 and np.array_equal(px.reshape(g["rgb_%02d" % i].shape), g["rgb_%02d" % i]), i
+    assert run(g["progressive_file"].tobytes())[0] == 3
+    rng = np.random.default_rng(11)
+    for h, w in ((16, 16), (23, 41), (9, 70), (128, 64)):
+        for ss in (0, 1, 2):
+            for extra in ({}, {"restart_marker_blocks": 2}, {"optimize": True}):
+                data, ref = _random_jpeg(rng, h, w, int(rng.integers(0, 2)), quality=int(rng.integers(30, 96)), subsampling=ss, **extra)
+                rc, px = run(data)
+                assert rc == 0 and np.array_equal(px.reshape(ref.shape), ref), (h, w, ss, extra)
+    # damaged entropy-coded data: decoded without a sanitizer report; a short segment is flagged (exit 4) like on the GPU
+    data, _ = _random_jpeg(rng, 64, 48, 1, quality=80)
+    assert run(data[:len(data) // 2] + b"\xff\xd9")[0] in (3, 4)
+
+
 def test_jpeg_host_parser_hands_malformed_files_to_pillow(golden):
     """a short / odd marker segment must never abort the batch with IndexError / struct.error -- every truncation and a set of
     corrupted headers either parses (damage inside the entropy-coded data is caught on the device) or raises NotBaseline (-> Pillow);

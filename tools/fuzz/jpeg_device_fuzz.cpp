@@ -29,6 +29,9 @@ static inline int fz_atomicOr(int32_t* p, int v) { const int o = *p; *p |= v; re
 #define atomicOr fz_atomicOr
 #include "jpeg_kernels_cut.inc"
 
+static std::vector<uint8_t>* g_pixels = nullptr;   // FZ_MAIN: where the decoded RGB bytes go
+static int g_status = -1;
+
 extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
   std::vector<uint8_t> a(data, data + size);
   const void* files[1] = {a.data()};
@@ -61,7 +64,32 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
       fz_blockIdx.x = (unsigned)px;
       ssg::jpeg::colour_kernel(imgs.data(), planes.data(), out.data());
     }
+    if (g_pixels) { *g_pixels = out; g_status = status[0]; }
   }
   ssg_jpeg_parse_close(h);
   return 0;
 }
+
+#ifdef FZ_MAIN
+// jpeg_device_host <in.jpg> <out.rgb>: the kernels' source text as a host decoder (tests/test_oracle_golden.py compares it with Pillow).
+// exit 0 = decoded, 3 = the parser hands the file to Pillow, 4 = the Huffman kernel flagged damaged data
+int main(int argc, char** argv) {
+  if (argc != 3) return 2;
+  FILE* f = fopen(argv[1], "rb");
+  if (!f) return 2;
+  std::vector<uint8_t> buf;
+  uint8_t tmp[65536];
+  size_t n;
+  while ((n = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+  fclose(f);
+  std::vector<uint8_t> px;
+  g_pixels = &px;
+  LLVMFuzzerTestOneInput(buf.data(), buf.size());
+  if (g_status < 0) return 3;
+  if (g_status) return 4;
+  f = fopen(argv[2], "wb");
+  fwrite(px.data(), 1, px.size(), f);
+  fclose(f);
+  return 0;
+}
+#endif
