@@ -1,0 +1,213 @@
+"""The scalar numerics rules of the device code, executed on the host and compared with numpy.
+
+csrc/ssg_common.h (numpy's half arithmetic, the one-rounding double -> half, final_dist from its compact form) and the integer
+half(sqrt(.)) rounding of the int8 Gram epilogue (csrc/gram_i8.hip) are scalar C++ behind `__device__`.  tools/hostexec/scalar_rules.cpp
+maps that to host functions and compiles the SAME SOURCE TEXT for x86 (ROCm's clang, host only); this file checks it bit for bit against
+numpy -- the arithmetic the reference runs (reid/rerank.py:33-122 in np.float16, scipy's float64 cdist + sqrt).  No GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="module")
+def hx(tmp_path_factory):
+    if not os.path.exists(CLANG):
+        pytest.skip("ROCm clang++ not present")
+    d = tmp_path_factory.mktemp("hx")
+    csrc = os.path.join(ROOT, "self-similarity-grouping_amd", "csrc")
+
+    def cut(fname, start, stop=None):
+        """the lines of csrc/<fname> from the one that starts with `start` to the function's closing brace (or up to `stop`)"""
+        out = []
+        for line in open(os.path.join(csrc, fname)):
+            if not out and not line.startswith(start):
+                continue
+            if stop is not None and stop in line:
+                break
+            out.append(line)
+            if stop is None:
+                code = line.split("//")[0].rstrip()
+                if (len(out) == 1 and code.endswith(("}", ";"))) or code in ("}", "};"):
+                    break
+        assert out, (fname, start)
+        return "".join(out)
+
+    text = [cut("gram_i8.hip", "__device__ __forceinline__ long long half_units24", stop="halfwave_max"),
+            cut("jaccard.hip", "__device__ __forceinline__ hbits jaccard_scaled"),
+            cut("krecip.hip", "__device__ float pairwise_sum_f32"),
+            "template <typename T>\n" + cut("cluster.hip", "__device__ T pw_leaf"),
+            cut("cluster.hip", "__device__ __forceinline__ int sur_bin(float x)"),
+            cut("cluster.hip", "__device__ __forceinline__ float sur_bin_upper"),
+            cut("topk_intro.hip", "constexpr uint32_t KEY_NAN"),
+            cut("topk_intro.hip", "__device__ __forceinline__ uint32_t norm_key")]
+    assert "sqrt_units48_to_half" in text[0]
+    (d / "rules_cut.inc").write_text("\n".join(text))
+    so = str(d / "libhx.so")
+    r = subprocess.run([CLANG, "-x", "hip", "--offload-host-only", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", "-I" + str(d), "-o", so,
+                        os.path.join(ROOT, "tools", "hostexec", "scalar_rules.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return ctypes.CDLL(so)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _interesting_doubles(rng, n):
+    """random doubles over the whole half range + everything around the half grid: values, midpoints, their float64 neighbours"""
+    hb = np.arange(0, 0x7C00, dtype=np.uint16)
+    hv = hb.view(np.float16).astype(np.float64)
+    mid = (hv[:-1] + hv[1:]) / 2
+    grid = np.concatenate([hv, mid, np.nextafter(mid, np.inf), np.nextafter(mid, -np.inf), np.nextafter(hv, np.inf), np.nextafter(hv, -np.inf)])
+    x = np.concatenate([grid, -grid, rng.standard_normal(n) * np.exp(rng.uniform(-30, 12, n)), rng.uniform(0, 4, n),
+                        np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 65504.0, 65519.999, 65520.0, 1e300, 5e-324, 2.0 ** -25, 2.0 ** -24 * 1.5])])
+    return np.ascontiguousarray(x)
+
+
+def test_double_to_half_is_numpys_single_rounding(hx):
+    """d2h (ssg_common.h) == numpy's float64 -> float16 cast (npy_double_to_half: ONE round-to-nearest-even, subnormals, overflow to inf)"""
+    x = _interesting_doubles(np.random.default_rng(0), 2_000_000)
+    out = np.empty(x.size, np.uint16)
+    hx.hx_d2h(_p(x), ctypes.c_long(x.size), _p(out))
+    with np.errstate(over="ignore"):
+        ref = x.astype(np.float16).view(np.uint16)
+    nan = np.isnan(x)
+    assert np.array_equal(out[~nan], ref[~nan])
+    assert np.all((out[nan] & 0x7FFF) > 0x7C00)
+
+
+def test_half_binary_ops_are_numpys(hx):
+    """h_add / h_sub / h_mul / h_div == numpy's float16 loops (float32 op + one rounding) on every class of operand"""
+    rng = np.random.default_rng(1)
+    n = 4_000_000
+    a = rng.integers(0, 1 << 16, n).astype(np.uint16); b = rng.integers(0, 1 << 16, n).astype(np.uint16)
+    a[:2 * 0x7C00] = np.repeat(np.arange(0, 0x7C00, dtype=np.uint16), 2)            # every non-negative finite half, twice
+    af, bf = a.view(np.float16), b.view(np.float16)
+    for op, fn in enumerate((np.add, np.subtract, np.multiply, np.divide)):
+        out = np.empty(n, np.uint16)
+        hx.hx_binop(op, _p(a), _p(b), ctypes.c_long(n), _p(out))
+        with np.errstate(all="ignore"):
+            ref = fn(af, bf).view(np.uint16)
+        nan = np.isnan(ref.view(np.float16))
+        assert np.array_equal(out[~nan], ref[~nan]), fn
+        assert np.all((out[nan] & 0x7FFF) > 0x7C00), fn
+
+
+def test_float_half_conversions(hx):
+    rng = np.random.default_rng(2)
+    with np.errstate(over="ignore"):
+        x = np.concatenate([rng.standard_normal(2_000_000).astype(np.float32) * np.exp(rng.uniform(-20, 12, 2_000_000)).astype(np.float32),
+                            _interesting_doubles(rng, 10).astype(np.float32)])
+    x = np.ascontiguousarray(x[~np.isnan(x)])
+    out = np.empty(x.size, np.uint16)
+    hx.hx_f2h(_p(x), ctypes.c_long(x.size), _p(out))
+    with np.errstate(over="ignore"):
+        assert np.array_equal(out, x.astype(np.float16).view(np.uint16))
+    hb = np.arange(0, 1 << 16, dtype=np.uint16)
+    f = np.empty(hb.size, np.float32)
+    hx.hx_h2f(_p(hb), ctypes.c_long(hb.size), _p(f))
+    ref = hb.view(np.float16).astype(np.float32)
+    assert np.array_equal(f.view(np.uint32)[~np.isnan(ref)], ref.view(np.uint32)[~np.isnan(ref)])
+
+
+def test_final_dist_from_compact_form(hx):
+    """final_dist_value == reid/rerank.py:122 `jaccard*(1-lambda) + original*lambda` as the reference evaluates it: J' is the half product
+    the matrix stores, the source term half(v_i + v_k) is promoted to float64 and scaled by the python float lambda"""
+    rng = np.random.default_rng(3)
+    n = 2_000_000
+    jp = rng.uniform(0, 1, n).astype(np.float16); vi = rng.uniform(0, 1, n).astype(np.float16); vk = rng.uniform(0, 1, n).astype(np.float16)
+    for lam in (0.3, 0.0, 1.0, 0.1):
+        out = np.empty(n, np.float64)
+        hx.hx_final_dist(_p(jp.view(np.uint16)), _p(vi.view(np.uint16)), _p(vk.view(np.uint16)), ctypes.c_double(lam), ctypes.c_long(n), _p(out))
+        ref = jp.astype(np.float64) + (vk + vi).astype(np.float64) * lam
+        assert np.array_equal(out.view(np.uint64), ref.view(np.uint64)), lam
+
+
+def test_integer_sqrt_rounding_is_half_of_float64_sqrt(hx):
+    """sqrt_units48_to_half(U) == float16(sqrt(float64(U * 2^-48))) -- scipy cdist's float64 root, then rerank.py:33's cast -- for
+    U < 2^50 (squared distances below 4: every pair of L2-normalised features), whatever the 1-ulp error of the device's approximate
+    square root does to the candidate (modes -1 / 0 / +1): random U, every half midpoint square +- 3, every half value squared +- 3."""
+    rng = np.random.default_rng(4)
+    hb = np.arange(0, 0x4000, dtype=np.uint32)                   # halves below 2.0
+    units = np.empty(hb.size, np.int64)
+    hx.hx_units24(_p(hb), ctypes.c_long(hb.size), _p(units))
+    assert np.array_equal(units, np.round(hb.astype(np.uint16).view(np.float16).astype(np.float64) * 2.0 ** 24).astype(np.int64))
+    mid2 = ((units[:-1] + units[1:]) ** 2) // 4                  # (midpoint in units of 2^-25)^2 / 4 = U of the midpoint's square (floor)
+    sq = units ** 2
+    near = np.concatenate([(mid2[:, None] + np.arange(-3, 4)[None, :]).ravel(), (sq[:, None] + np.arange(-3, 4)[None, :]).ravel()])
+    u = np.concatenate([near, rng.integers(0, 1 << 50, 2_000_000), rng.integers(0, 1 << 30, 500_000), rng.integers(0, 1 << 12, 5000), np.array([0, 1, 2, (1 << 50) - 1])])
+    u = np.ascontiguousarray(u[(u >= 0) & (u < (1 << 50))].astype(np.int64))
+    ref = np.sqrt(u.astype(np.float64) * 2.0 ** -48).astype(np.float16).view(np.uint16)
+    for mode in (0, 1, -1):
+        out = np.empty(u.size, np.uint16)
+        hx.hx_sqrt48(_p(u), ctypes.c_long(u.size), ctypes.c_int(mode), _p(out))
+        bad = np.flatnonzero(out != ref)
+        assert bad.size == 0, (mode, bad[:5], u[bad[:5]], out[bad[:5]], ref[bad[:5]])
+
+
+def test_jaccard_scaled_is_the_references_half_expression(hx):
+    """jaccard_scaled(t, half(1-lambda)) == rerank.py:120-122 in np.float16: 1 - t/(2 - t), negatives to 0, times the python float 1-lambda
+    (a weak scalar: the product is a half op) -- for EVERY half t in [0, 2] and a range of lambda"""
+    t = np.arange(0, 0x4001, dtype=np.uint16)
+    tf = t.view(np.float16)
+    for lam in (0.3, 0.0, 0.1, 0.5, 0.9, 1.0):
+        om = np.float16(1.0 - lam)
+        out = np.empty(t.size, np.uint16)
+        hx.hx_jaccard_scaled(_p(t), ctypes.c_uint16(int(om.view(np.uint16))), ctypes.c_long(t.size), _p(out))
+        with np.errstate(all="ignore"):
+            j = np.float16(1) - tf / (np.float16(2) - tf)
+            j[j < 0] = 0
+            ref = (j * (1.0 - lam)).astype(np.float16)       # float16 array * python float
+        ok = ~np.isnan(ref)
+        assert ref.dtype == np.float16 and np.array_equal(out[ok], ref.view(np.uint16)[ok]), lam
+
+
+def test_pairwise_sums_are_numpys(hx):
+    """pairwise_sum_f32 (the V row normalisation, rerank.py:91) and the leaves of the eps mean (selftraining.py:293) add in numpy's
+    pairwise order: equal to np.sum / np.add.reduce bit for bit for every length that occurs (V rows <= a few hundred entries; leaves <= 128)"""
+    rng = np.random.default_rng(6)
+    hx.hx_pairwise_sum_f32.restype = ctypes.c_float
+    hx.hx_pw_leaf_f64.restype = ctypes.c_double
+    hx.hx_pw_leaf_f32.restype = ctypes.c_float
+    for n in list(range(0, 300)) + [511, 512, 1000, 4097]:
+        a = np.exp(-rng.uniform(0, 3, n)).astype(np.float32)
+        got = hx.hx_pairwise_sum_f32(_p(a), ctypes.c_int(n))
+        assert np.float32(got).view(np.uint32) == np.add.reduce(a, dtype=np.float32).view(np.uint32), n
+    for n in range(0, 129):
+        x = rng.uniform(0, 2, n + 3)
+        keys = np.ascontiguousarray(x.view(np.uint64))
+        got = hx.hx_pw_leaf_f64(_p(keys), ctypes.c_longlong(3), ctypes.c_int(n))
+        assert np.float64(got).view(np.uint64) == np.add.reduce(x[3:]).view(np.uint64), n
+        got32 = hx.hx_pw_leaf_f32(_p(keys), ctypes.c_longlong(3), ctypes.c_int(n))
+        assert np.float32(got32).view(np.uint32) == np.add.reduce(x[3:].astype(np.float32), dtype=np.float32).view(np.uint32), n
+
+
+def test_rank_key_and_surrogate_bins(hx):
+    """norm_key = the bit pattern of half(D / rowmax) (rerank.py:68: original_dist / max in np.float16; non-negative halves order like
+    their bits, NaN last like numpy's sort); the eps rule's surrogate bins are monotone and their upper edges bound their members."""
+    raw = np.arange(0, 0x7C01, dtype=np.uint32)
+    d = raw.astype(np.uint16).view(np.float16)
+    for mx in (np.float16(1.0), np.float16(0.37), np.float16(3.998), np.float16(6e-5), np.float16(0.0)):
+        out = np.empty(raw.size, np.uint32)
+        hx.hx_norm_key(_p(raw), ctypes.c_float(float(mx)), ctypes.c_long(raw.size), _p(out))
+        with np.errstate(all="ignore"):
+            ref = (d / mx)
+        nan = np.isnan(ref)
+        assert np.array_equal(out[~nan], ref.view(np.uint16)[~nan].astype(np.uint32)) and np.all(out[nan] == 0xFFFF), mx
+    x = np.sort(np.concatenate([np.random.default_rng(7).uniform(0, 4.5, 1_000_000), np.exp(np.random.default_rng(8).uniform(-30, 2, 200_000)), [0.0]])).astype(np.float32)
+    b = np.empty(x.size, np.int32)
+    hx.hx_sur_bin(_p(x), ctypes.c_long(x.size), _p(b))
+    assert np.all(np.diff(b) >= 0) and b.min() == 0 and b.max() == 4095
+    hx.hx_sur_bin_upper.restype = ctypes.c_float
+    up = np.array([hx.hx_sur_bin_upper(int(k)) for k in range(4096)], np.float32)
+    inside = b < 4095
+    assert np.all(x[inside] < up[b[inside]]) and np.all(np.diff(up) > 0)
+    lo = b > 0
+    assert np.all(x[lo] >= up[b[lo] - 1])

@@ -1,0 +1,60 @@
+// The scalar numerics rules of the device code, executed on the host: csrc/ssg_common.h (half arithmetic as numpy does it, the one-rounding
+// double -> half, final_dist from its compact form) and the scalar helpers of the kernels -- the integer half(sqrt(.)) rounding of
+// gram_i8.hip, jaccard_scaled (jaccard.hip), numpy's pairwise summation (krecip.hip float32, cluster.hip float64 leaves), the rank key of
+// the introsort replay (topk_intro.hip), the eps rule's surrogate bins (cluster.hip) -- are plain scalar C++ behind `__device__`.  The test
+// cuts their text out of the .hip files into rules_cut.inc; with `__device__` mapped to host functions the SAME TEXT is compiled for x86 and
+// compared with numpy on millions of inputs (tests/test_host_exec.py) -- a CPU-side pin of the rules DESIGN.md §4 lists, next to the
+// `-m gpu` tests that run them on the GPU.  Test infrastructure: nothing here is linked into the product.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstring>
+#undef __device__
+#undef __forceinline__
+#define __device__
+#define __forceinline__ inline
+static int g_sqrt_mode = 0;     // the device's v_sqrt_f32 is good to 1 ulp: the candidate may be off by one float either way
+static inline float hx_sqrtf(float x) {
+  const float r = sqrtf(x);
+  return g_sqrt_mode > 0 ? nextafterf(r, INFINITY) : g_sqrt_mode < 0 ? nextafterf(r, 0.0f) : r;
+}
+#define __builtin_amdgcn_sqrtf hx_sqrtf
+static inline long long hx_double_as_longlong(double x) { long long r; memcpy(&r, &x, 8); return r; }
+#define __double_as_longlong hx_double_as_longlong
+static inline double hx_longlong_as_double(long long x) { double r; memcpy(&r, &x, 8); return r; }
+#define __longlong_as_double hx_longlong_as_double
+static inline unsigned hx_float_as_uint(float x) { unsigned r; memcpy(&r, &x, 4); return r; }
+static inline float hx_uint_as_float(unsigned x) { float r; memcpy(&r, &x, 4); return r; }
+#define __float_as_uint hx_float_as_uint
+#define __uint_as_float hx_uint_as_float
+#define threadIdx hx_threadIdx
+static struct { unsigned x, y, z; } hx_threadIdx;
+#include "../../self-similarity-grouping_amd/csrc/ssg_common.h"
+namespace ssg {
+#include "rules_cut.inc"
+}
+using namespace ssg;
+
+extern "C" {
+void hx_d2h(const double* x, long n, uint16_t* out) { for (long i = 0; i < n; i++) out[i] = d2h(x[i]); }
+void hx_f2h(const float* x, long n, uint16_t* out) { for (long i = 0; i < n; i++) out[i] = f2h(x[i]); }
+void hx_h2f(const uint16_t* x, long n, float* out) { for (long i = 0; i < n; i++) out[i] = h2f(x[i]); }
+void hx_binop(int op, const uint16_t* a, const uint16_t* b, long n, uint16_t* out) {
+  for (long i = 0; i < n; i++) out[i] = op == 0 ? h_add(a[i], b[i]) : op == 1 ? h_sub(a[i], b[i]) : op == 2 ? h_mul(a[i], b[i]) : h_div(a[i], b[i]);
+}
+void hx_final_dist(const uint16_t* jp, const uint16_t* vi, const uint16_t* vk, double lam, long n, double* out) {
+  for (long i = 0; i < n; i++) out[i] = final_dist_value(jp[i], vi[i], vk[i], lam);
+}
+void hx_sqrt48(const long long* u, long n, int mode, uint16_t* out) {
+  g_sqrt_mode = mode;
+  for (long i = 0; i < n; i++) out[i] = sqrt_units48_to_half(u[i]);
+  g_sqrt_mode = 0;
+}
+void hx_jaccard_scaled(const uint16_t* t, uint16_t om, long n, uint16_t* out) { for (long i = 0; i < n; i++) out[i] = jaccard_scaled(t[i], om); }
+float hx_pairwise_sum_f32(const float* a, int n) { return pairwise_sum_f32(a, n); }
+double hx_pw_leaf_f64(const unsigned long long* keys, long long off, int n) { return pw_leaf<double>(keys, off, n); }
+float hx_pw_leaf_f32(const unsigned long long* keys, long long off, int n) { return pw_leaf<float>(keys, off, n); }
+void hx_norm_key(const uint32_t* raw, float fmx, long n, uint32_t* out) { for (long i = 0; i < n; i++) out[i] = norm_key(raw[i], fmx); }
+void hx_sur_bin(const float* x, long n, int* out) { for (long i = 0; i < n; i++) out[i] = sur_bin(x[i]); }
+float hx_sur_bin_upper(int b) { return sur_bin_upper(b); }
+void hx_units24(const uint32_t* h, long n, long long* out) { for (long i = 0; i < n; i++) out[i] = half_units24(h[i]); }
+}
