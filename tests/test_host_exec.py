@@ -49,6 +49,8 @@ def hx(tmp_path_factory):
             cut("topk_intro.hip", "__device__ __forceinline__ uint32_t norm_key")]
     assert "sqrt_units48_to_half" in text[0]
     (d / "rules_cut.inc").write_text("\n".join(text))
+    (d / "preprocess_cut.inc").write_text(cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_h_u8_kernel") + "\n" +
+                                          cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_v_normalize_kernel"))
     so = str(d / "libhx.so")
     r = subprocess.run([CLANG, "-x", "hip", "--offload-host-only", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", "-I" + str(d), "-o", so,
                         os.path.join(ROOT, "tools", "hostexec", "scalar_rules.cpp")], capture_output=True, text=True)
@@ -211,3 +213,25 @@ def test_rank_key_and_surrogate_bins(hx):
     assert np.all(x[inside] < up[b[inside]]) and np.all(np.diff(up) > 0)
     lo = b > 0
     assert np.all(x[lo] >= up[b[lo] - 1])
+
+
+def test_resize_kernels_on_host_match_pillow(hx):
+    """preprocess.hip's two kernels (grid-stride, no wave-level operation: executed by ONE host thread) with the product's coefficient
+    tables (ssg_amd.preprocessor.bilinear_coeffs) == Resize((H, W)) + ToTensor + Normalize of the reference loaders
+    (selftraining.py:43-47, preprocessor.py:28-30) computed with Pillow + numpy float32: up- and down-scaling, odd sizes."""
+    from PIL import Image
+    from ssg_amd import preprocessor as pp
+    rng = np.random.default_rng(9)
+    mean = np.array(pp.MEAN, np.float32); std = np.array(pp.STD, np.float32)
+    for (h, w, H, W) in ((128, 64, 256, 128), (300, 117, 256, 128), (57, 31, 64, 32), (256, 128, 256, 128), (640, 480, 256, 128)):
+        B = 2
+        src = rng.integers(0, 256, (B, h, w, 3), dtype=np.uint8)
+        src[1] = np.clip(np.add.outer(np.arange(h), np.arange(w))[..., None] * 255.0 / (h + w) + rng.normal(0, 6, (h, w, 3)), 0, 255).astype(np.uint8)
+        (xf, xc, xk), (yf, yc, yk) = pp.bilinear_coeffs(w, W), pp.bilinear_coeffs(h, H)
+        xk = np.ascontiguousarray(xk); yk = np.ascontiguousarray(yk)
+        tmp = np.empty((B, h, W, 3), np.uint8); out = np.empty((B, 3, H, W), np.float32)
+        hx.hx_preprocess(_p(src), B, h, w, H, W, _p(xf), _p(xc), _p(xk), xk.shape[1], _p(yf), _p(yc), _p(yk), yk.shape[1], _p(mean), _p(std), _p(tmp), _p(out))
+        for b in range(B):
+            pil = np.asarray(Image.fromarray(src[b]).resize((W, H), Image.BILINEAR))
+            ref = ((pil.astype(np.float32) / np.float32(255)).transpose(2, 0, 1) - mean[:, None, None]) / std[:, None, None]
+            assert ref.dtype == np.float32 and np.array_equal(out[b].view(np.uint32), ref.view(np.uint32)), (h, w, H, W, b)

@@ -27,10 +27,22 @@ static inline float hx_uint_as_float(unsigned x) { float r; memcpy(&r, &x, 4); r
 #define __float_as_uint hx_float_as_uint
 #define __uint_as_float hx_uint_as_float
 #define threadIdx hx_threadIdx
-static struct { unsigned x, y, z; } hx_threadIdx;
+#define blockIdx hx_blockIdx
+#define blockDim hx_blockDim
+#define gridDim hx_gridDim
+struct HxDim { unsigned x, y, z; };
+static HxDim hx_threadIdx = {0, 0, 0}, hx_blockIdx = {0, 0, 0}, hx_blockDim = {1, 1, 1}, hx_gridDim = {1, 1, 1};   // ONE thread: grid-stride kernels cover everything
+#undef __global__
+#define __global__
+#undef __launch_bounds__
+#define __launch_bounds__(x)
 #include "../../self-similarity-grouping_amd/csrc/ssg_common.h"
+#include <algorithm>
+using std::max;
+using std::min;
 namespace ssg {
 #include "rules_cut.inc"
+#include "preprocess_cut.inc"
 }
 using namespace ssg;
 
@@ -56,5 +68,11 @@ float hx_pw_leaf_f32(const unsigned long long* keys, long long off, int n) { ret
 void hx_norm_key(const uint32_t* raw, float fmx, long n, uint32_t* out) { for (long i = 0; i < n; i++) out[i] = norm_key(raw[i], fmx); }
 void hx_sur_bin(const float* x, long n, int* out) { for (long i = 0; i < n; i++) out[i] = sur_bin(x[i]); }
 float hx_sur_bin_upper(int b) { return sur_bin_upper(b); }
+// the two resize kernels of preprocess.hip (grid-stride, one thread here): uint8 [B,h,w,3] -> float32 [B,3,H,W]
+void hx_preprocess(const uint8_t* src, int B, int h, int w, int H, int W, const int32_t* xmin, const int32_t* xcnt, const int32_t* kkx, int ksx,
+                   const int32_t* ymin, const int32_t* ycnt, const int32_t* kky, int ksy, const float* m, const float* sd, uint8_t* tmp, float* out) {
+  resize_h_u8_kernel(src, tmp, B, h, w, W, xmin, xcnt, kkx, ksx);
+  resize_v_normalize_kernel(tmp, out, B, h, H, W, ymin, ycnt, kky, ksy, m[0], m[1], m[2], sd[0], sd[1], sd[2]);
+}
 void hx_units24(const uint32_t* h, long n, long long* out) { for (long i = 0; i < n; i++) out[i] = half_units24(h[i]); }
 }
