@@ -51,6 +51,7 @@ def hx(tmp_path_factory):
     (d / "rules_cut.inc").write_text("\n".join(text))
     (d / "preprocess_cut.inc").write_text(cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_h_u8_kernel") + "\n" +
                                           cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_v_normalize_kernel"))
+    (d / "cc_cut.inc").write_text(cut("cluster.hip", "// ------------------------------------------------------------------ K12 union-find", stop="}  // namespace ssg"))
     so = str(d / "libhx.so")
     r = subprocess.run([CLANG, "-x", "hip", "--offload-host-only", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", "-I" + str(d), "-o", so,
                         os.path.join(ROOT, "tools", "hostexec", "scalar_rules.cpp")], capture_output=True, text=True)
@@ -235,3 +236,31 @@ def test_resize_kernels_on_host_match_pillow(hx):
             pil = np.asarray(Image.fromarray(src[b]).resize((W, H), Image.BILINEAR))
             ref = ((pil.astype(np.float32) / np.float32(255)).transpose(2, 0, 1) - mean[:, None, None]) / std[:, None, None]
             assert ref.dtype == np.float32 and np.array_equal(out[b].view(np.uint32), ref.view(np.uint32)), (h, w, H, W, b)
+
+
+def test_union_find_kernels_on_host_number_labels_like_sklearn(hx):
+    """The connected-components kernels of cluster.hip (union-find with path halving, roots = smallest core index, clusters numbered
+    by an exclusive scan over the roots, border points to the smallest adjacent cluster) executed on the host in ssg_dbscan_cc's launch
+    order == sklearn.cluster.DBSCAN(metric='precomputed').fit_predict (selftraining.py:299-306) incl. its numbering, whatever the
+    order of the edge list -- blobs with noise, border points shared by two clusters, min_samples 1..6, no edges at all."""
+    from sklearn.cluster import DBSCAN
+    rng = np.random.default_rng(10)
+    for trial in range(12):
+        n = int(rng.integers(40, 400))
+        k = int(rng.integers(2, 9))
+        centres = rng.uniform(0, 6, (k, 2))
+        x = np.concatenate([centres[rng.integers(0, k, n)] + rng.normal(0, 0.25, (n, 2)), rng.uniform(0, 6, (n // 5, 2))])
+        x = x[rng.permutation(x.shape[0])]
+        N = x.shape[0]
+        dist = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(-1))
+        for eps, ms in ((0.2, 4), (0.35, 4), (0.3, int(rng.integers(1, 7))), (1e-9, 2)):
+            ref = DBSCAN(eps=eps, min_samples=ms, metric="precomputed", n_jobs=1).fit_predict(dist).astype(np.int64)
+            hit = dist <= eps
+            cnt = hit.sum(1).astype(np.int32)                         # the point itself counts (sklearn's radius neighbours)
+            ii, kk = np.nonzero(hit)
+            for order in range(2):
+                perm = rng.permutation(ii.size) if order else np.arange(ii.size)
+                edges = np.ascontiguousarray(np.stack([ii[perm], kk[perm]], 1).astype(np.int32))
+                labels = np.empty(N, np.int64)
+                hx.hx_dbscan_cc(_p(cnt), _p(edges), ctypes.c_ulonglong(edges.shape[0]), N, ms, _p(labels))
+                assert np.array_equal(labels, ref), (trial, eps, ms, order)

@@ -37,12 +37,20 @@ static HxDim hx_threadIdx = {0, 0, 0}, hx_blockIdx = {0, 0, 0}, hx_blockDim = {1
 #undef __launch_bounds__
 #define __launch_bounds__(x)
 #include "../../self-similarity-grouping_amd/csrc/ssg_common.h"
+// single host thread: the atomics of the union-find kernels are plain operations
+#define __hip_atomic_load(p, order, scope) (*(p))
+static inline int hx_atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }
+static inline int hx_atomicCAS(int* p, int cmp, int v) { const int o = *p; if (o == cmp) *p = v; return o; }
+#define atomicMin hx_atomicMin
+#define atomicCAS hx_atomicCAS
 #include <algorithm>
+#include <vector>
 using std::max;
 using std::min;
 namespace ssg {
 #include "rules_cut.inc"
 #include "preprocess_cut.inc"
+#include "cc_cut.inc"
 }
 using namespace ssg;
 
@@ -73,6 +81,26 @@ void hx_preprocess(const uint8_t* src, int B, int h, int w, int H, int W, const 
                    const int32_t* ymin, const int32_t* ycnt, const int32_t* kky, int ksy, const float* m, const float* sd, uint8_t* tmp, float* out) {
   resize_h_u8_kernel(src, tmp, B, h, w, W, xmin, xcnt, kkx, ksx);
   resize_v_normalize_kernel(tmp, out, B, h, H, W, ymin, ycnt, kky, ksy, m[0], m[1], m[2], sd[0], sd[1], sd[2]);
+}
+// ssg_dbscan_cc's launch sequence (cluster.hip dbscan_cc_impl) with the kernels' own text: per-index kernels run index by index, the
+// grid-stride ones (union, border) as one thread over the edge list in the order given; the exclusive scan of the root flags (a wave-level
+// kernel on the device) is restated here
+void hx_dbscan_cc(const int32_t* cnt, const int32_t* edges, unsigned long long ne, int N, int min_samples, int64_t* labels) {
+  std::vector<int> parent(N), lab(N);
+  std::vector<int32_t> rootflag(N);
+  std::vector<int64_t> rootid(N + 1);
+  hx_blockDim.x = 1; hx_gridDim.x = 1; hx_threadIdx.x = 0;
+  for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_init_kernel(cnt, N, min_samples, parent.data(), lab.data()); }
+  hx_blockIdx.x = 0;
+  if (ne) cc_union_kernel(edges, ne, nullptr, cnt, min_samples, parent.data());
+  for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_flatten_kernel(cnt, N, min_samples, parent.data(), rootflag.data()); }
+  int64_t run = 0;
+  for (int i = 0; i < N; i++) { rootid[i] = run; run += rootflag[i]; }
+  for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_label_core_kernel(cnt, N, min_samples, parent.data(), rootid.data(), lab.data()); }
+  hx_blockIdx.x = 0;
+  if (ne) cc_border_kernel(edges, ne, nullptr, cnt, min_samples, parent.data(), rootid.data(), lab.data());
+  for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_finalize_kernel(lab.data(), N, labels); }
+  hx_blockIdx.x = 0;
 }
 void hx_units24(const uint32_t* h, long n, long long* out) { for (long i = 0; i < n; i++) out[i] = half_units24(h[i]); }
 }
