@@ -52,6 +52,7 @@ def hx(tmp_path_factory):
     (d / "preprocess_cut.inc").write_text(cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_h_u8_kernel") + "\n" +
                                           cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_v_normalize_kernel"))
     (d / "cc_cut.inc").write_text(cut("cluster.hip", "// ------------------------------------------------------------------ K12 union-find", stop="}  // namespace ssg"))
+    (d / "split_cut.inc").write_text(cut("conv.hip", "__device__ __forceinline__ unsigned pack_h2", stop="struct ConvParams"))
     so = str(d / "libhx.so")
     r = subprocess.run([CLANG, "-x", "hip", "--offload-host-only", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", "-I" + str(d), "-o", so,
                         os.path.join(ROOT, "tools", "hostexec", "scalar_rules.cpp")], capture_output=True, text=True)
@@ -264,3 +265,28 @@ def test_union_find_kernels_on_host_number_labels_like_sklearn(hx):
                 labels = np.empty(N, np.int64)
                 hx.hx_dbscan_cc(_p(cnt), _p(edges), ctypes.c_ulonglong(edges.shape[0]), N, ms, _p(labels))
                 assert np.array_equal(labels, ref), (trial, eps, ms, order)
+
+
+def test_split_half_format_carries_22_bits(hx):
+    """The embedding's operand format (conv.hip "split-half activations"): hi = half(v), lo = half(v - hi), both numpy's roundings;
+    hi + lo reproduces v to 2^-22 relative (absolute floor 2^-25: the half subnormal grid) for |v| < 65504 -- the bound behind the
+    5e-6 parity tolerance of the embedding -- and values outside the format are detected by the non-finite test."""
+    rng = np.random.default_rng(12)
+    n = 4_000_000
+    with np.errstate(over="ignore"):
+        v = (rng.standard_normal(n) * np.exp(rng.uniform(-25, 11, n))).astype(np.float32)
+    v[:8] = [0.0, -0.0, 65503.9, -65503.9, 2.0 ** -24, 2.0 ** -26, 1.0, 1.0 + 2.0 ** -12]
+    v = np.ascontiguousarray(np.clip(v, -65503.9, 65503.9))
+    hi = np.empty(n // 2, np.uint32); lo = np.empty(n // 2, np.uint32); dec = np.empty(n, np.float32); nf = np.empty(n // 4, np.uint8)
+    hx.hx_split(_p(v), ctypes.c_long(n // 4), _p(hi), _p(lo), _p(dec), _p(nf))
+    h_ref = v.astype(np.float16)
+    l_ref = (v - h_ref.astype(np.float32)).astype(np.float16)
+    assert np.array_equal(hi.view(np.uint16), h_ref.view(np.uint16)) and np.array_equal(lo.view(np.uint16), l_ref.view(np.uint16))
+    assert np.array_equal(dec.view(np.uint32), (h_ref.astype(np.float32) + l_ref.astype(np.float32)).view(np.uint32)) and not nf.any()
+    err = np.abs(dec.astype(np.float64) - v.astype(np.float64))
+    assert np.all(err <= np.maximum(np.abs(v.astype(np.float64)) * 2.0 ** -22, 2.0 ** -25))
+    big = np.ascontiguousarray(np.array([1.0, 70000.0, 2.0, 3.0, 1.0, 2.0, np.inf, 3.0, np.nan, 0.0, 0.0, 0.0, 65519.9, 0, 0, 0], np.float32))
+    nf4 = np.empty(4, np.uint8)
+    with np.errstate(all="ignore"):
+        hx.hx_split(_p(big), ctypes.c_long(4), _p(hi), _p(lo), _p(dec), _p(nf4))
+    assert nf4.tolist() == [1, 1, 1, 0]

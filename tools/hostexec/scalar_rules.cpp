@@ -51,6 +51,7 @@ namespace ssg {
 #include "rules_cut.inc"
 #include "preprocess_cut.inc"
 #include "cc_cut.inc"
+#include "split_cut.inc"
 }
 using namespace ssg;
 
@@ -101,6 +102,18 @@ void hx_dbscan_cc(const int32_t* cnt, const int32_t* edges, unsigned long long n
   if (ne) cc_border_kernel(edges, ne, nullptr, cnt, min_samples, parent.data(), rootid.data(), lab.data());
   for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_finalize_kernel(lab.data(), N, labels); }
   hx_blockIdx.x = 0;
+}
+// split-half format of the embedding (conv.hip): n4 groups of 4 floats -> hi / lo dword pairs, the non-finite test, and back
+void hx_split(const float* in, long n4, uint32_t* hi, uint32_t* lo, float* dec, uint8_t* nonfinite) {
+  for (long i = 0; i < n4; i++) {
+    const float4 v = make_float4(in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]);
+    uint2 h, l;
+    split_encode4(v, h, l);
+    hi[2 * i] = h.x; hi[2 * i + 1] = h.y; lo[2 * i] = l.x; lo[2 * i + 1] = l.y;
+    nonfinite[i] = split_hi_nonfinite(h) ? 1 : 0;
+    const float4 d = split_decode4(h, l);
+    dec[4 * i] = d.x; dec[4 * i + 1] = d.y; dec[4 * i + 2] = d.z; dec[4 * i + 3] = d.w;
+  }
 }
 void hx_units24(const uint32_t* h, long n, long long* out) { for (long i = 0; i < n; i++) out[i] = half_units24(h[i]); }
 }
