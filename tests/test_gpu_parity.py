@@ -373,6 +373,37 @@ def test_selftraining_surface_and_edge_cases(dev, ora):
     assert clusters2 is clusters and all(np.array_equal(a, b) for a, b in zip(labels, labels2))
 
 
+def test_selftraining_functions_vs_the_references_own(dev, golden):
+    """tests/golden/selftraining_ref.npz = outputs of the reference's OWN compute_dist / generate_selflabel / generate_dataloader
+    (selftraining.py:255-331 imported by tools/make_golden.py, two iterations, 3 splits, N = 200): the product's functions of the
+    same names give the same eps per split (iteration 0), the same labels incl. numbering (iteration 1 on the CACHED estimators:
+    eps frozen, selftraining.py:297-298), the same final_dist bytes and the same joined dataset (a6, a8, a9, a10)."""
+    import hashlib
+    from types import SimpleNamespace
+    from ssg_amd import compute_dist, generate_selflabel
+    from ssg_amd.selftraining import generate_dataset
+    g = golden("selftraining_ref.npz")
+    N, S1 = int(g["N"]), int(g["splits"])
+    args = SimpleNamespace(no_rerank=False, rho=float(g["rho"]))
+    trainval = [("img_%05d_c%d.jpg" % (i, i % 6), i // 16, i % 6) for i in range(N)]
+    clusters = []
+    for it in range(2):
+        src = [torch.from_numpy(g["src_%d_%d" % (it, s)]) for s in range(S1)]
+        tgt = [torch.from_numpy(g["tgt_%d_%d" % (it, s)]) for s in range(S1)]
+        e_list, r_list = compute_dist(src, tgt, float(g["lambda_value"]), False)
+        assert e_list == [[]] * S1
+        labels, clusters = generate_selflabel(e_list, r_list, it, args, clusters)
+        assert len(clusters) == S1
+        for s in range(S1):
+            assert clusters[s].eps == float(g["eps_%d" % s]), (it, s)
+            assert np.array_equal(np.asarray(labels[s]).astype(np.int64), g["labels_%d_%d" % (it, s)]), (it, s)
+            f = r_list[s].final_dist().cpu().numpy()
+            assert f.dtype == np.float64 and hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest() == str(g["sha_final_%d_%d" % (it, s)]), (it, s)
+        ds = generate_dataset(trainval, labels, iter_n=it)
+        assert [int(f[4:9]) for f, _, _ in ds] == g["kept_%d" % it].tolist() and all(c == 0 for _, _, c in ds)
+        assert np.array_equal(np.array([[int(x) for x in lab] for _, lab, _ in ds], np.int64).reshape(len(ds), S1), g["kept_labels_%d" % it])
+
+
 def test_nan_path_is_raised(dev):
     """reid/rerank.py:40 divides by max(source_dist_vec)==0 -> NaN; the build raises instead."""
     from ssg_amd import rerank

@@ -244,6 +244,32 @@ def _random_jpeg(rng, h, w, kind, **kw):
     return data, np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
 
 
+def test_selftraining_fixture_oracle_and_host_join(golden, ora):
+    """The fixture written by the reference's own compute_dist / generate_selflabel / generate_dataloader (selftraining.py:255-331,
+    tools/make_golden.py selftraining_fixture): the oracle reproduces final_dist, eps (iteration 0) and the labels of both iterations
+    (iteration 1 with the frozen eps), and the product's HOST-side join (ssg_amd.selftraining.generate_dataset, no GPU) rebuilds the
+    dataset the reference handed to its Preprocessor."""
+    import ssg_amd  # noqa: F401  (package alias)
+    from ssg_amd.selftraining import generate_dataset
+    g = golden("selftraining_ref.npz")
+    N, S1, lam, rho = int(g["N"]), int(g["splits"]), float(g["lambda_value"]), float(g["rho"])
+    trainval = [("img_%05d_c%d.jpg" % (i, i % 6), i // 16, i % 6) for i in range(N)]
+    for it in range(2):
+        labels = []
+        for s in range(S1):
+            _, f = ora.re_ranking(g["src_%d_%d" % (it, s)], g["tgt_%d_%d" % (it, s)], lambda_value=lam)
+            assert hashlib.sha256(np.ascontiguousarray(f).tobytes()).hexdigest() == str(g["sha_final_%d_%d" % (it, s)]), (it, s)
+            if it == 0:
+                assert ora.eps_rule(f, rho)[0] == float(g["eps_%d" % s])
+            lab = ora.dbscan(f, float(g["eps_%d" % s]), 4)
+            assert np.array_equal(lab, g["labels_%d_%d" % (it, s)]), (it, s)
+            labels.append(g["labels_%d_%d" % (it, s)])
+        ds = generate_dataset(trainval, labels)
+        assert [int(f[4:9]) for f, _, _ in ds] == g["kept_%d" % it].tolist() and all(c == 0 for _, _, c in ds)
+        assert np.array_equal(np.array([[int(x) for x in lab] for _, lab, _ in ds], np.int64).reshape(len(ds), S1), g["kept_labels_%d" % it])
+        assert 0 < len(ds) < N
+
+
 def test_jpeg_oracle_vs_golden_and_pillow(golden):
     """oracle/jpeg_oracle.py (numpy restatement of libjpeg's default decompression) == the committed Pillow outputs, and == Pillow
     itself on freshly generated files (sizes that are not MCU multiples, all three chroma layouts, restart intervals)."""

@@ -8,8 +8,9 @@ oracle disagrees with the reference on any fixture.
 
 Reference entry points exercised (paths relative to /root/reference):
   reid/rerank.py:27-127   re_ranking       (loaded by path; needs only numpy+scipy)
-  selftraining.py:289-293 epsilon rule     (restated verbatim below: selftraining.py imports
-                                            torchvision at :14, which this image lacks)
+  selftraining.py:289-293 epsilon rule     (restated verbatim below for the per-stage fixtures; selftraining_fixture() runs the
+                                            reference's own compute_dist / generate_selflabel / generate_dataloader, imported
+                                            under the stub modules of import_reid(): selftraining.py needs torchvision at :14)
   selftraining.py:295,306 sklearn.cluster.DBSCAN(eps, min_samples=4, metric='precomputed')
 Stage boundaries inside re_ranking (V, V_qe, jaccard) are captured with sys.settrace on the
 reference frame -- no source edit, no copy.
@@ -461,6 +462,62 @@ def wide_fixture(mod):
     return all(chk.values()) and not quirky
 
 
+def selftraining_fixture():
+    """a6 / a8 / a9 / a10 through the reference's OWN functions: /root/reference/selftraining.py imported by path under the stub modules of
+    import_reid() (it needs torchvision at :14), then compute_dist (:255-277), generate_selflabel (:280-313; iteration 0 = eps rule +
+    cached estimators, iteration 1 = the cached estimators on new distances, eps frozen) and generate_dataloader (:315-331; the
+    DataLoader / Preprocessor / RandomIdentitySampler it wraps around the joined dataset are replaced by recorders through the
+    module's globals -- no source edit) on 3 splits of synthetic embeddings.  The oracle is checked against every output."""
+    import types
+    import torch
+    import_reid()
+    spec = importlib.util.spec_from_file_location("ref_selftraining", os.path.join(REF, "selftraining.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    m.print = lambda *a, **k: None
+    sys.modules["reid.rerank"].print = lambda *a, **k: None
+    seen = {}
+    m.Preprocessor = lambda dataset, root=None, transform=None: seen.setdefault("dataset", list(dataset))
+    m.RandomIdentitySampler = lambda dataset, num_instances: None
+    m.DataLoader = lambda ds, **kw: "loader"
+    N, Ns, d, lam, rho, S1 = 200, 150, 64, 0.1, 6e-2, 3
+    args = types.SimpleNamespace(no_rerank=False, rho=rho, batch_size=32, num_instances=4)
+    rec = dict(N=N, Ns=Ns, d=d, lambda_value=lam, rho=rho, splits=S1)
+    ok = True
+    cluster_list = []
+    for it in range(2):
+        tgt = [clustered(N, d, 300 + 10 * it + s, intra=0.35) for s in range(S1)]
+        src = [clustered(Ns, d, 1300 + 10 * it + s, intra=0.6) for s in range(S1)]
+        e_list, r_list = m.compute_dist([torch.from_numpy(x) for x in src], [torch.from_numpy(x) for x in tgt], lam, False)
+        assert e_list == [[]] * S1 and len(r_list) == S1 and r_list[0].dtype == np.float64
+        labels_list, cluster_list = m.generate_selflabel(e_list, r_list, it, args, cluster_list)
+        for s in range(S1):
+            rec["src_%d_%d" % (it, s)] = src[s]; rec["tgt_%d_%d" % (it, s)] = tgt[s]
+            rec["labels_%d_%d" % (it, s)] = np.asarray(labels_list[s]).astype(np.int64)
+            rec["sha_final_%d_%d" % (it, s)] = sha(r_list[s])
+            _, of = ora.re_ranking(src[s], tgt[s], lambda_value=lam)
+            good = beq(r_list[s], of)
+            if it == 0:
+                rec["eps_%d" % s] = np.float64(cluster_list[s].eps)
+                oeps, _, _ = ora.eps_rule(of, rho)
+                good = good and float(cluster_list[s].eps) == oeps
+            good = good and beq(np.asarray(labels_list[s]).astype(np.int64), ora.dbscan(of, float(cluster_list[s].eps), 4))
+            ok = ok and bool(good)
+        trainval = [("img_%05d_c%d.jpg" % (i, i % 6), i // 16, i % 6) for i in range(N)]
+        seen.clear()
+        loader = m.generate_dataloader(types.SimpleNamespace(trainval=trainval, images_dir="/nowhere"), labels_list, None, it, args)
+        assert loader == "loader"
+        ds = seen["dataset"]
+        rec["kept_%d" % it] = np.array([int(f[4:9]) for f, _, _ in ds], np.int64)
+        rec["kept_labels_%d" % it] = np.array([[int(x) for x in lab] for _, lab, _ in ds], np.int64).reshape(len(ds), S1)
+        assert all(c == 0 for _, _, c in ds)
+        print("selftraining it=%d: ids per split %s, %d of %d images kept, oracle==reference: %s" % (
+            it, [len(set(l.tolist())) - (1 if -1 in l else 0) for l in labels_list], len(ds), N, ok))
+    assert len(cluster_list) == S1                      # iteration 1 reused the cached estimators (eps frozen)
+    np.savez_compressed(os.path.join(OUT, "selftraining_ref.npz"), **rec)
+    return ok
+
+
 def preprocess_fixture():
     """tests/golden/preprocess.npz: decoded-image inputs and what the reference's extraction transform makes of them
     (selftraining.py:43-47 via reid/utils/data/preprocessor.py:22-30).  The resize is run with PIL itself (what
@@ -508,6 +565,11 @@ def main():
         ok = pairwise_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
         sys.exit(0 if ok else 1)
+    if "--only-selftraining" in sys.argv:  # regenerate just tests/golden/selftraining_ref.npz
+        ora.build(force=False)
+        ok = selftraining_fixture()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     if "--only-eval" in sys.argv:         # regenerate just tests/golden/eval_cases.npz
         ok = eval_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
@@ -526,6 +588,7 @@ def main():
     ok = tiefree_fixture(mod)
     ok = variant_fixtures(mod) and ok
     ok = preprocess_fixture() and ok
+    ok = selftraining_fixture() and ok
 
     # ---- half exp table of this host's numpy + the exceptions vs correct rounding
     allh, npx, cr, bad = exp_quirk_inputs()
