@@ -226,6 +226,50 @@ def test_triplet_pairwise_block_backward_vs_torch():
     assert xc.grad is not None and xc.grad.device.type == "cpu"
 
 
+@pytest.mark.gpu
+def test_triplet_block_inside_the_references_loss_vs_golden(golden):
+    """tests/golden/triplet_ref.npz = the reference's own TripletLoss (reid/loss/triplet.py:11-77, float64, both mining modes) on seeded
+    batches: loss, precision, d loss / d features.  Here `ssg_amd.triplet.pairwise_dist` stands where lines :28-31 stand, the mining and
+    MarginRankingLoss of :32-77 follow in torch -- the loss, the precision and the gradient that reaches the features agree with the
+    reference's numbers to float32 accuracy."""
+    from ssg_amd import triplet
+    g = golden("triplet_ref.npz")
+
+    def mine(dist, targets, semi, K=4):
+        n = dist.shape[0]
+        mask = targets.expand(n, n).eq(targets.expand(n, n).t())
+        ap, an = [], []
+        if semi:                                                    # triplet.py:48-55
+            for i in range(n // K):
+                for j in range(K):
+                    row = i * K + j
+                    neg = dist[row][mask[row] == 0].min().view(1)
+                    for pair in range(j + 1, K):
+                        ap.append(dist[row][i * K + pair].view(1)); an.append(neg)
+        else:                                                       # triplet.py:57-61
+            for i in range(n):
+                ap.append(dist[i][mask[i]].max().view(1)); an.append(dist[i][mask[i] == 0].min().view(1))
+        ap, an = torch.cat(ap), torch.cat(an)
+        loss = torch.nn.functional.margin_ranking_loss(an, ap, torch.ones_like(an), margin=0.5)
+        return loss, float((an.detach() > ap.detach()).sum()) / an.shape[0]
+
+    for ci in range(int(g["cases"])):
+        x = torch.from_numpy(g["x_%d" % ci]); targets = torch.from_numpy(g["targets_%d" % ci]).cuda()
+        for semi in (True, False):
+            tag = "%d_%s" % (ci, "semi" if semi else "ohem")
+            xg = x.clone().cuda().requires_grad_(True)
+            dist = triplet.pairwise_dist(xg)
+            loss, prec = mine(dist, targets, semi)
+            loss.backward()
+            ref = torch.from_numpy(g["grad_" + tag]).double()
+            # float32 distances of magnitude max(dist) carry ~1e-7 * max(dist) each; the loss is a mean of differences of two of them
+            lerr = abs(float(loss.detach()) - float(g["loss_" + tag]))
+            assert lerr < 1e-6 * max(1.0, float(dist.detach().max())), (tag, lerr, float(dist.detach().max()))
+            assert abs(prec - float(g["prec_" + tag])) < 1e-7, tag              # (the reference holds it as a float32 tensor)
+            err = float((xg.grad.cpu().double() - ref).abs().max())
+            assert err < 3e-5 * max(float(ref.abs().max()), 1e-3), (tag, err)
+
+
 # ------------------------------------------------------------------ fused embedding kernels: shape gating (host functions, CPU)
 def test_fused_kernel_shape_gates():
     """ssg_stem_pool_supported / ssg_bottleneck_supported decide between the fused kernels and the launch-per-layer path; the

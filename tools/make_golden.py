@@ -518,6 +518,36 @@ def selftraining_fixture():
     return ok
 
 
+def triplet_fixture():
+    """f4 (triplet block): the reference's OWN TripletLoss (reid/loss/triplet.py:11-77, both mining modes: `use_semi` and plain
+    hardest-positive / hardest-negative) run in float64 on seeded batches -- loss, precision and the gradient with respect to the
+    features.  The product replaces lines :28-31 of its forward (ssg_amd.triplet.pairwise_dist); the GPU test feeds that block into the
+    same mining and compares with these numbers."""
+    import warnings
+    import torch
+    import_reid()
+    from reid.loss import TripletLoss
+    rec = {}
+    g = torch.Generator().manual_seed(21)
+    cases = ((32, 2048), (96, 500), (32, 37))
+    for ci, (n, d) in enumerate(cases):
+        x = torch.randn(n, d, generator=g) * 0.3
+        targets = torch.arange(n) // 4
+        rec["x_%d" % ci] = x.numpy(); rec["targets_%d" % ci] = targets.numpy()
+        for semi in (True, False):
+            xr = x.clone().double().requires_grad_(True)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                loss, prec = TripletLoss(margin=0.5, num_instances=4, use_semi=semi)(xr, targets, 0)
+                loss.backward()
+            tag = "%d_%s" % (ci, "semi" if semi else "ohem")
+            rec["loss_" + tag] = np.float64(loss.item()); rec["prec_" + tag] = np.float64(float(prec)); rec["grad_" + tag] = xr.grad.numpy().astype(np.float32)
+            print("triplet n=%d d=%d %s: loss %.6f prec %.4f" % (n, d, "semi" if semi else "ohem", loss.item(), float(prec)))
+    rec["cases"] = len(cases)
+    np.savez_compressed(os.path.join(OUT, "triplet_ref.npz"), **rec)
+    return True
+
+
 def preprocess_fixture():
     """tests/golden/preprocess.npz: decoded-image inputs and what the reference's extraction transform makes of them
     (selftraining.py:43-47 via reid/utils/data/preprocessor.py:22-30).  The resize is run with PIL itself (what
@@ -565,6 +595,10 @@ def main():
         ok = pairwise_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
         sys.exit(0 if ok else 1)
+    if "--only-triplet" in sys.argv:      # regenerate just tests/golden/triplet_ref.npz
+        ok = triplet_fixture()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     if "--only-selftraining" in sys.argv:  # regenerate just tests/golden/selftraining_ref.npz
         ora.build(force=False)
         ok = selftraining_fixture()
@@ -589,6 +623,7 @@ def main():
     ok = variant_fixtures(mod) and ok
     ok = preprocess_fixture() and ok
     ok = selftraining_fixture() and ok
+    ok = triplet_fixture() and ok
 
     # ---- half exp table of this host's numpy + the exceptions vs correct rounding
     allh, npx, cr, bad = exp_quirk_inputs()
