@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 4 : 2) void source_bound_kernel(con
 constexpr int TB = 256;
 __global__ __launch_bounds__(512, 1) void source_bound_dma_kernel(const _Float16* __restrict__ X, const _Float16* __restrict__ Y, int M, int Npad, int K,
                                                                   const float* __restrict__ rowterm, const float* __restrict__ colterm, float acc_scale,
-                                                                  float* __restrict__ tilemin, int tmin_ld) {
+                                                                  float* __restrict__ tilemin, int tmin_ld, int gran4) {
   constexpr int NS = 4, XB = TB * 64, STAGE = 2 * XB, TDMA = 4, MT = 4, NT = 2;
   __shared__ __attribute__((aligned(1024))) unsigned char st0[STAGE];
   __shared__ __attribute__((aligned(1024))) unsigned char st1[STAGE];
@@ -239,15 +239,22 @@ __global__ __launch_bounds__(512, 1) void source_bound_dma_kernel(const _Float16
     for (int j = 0; j < NT; j++) {
       const int n0 = tn * TB + wn * 64 + j * 32;
       if (n0 >= Npad) continue;                              // (Npad is a multiple of 128, the tile of 256: the last source tile may be half empty)
-      float gq[4];
+      float mq[4], oq[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const float4 ct = *reinterpret_cast<const float4*>(colterm + n0 + 8 * q + 4 * h);
-        const float mn = fminf(fminf((rt + ct.x) - 2.f * (acc[i][j][4 * q] * acc_scale), (rt + ct.y) - 2.f * (acc[i][j][4 * q + 1] * acc_scale)),
-                               fminf((rt + ct.z) - 2.f * (acc[i][j][4 * q + 2] * acc_scale), (rt + ct.w) - 2.f * (acc[i][j][4 * q + 3] * acc_scale)));
-        gq[q] = fminf(mn, __shfl_xor(mn, 32, 64));
+        mq[q] = fminf(fminf((rt + ct.x) - 2.f * (acc[i][j][4 * q] * acc_scale), (rt + ct.y) - 2.f * (acc[i][j][4 * q + 1] * acc_scale)),
+                      fminf((rt + ct.z) - 2.f * (acc[i][j][4 * q + 2] * acc_scale), (rt + ct.w) - 2.f * (acc[i][j][4 * q + 3] * acc_scale)));
+        oq[q] = __shfl_xor(mq[q], 32, 64);                 // the other half-wave's four sources of the same 8
       }
-      if (h == 0 && m < M) *reinterpret_cast<float4*>(tilemin + (int64_t)m * tmin_ld + n0 / 8) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+      if (gran4) {
+        // 4-source granules (round 4: the float64 pass re-reads half the bytes per candidate): granule (n0 + 8 q + 4 h) / 4 = n0 / 4 + 2 q + h;
+        // half-wave 0 stores granules n0/4 + 0..3, half-wave 1 stores n0/4 + 4..7 -- one 16-byte store per lane, tmin_ld = Npad / 4
+        const float4 w = h == 0 ? make_float4(mq[0], oq[0], mq[1], oq[1]) : make_float4(oq[2], mq[2], oq[3], mq[3]);
+        if (m < M) *reinterpret_cast<float4*>(tilemin + (int64_t)m * tmin_ld + n0 / 4 + 4 * h) = w;
+      } else if (h == 0 && m < M) {
+        *reinterpret_cast<float4*>(tilemin + (int64_t)m * tmin_ld + n0 / 8) = make_float4(fminf(mq[0], oq[0]), fminf(mq[1], oq[1]), fminf(mq[2], oq[2]), fminf(mq[3], oq[3]));
+      }
     }
   }
 }

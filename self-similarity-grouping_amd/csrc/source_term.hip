@@ -7,6 +7,8 @@ namespace ssg {
 // Exact refinement of the source-term minimum: one wave per target row.  Granules (8 sources) whose float32
 // lower-bounded minimum can still beat the row's best are re-evaluated in float64 with the difference form
 // sum_k (x_k - y_k)^2 (like cdist), then half(sqrt(s)^2) as in reid/rerank.py:36-37.
+// G = sources per granule (8: every bound kernel; 4: source_bound_dma_kernel with gran4), 64 / G lanes share one source's k range.
+template <int G>
 __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restrict__ tgt, const float* __restrict__ src, const float* __restrict__ tilemin,
                                                             int ld, int ngran, float tol, int nrows, int Ns, int d, unsigned* __restrict__ rowmin) {
   const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -38,30 +40,31 @@ __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restr
     while (cand) {
       const int tt = t0 + __ffsll((long long)cand) - 1;
       cand &= cand - 1;
-      // 8 sources of the granule: lane group g = lane>>3 takes source tt*8+g, its 8 lanes split k
-      const int sidx = tt * 8 + (lane >> 3);
+      // G sources of the granule: lane group g = lane / LPS takes source tt*G+g, its LPS = 64 / G lanes split k
+      constexpr int LPS = 64 / G;
+      const int sidx = tt * G + lane / LPS;
       double acc = 0.0;
       if (sidx < Ns) {
         const float* y = src + (int64_t)sidx * d;
         // eight 16-byte pieces of x and of y in flight per lane (round 4: one pair per trip made every candidate a chain of 64 L2 / fabric
         // round trips -- the pass ran at the latency, not at the bandwidth, of the 128 KB it reads per row); same summation order
-        for (int k0 = (lane & 7) * 4; k0 < d; k0 += 256) {
+        for (int k0 = (lane & (LPS - 1)) * 4; k0 < d; k0 += 32 * LPS) {
           float4 xv[8], yv[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            const int k = min(k0 + 32 * u, d - 4);
+            const int k = min(k0 + 4 * LPS * u, d - 4);
             xv[u] = *reinterpret_cast<const float4*>(x + k); yv[u] = *reinterpret_cast<const float4*>(y + k);
           }
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            if (k0 + 32 * u >= d) break;
+            if (k0 + 4 * LPS * u >= d) break;
             const double d0 = (double)xv[u].x - (double)yv[u].x, d1 = (double)xv[u].y - (double)yv[u].y, d2 = (double)xv[u].z - (double)yv[u].z,
                          d3 = (double)xv[u].w - (double)yv[u].w;
             acc += d0 * d0; acc += d1 * d1; acc += d2 * d2; acc += d3 * d3;
           }
         }
       }
-      for (int sh = 1; sh < 8; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
+      for (int sh = 1; sh < LPS; sh <<= 1) acc += __shfl_xor(acc, sh, 64);
       if (sidx < Ns) {
         const double dist = sqrt(acc);
         const unsigned hb = d2h(dist * dist);     // np.power(cdist, 2).astype(float16)
@@ -90,29 +93,43 @@ static int source_rowmin_filtered_impl(const float* tgt, const float* src, int n
     return SSG_ERR_INVALID;
   }
   float* rowterm = ws; float* colterm = ws + nrows; float* tilemin = colterm + Ns_pad;
-  const int ntiles = Ns_pad / 8;   // 8-source granules
+  int ntiles = Ns_pad / 8;   // 8-source granules
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
   hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
   if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
   const bool split = scale_t > 0.f && scale_s > 0.f;
   if (split && one_product && (Ns_pad % 128) == 0 && (d % sbound::BK) == 0) {
     // bound pass as a plain fp16 GEMM on half copies of the scaled operands (source_bound.hip): 2 bytes per element, 1 product
+    static int sb_dma = -1;                 // SSG_SB_DMA=0: the register-staged 128 x 128 kernel
+    if (sb_dma < 0) { const char* e = getenv("SSG_SB_DMA"); sb_dma = e ? atoi(e) : 1; }
+    static int sb_gran = -1;                // SSG_SB_GRAN=8: 8-source granules everywhere
+    if (sb_gran < 0) { const char* e = getenv("SSG_SB_GRAN"); sb_gran = e ? atoi(e) : 4; }
+    // 4-source granules halve what the float64 pass re-reads per candidate (it runs at the L2 <- fabric rate: 0.46 -> 0.26 ms at the bench's
+    // shape) and double the bounds table; used when that table still fits the documented workspace next to the half copies (which need
+    // only half of the (nrows + Ns_pad) * d floats the split-half copies would take): always at d = 2048, not for short features
+    const int64_t doc_floats = (int64_t)nrows + Ns_pad + (int64_t)nrows * (Ns_pad / 8) + ((int64_t)nrows + Ns_pad) * d;
+    const int64_t need4 = (int64_t)nrows + Ns_pad + (int64_t)nrows * (Ns_pad / 4) + 4 + (((int64_t)nrows + Ns_pad) * d + 1) / 2;
+    const int gran4 = (sb_dma && sb_gran == 4 && need4 <= doc_floats && (int64_t)nrows * d * 2 < 0x7fffffffLL && (int64_t)Ns_pad * d * 2 < 0x7fffffffLL) ? 1 : 0;
+    if (gran4) ntiles = Ns_pad / 4;
     uintptr_t a = (uintptr_t)(tilemin + (int64_t)nrows * ntiles); a = (a + 15) & ~(uintptr_t)15;
     _Float16* x16 = (_Float16*)a; _Float16* y16 = x16 + (int64_t)nrows * d;
     hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, tgt, x16, (int64_t)nrows * d / 4, scale_t);
     hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, src, y16, (int64_t)Ns_pad * d / 4, scale_s);
-    static int sb_dma = -1;                 // SSG_SB_DMA=0: the register-staged 128 x 128 kernel
-    if (sb_dma < 0) { const char* e = getenv("SSG_SB_DMA"); sb_dma = e ? atoi(e) : 1; }
     if (sb_dma && (int64_t)nrows * d * 2 < 0x7fffffffLL && (int64_t)Ns_pad * d * 2 < 0x7fffffffLL) {     // (operands go through 2 GiB buffer resources)
       const int tiles = ((nrows + sbound::TB - 1) / sbound::TB) * ((Ns_pad + sbound::TB - 1) / sbound::TB);
       hipLaunchKernelGGL(sbound::source_bound_dma_kernel, dim3(tiles), dim3(512), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
-                         1.f / (scale_t * scale_s), tilemin, ntiles);
+                         1.f / (scale_t * scale_s), tilemin, ntiles, gran4);
+      if (gran4) {
+        hipLaunchKernelGGL(source_refine_kernel<4>, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
+        SSG_LAUNCH_CHECK("source_bound / source_refine kernels");
+        return SSG_OK;
+      }
     } else {
       const int tiles = ((nrows + sbound::BM - 1) / sbound::BM) * (Ns_pad / sbound::BN);
       hipLaunchKernelGGL(sbound::source_bound_kernel, dim3(tiles), dim3(256), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
                          1.f / (scale_t * scale_s), tilemin, ntiles);
     }
-    hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
+    hipLaunchKernelGGL(source_refine_kernel<8>, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
     SSG_LAUNCH_CHECK("source_bound / source_refine kernels");
     return SSG_OK;
   }
@@ -133,7 +150,7 @@ static int source_rowmin_filtered_impl(const float* tgt, const float* src, int n
   int rc = split ? ((Ns_pad % 256) == 0 ? launch_conv_wide(p, stream) : launch_conv_bk<128, 128, 64, 64, false, 32, true>(p, stream))
                  : launch_conv<128, 128, 64, 64, false>(p, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(source_refine_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
+  hipLaunchKernelGGL(source_refine_kernel<8>, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, src, tilemin, ntiles, ntiles, tol, nrows, Ns, d, rowmin);
   SSG_LAUNCH_CHECK("source_refine_kernel");
   return SSG_OK;
 }

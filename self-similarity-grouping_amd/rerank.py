@@ -161,7 +161,7 @@ def range_stats(tgt, src=None):
 def source_vector(src, tgt, row0=0, nrows=None, exact_gemm=None, stats=None):
     """reid/rerank.py:35-40 on device -> (rowmin uint32-as-int32 [nrows]) for a row block.
 
-    Default: filter-and-refine (a matrix-core pass bounds every distance per 8-source granule -- split-half
+    Default: filter-and-refine (a matrix-core pass bounds every distance per 4- or 8-source granule -- split-half
     operands on the fp16 cores, or float32 MFMA with SSG_SOURCE_BOUND=f32 -- then float64 re-evaluates the
     granules that can still hold the minimum): the exact minimum of the half-rounded float64 distances
     at a fraction of the cost of the full float64 Gram.  exact_gemm=True (or SSG_SOURCE_EXACT_GEMM=1)
