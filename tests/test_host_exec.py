@@ -53,6 +53,7 @@ def hx(tmp_path_factory):
                                           cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_v_normalize_kernel"))
     (d / "cc_cut.inc").write_text(cut("cluster.hip", "// ------------------------------------------------------------------ K12 union-find", stop="}  // namespace ssg"))
     (d / "split_cut.inc").write_text(cut("conv.hip", "__device__ __forceinline__ unsigned pack_h2", stop="struct ConvParams"))
+    (d / "pool_cut.inc").write_text(cut("conv.hip", "__device__ __forceinline__ void h8l8_load8", stop="// out = (a + b) / ||a + b||_2 per row"))
     so = str(d / "libhx.so")
     r = subprocess.run([CLANG, "-x", "hip", "--offload-host-only", "-O2", "-shared", "-fPIC", "-I/opt/rocm/include", "-I" + str(d), "-o", so,
                         os.path.join(ROOT, "tools", "hostexec", "scalar_rules.cpp")], capture_output=True, text=True)
@@ -290,3 +291,34 @@ def test_split_half_format_carries_22_bits(hx):
     with np.errstate(all="ignore"):
         hx.hx_split(_p(big), ctypes.c_long(4), _p(hi), _p(lo), _p(dec), _p(nf4))
     assert nf4.tolist() == [1, 1, 1, 0]
+
+
+def test_pooling_kernels_on_host_vs_torch(hx):
+    """The embedding's non-GEMM layers on split-half tensors (conv.hip, executed by one host thread): encode -> 3x3 stride-2 max pooling
+    (pad 1) -> decode is EXACTLY torch's max_pool2d of the decoded input (base.py:104 maxpool), and the global + stripe average
+    pooling (resnet.py:93-111) equals avg_pool2d over the whole map and over each of the S row stripes to float32 summation accuracy."""
+    import torch
+    rng = np.random.default_rng(13)
+    B, H, W, C = 2, 14, 10, 16
+    x = rng.standard_normal((B, H, W, C)).astype(np.float32) * 3
+    enc = np.empty_like(x); dec = np.empty_like(x)
+    hx.hx_h8l8_encode(_p(x), _p(enc), ctypes.c_long(x.size))
+    hx.hx_h8l8_decode(_p(enc), _p(dec), ctypes.c_long(x.size))
+    assert np.all(np.abs(dec - x) <= np.abs(x) * 2.0 ** -22 + 2.0 ** -25)
+    OH, OW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = np.empty((B, OH, OW, C), np.float32); out_dec = np.empty_like(out)
+    hx.hx_maxpool_h8l8(_p(enc), _p(out), B, H, W, C, OH, OW)
+    hx.hx_h8l8_decode(_p(out), _p(out_dec), ctypes.c_long(out.size))
+    ref = torch.nn.functional.max_pool2d(torch.from_numpy(dec).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).numpy()
+    assert np.array_equal(out_dec, ref)                       # (re-encoding a decoded value is exact: hi + lo is its own split)
+    for S in (0, 2, 7):
+        nsets = S + 1 if S > 1 else 1
+        g = np.empty((nsets, B, C), np.float32)
+        hx.hx_gap_h8l8(_p(enc), _p(g), B, H, W, C, S)
+        t = torch.from_numpy(dec).permute(0, 3, 1, 2).double()
+        want = [t.mean(dim=(2, 3))]
+        if S > 1:
+            hs = H // S
+            want += [t[:, :, hs * k:hs * (k + 1)].mean(dim=(2, 3)) for k in range(S)]
+        want = torch.stack(want).numpy()
+        assert np.abs(g - want).max() < 2e-6 * np.abs(want).max() + 1e-7, S

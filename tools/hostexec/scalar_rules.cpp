@@ -52,6 +52,7 @@ namespace ssg {
 #include "preprocess_cut.inc"
 #include "cc_cut.inc"
 #include "split_cut.inc"
+#include "pool_cut.inc"
 }
 using namespace ssg;
 
@@ -115,5 +116,11 @@ void hx_split(const float* in, long n4, uint32_t* hi, uint32_t* lo, float* dec, 
     dec[4 * i] = d.x; dec[4 * i + 1] = d.y; dec[4 * i + 2] = d.z; dec[4 * i + 3] = d.w;
   }
 }
+// the non-GEMM layers of the embedding on split-half tensors (conv.hip; grid-stride, one thread here): n floats <-> h8l8, 3x3 / 2 max
+// pooling, global + stripe average pooling
+void hx_h8l8_encode(const float* in, float* out, long n) { h8l8_encode_kernel(in, out, n / 8, 1.f); }
+void hx_h8l8_decode(const float* in, float* out, long n) { h8l8_decode_kernel(in, out, n / 8, 1.f); }
+void hx_maxpool_h8l8(const float* in, float* out, int B, int H, int W, int C, int OH, int OW) { maxpool3x3s2_h8l8_kernel(in, out, B, H, W, C, OH, OW); }
+void hx_gap_h8l8(const float* in, float* out, int B, int H, int W, int C, int S) { gap_stripes_h8l8_kernel(in, out, B, H, W, C, S); }
 void hx_units24(const uint32_t* h, long n, long long* out) { for (long i = 0; i < n; i++) out[i] = half_units24(h[i]); }
 }
