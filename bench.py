@@ -247,13 +247,16 @@ def main():
     timer = KernelTimer(_lib.lib())
     _lib._lib = timer
 
-    # ---- inputs resident in HBM before the timed region.  Every rank holds the whole synthetic image set (11.4 GB; same seed), the
-    # product API (`extract_embeddings(..., group=)`) shards the batches over the ranks and all-gathers the embeddings
+    # ---- inputs resident in HBM before the timed region.  Every rank generates and holds ONLY its own block of the synthetic image
+    # sets (the `shard_bounds` block the product API `extract_embeddings(..., group=)` hands it: 11.4 GB / world; seed 1 + rank, so one
+    # GPU sees the same images as before) -- start-up work and memory no longer grow with the number of ranks
     model = ssg_amd.create("resnet50", num_classes=0, num_split=1, cluster=False, seed=1, pretrained=False).cuda(local).eval()
     precision = model.precision
-    g = torch.Generator(device=dev).manual_seed(1)
-    tgt_imgs = torch.randn(args.N, 3, 256, 128, generator=g, device=dev)
-    src_imgs = torch.randn(args.Ns, 3, 256, 128, generator=g, device=dev)
+    g = torch.Generator(device=dev).manual_seed(1 + rank)
+    t_lo, t_hi = sdist.shard_bounds(args.N, rank, world)
+    s_lo, s_hi = sdist.shard_bounds(args.Ns, rank, world)
+    tgt_imgs = torch.randn(t_hi - t_lo, 3, 256, 128, generator=g, device=dev)
+    src_imgs = torch.randn(s_hi - s_lo, 3, 256, 128, generator=g, device=dev)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import synth
     gens = {"hard": synth.hard_clustered, "separable": synth.clustered}
@@ -268,7 +271,7 @@ def main():
 
         def shard(self, r, w):
             s_ = super().shard(r, w)
-            return TimedLoader(s_.images, s_.batch_size, s_.fnames, s_.pids, s_.first, s_.count)
+            return TimedLoader(s_.images, s_.batch_size, s_.fnames, s_.pids, s_.first, s_.count, s_.base)
 
         def __iter__(self):
             for bi, batch in enumerate(super().__iter__()):
@@ -281,7 +284,10 @@ def main():
                 yield batch
             timer.sample = True; model.flip_streams = True
 
-    tgt_loader, src_loader = TimedLoader(tgt_imgs, args.batch), TimedLoader(src_imgs, args.batch)
+    # the loaders describe the WHOLE sets (count = N / Ns: block lengths and names of every rank follow from it); a rank's resident block
+    # starts at item `base`
+    tgt_loader = TimedLoader(tgt_imgs, args.batch, count=args.N, base=t_lo)
+    src_loader = TimedLoader(src_imgs, args.batch, count=args.Ns, base=s_lo)
     imgs_rank = tgt_loader.shard(rank, world).num_items() + src_loader.shard(rank, world).num_items()
 
     def step():
@@ -367,6 +373,54 @@ def main():
         extras["grouping_other_track"] = {"track": other, "rerank_dbscan_ms": round(t_other, 3), "clusters": int(l_o.max() + 1),
                                           "noise": int((l_o < 0).sum()), "eps": e_o}
         del so, to
+        # (d) the LITERAL drop-in chain INTEGRATION.md section 1 tells a maintainer to call, next to the fused path the timed region runs
+        # ("API materialisation timed and reported separately"): extract_features -> OrderedDict of N CPU tensors
+        # (reid/evaluators.py:18-60) -> the reorder + stack loop of selftraining.py:197-209 -> compute_dist (CPU tensors in: re-upload)
+        # -> generate_selflabel; and re_ranking's numpy return (rerank.py:27: float16 euclidean_dist + float64 final_dist on the host)
+        import contextlib
+        import io
+        from types import SimpleNamespace
+        from ssg_amd import selftraining
+        names_t = ["t%06d.jpg" % i for i in range(args.N)]; names_s = ["s%06d.jpg" % i for i in range(args.Ns)]
+        quiet = contextlib.redirect_stdout(io.StringIO())
+        torch.cuda.synchronize(); c0 = time.perf_counter()
+        tf, _ = evaluators.extract_features(model, evaluators.TensorBatchLoader(tgt_imgs, args.batch, names_t), print_freq=0, for_eval=False)
+        sf, _ = evaluators.extract_features(model, evaluators.TensorBatchLoader(src_imgs, args.batch, names_s), print_freq=0, for_eval=False)
+        c1 = time.perf_counter()
+        target_features = torch.cat([tf[f].unsqueeze(0) for f in names_t], 0)
+        source_features = torch.cat([sf[f].unsqueeze(0) for f in names_s], 0)
+        c2 = time.perf_counter()
+        assert target_features.shape == (args.N, 2048) and source_features.shape == (args.Ns, 2048) and not target_features.is_cuda
+        del tf, sf, target_features, source_features
+        # (the grouping calls get the clustered track as CPU tensors -- the form the reference holds its stacked features in; the
+        # embedder's own output on N(0,1) images is degenerate, see `legs`)
+        src_cpu, tgt_cpu = torch.from_numpy(emb_np[args.track_g][0]), torch.from_numpy(emb_np[args.track_g][1])
+        ns_args = SimpleNamespace(no_rerank=False, rho=args.rho)
+        with quiet:
+            selftraining.generate_selflabel(*selftraining.compute_dist(src_cpu, tgt_cpu, lambda_value=args.lambda_value, no_rerank=False, num_split=1), 0, ns_args, [])
+        torch.cuda.synchronize(); c3 = time.perf_counter()
+        e_l, r_l = selftraining.compute_dist(src_cpu, tgt_cpu, lambda_value=args.lambda_value, no_rerank=False, num_split=1)
+        torch.cuda.synchronize(); c4 = time.perf_counter()
+        with quiet:
+            lab_l, _ = selftraining.generate_selflabel(e_l, r_l, 0, ns_args, [])
+        c5 = time.perf_counter()
+        del e_l, r_l
+        with quiet:
+            eu_np, fin_np = rerank.re_ranking(emb_np[args.track_g][0], emb_np[args.track_g][1], k1=20, k2=6, lambda_value=args.lambda_value)
+        c6 = time.perf_counter()
+        with quiet:        # the reference's own consumer of that matrix (selftraining.py:280-313): the array still carries its device handle
+            lab_n, _ = selftraining.generate_selflabel([[]], [fin_np], 0, ns_args, [])
+        c7 = time.perf_counter()
+        extras["dropin_chain"] = {
+            "what": "untimed-region cost of the literal drop-in surface (INTEGRATION.md section 1) beside the fused device path of the timed region, seconds",
+            "extract_features_dicts_s": round(c1 - c0, 4), "extract_images": args.N + args.Ns,
+            "stack_loop_selftraining_197_209_s": round(c2 - c1, 4),
+            "compute_dist_from_cpu_tensors_s": round(c4 - c3, 5), "generate_selflabel_s": round(c5 - c4, 5),
+            "re_ranking_numpy_return_s": round(c6 - c5, 4), "re_ranking_numpy_return_bytes": int(eu_np.nbytes + fin_np.nbytes),
+            "generate_selflabel_on_numpy_final_dist_s": round(c7 - c6, 5),
+            "labels_equal_fused": bool(np.array_equal(lab_l[0], labels)) and bool(np.array_equal(lab_n[0], labels)),
+            "fused_path_for_comparison_s": {"embed": round(t_embed * 1e-3, 4), "rerank_eps_dbscan": round((t_rerank + t_cluster) * 1e-3, 5)}}
+        del eu_np, fin_np
 
     # host round trips and collectives of one grouping leg (re-rank + eps rule + DBSCAN), counted on an extra untimed pass -- on every
     # rank, at any world size (the sharded path adds its own blocking reads: sizes of the ragged candidate / edge blocks)

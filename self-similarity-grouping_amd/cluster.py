@@ -109,8 +109,9 @@ def _eps_rule_sampled(L, h, rho, st):
         import torch.distributed as dist
         table = gather_rows(local.view(1, -1), h.group).tolist()                                                # host round trip 1
         vals = list(table[dist.get_rank(h.group)])
-        if npend >= 2:
-            vals[4] = max(int(r[4]) for r in table)      # a digit overflow on ANY rank raises on every rank (no rank left waiting in a collective)
+        if pend is not None:
+            # a digit overflow / a missed query-expansion guess on ANY rank is seen by every rank (no rank left waiting in a collective)
+            vals[3:] = h.global_status(None, table=table, first=3)
         gots = [int(r[0]) for r in table]
         zeros_all, got_all, overflow = sum(int(r[1]) for r in table), sum(gots), int(any(g > n_cap for g in gots))
     else:
@@ -230,9 +231,13 @@ class DBSCAN:
         dev, st, N = h.device, stream(), h.N
         eps = float(self.eps)
         cnt = torch.empty(h.nrows, dtype=torch.int32, device=dev)
-        cap = max(64 * h.nrows, 1 << 16)
+        mx_rows = h.nrows
+        if h.group is not None:
+            import torch.distributed as dist
+            mx_rows = -(-N // dist.get_world_size(h.group))      # the longest row block: every rank sizes its edge list alike (they travel in one flat gather)
+        cap = max(64 * mx_rows, 1 << 16)
         ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws_buf = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         labels = torch.empty(N, dtype=torch.int64, device=dev)
         if hasattr(h, "validate"):
             h.validate()
@@ -253,7 +258,7 @@ class DBSCAN:
             if h.group is None:
                 # one GPU: components and labels follow on the stream, the edge count stays on the device; ONE read-back at
                 # the end brings labels, neighbour counts and the count (which tells whether the edge list was big enough)
-                check(L.ssg_dbscan_cc_dev(ptr(cnt), ptr(edges), ptr(cursor), cap, N, int(self.min_samples), ptr(ws), ws_bytes, ptr(labels), st),
+                check(L.ssg_dbscan_cc_dev(ptr(cnt), ptr(edges), ptr(cursor), cap, N, int(self.min_samples), ptr(ws_buf), ws_bytes, ptr(labels), st),
                       "ssg_dbscan_cc_dev")
                 host = torch.cat([cursor, labels, cnt.to(torch.int64)]).cpu().numpy()
                 ne = int(host[0])
@@ -263,16 +268,22 @@ class DBSCAN:
                     break
                 cap = ne       # the cursor counted every hit: retry once with the exact size
                 continue
-            # sharded rows: ONE flat all-gather of the edge counts + ONE blocking read give this rank's count (capacity check) and the
-            # block lengths of the edge gather; the labels and the neighbour counts come back with one more read
-            from .dist import gather_ragged
-            nes = [int(x) for x in gather_rows(cursor.view(1, 1), h.group).flatten().tolist()]
+            # sharded rows: ONE flat all-gather carries every rank's edge count, neighbour counts and edge list (at the common capacity:
+            # 64 edges per row is 1 MB per rank at N = 16 000 over 8 ranks) and ONE blocking read of the counts tells every rank whether
+            # the lists were big enough and where each rank's edges end; the labels come back with one more read (round 4: two
+            # gathers -- counts, then the exact-size lists -- plus the neighbour-count gather)
+            from .dist import gather_packed, shard_bounds
+            import torch.distributed as dist
+            ws = dist.get_world_size(h.group)
+            cnt_pad = cnt if h.nrows == mx_rows else torch.cat([cnt, torch.zeros(mx_rows - h.nrows, dtype=cnt.dtype, device=dev)])
+            g_cur, g_cnt, g_edges = gather_packed([cursor.view(1), cnt_pad, edges], h.group)
+            nes = [int(x) for x in g_cur.flatten().tolist()]
             if max(nes) <= cap:
-                cnt_all = gather_rows(cnt, h.group, N)
-                import torch.distributed as dist
-                edges = gather_ragged(edges[:nes[dist.get_rank(h.group)]], nes, h.group).contiguous()
+                rows = [shard_bounds(N, r, ws) for r in range(ws)]
+                cnt_all = torch.cat([g_cnt[r, :hi - lo] for r, (lo, hi) in enumerate(rows)])
+                edges = torch.cat([g_edges[r, :nes[r]] for r in range(ws)], dim=0).contiguous()
                 ne = int(edges.shape[0])
-                check(L.ssg_dbscan_cc(ptr(cnt_all), ptr(edges), ne, N, int(self.min_samples), ptr(ws), ws_bytes, ptr(labels), st), "ssg_dbscan_cc")
+                check(L.ssg_dbscan_cc(ptr(cnt_all), ptr(edges), ne, N, int(self.min_samples), ptr(ws_buf), ws_bytes, ptr(labels), st), "ssg_dbscan_cc")
                 host = torch.cat([labels, cnt_all.to(torch.int64)]).cpu().numpy()
                 self.labels_ = host[:N].copy()
                 self.core_sample_indices_ = np.nonzero(host[N:] >= int(self.min_samples))[0]

@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <link.h>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 // One RCCL per process.  libssg_hip.so does NOT link librccl: a process that also runs torch.distributed already
@@ -27,17 +28,24 @@ struct Rccl {
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclGetVersion) GetVersion = nullptr;
   std::string path;
+  int version = 0;
   bool ok = false;
 };
 Rccl g_rccl;
+std::mutex g_rccl_mutex;        // the first collective of two threads must not race on the table (bound once, under the lock)
 
 int find_loaded_rccl(struct dl_phdr_info* info, size_t, void* out) {
   if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) { *static_cast<std::string*>(out) = info->dlpi_name; return 1; }
   return 0;
 }
 
+// ncclGetVersion's code: major * 10000 + minor * 100 + patch from 2.9 on (major * 1000 + ... before)
+int rccl_major(int code) { return code >= 10000 ? code / 10000 : code / 1000; }
+
 int rccl_bind() {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.ok) return SSG_OK;
   std::string loaded;
   dl_iterate_phdr(find_loaded_rccl, &loaded);
@@ -59,7 +67,17 @@ int rccl_bind() {
     ssg_set_error("RCCL at %s lacks an entry point", loaded.c_str());
     return SSG_ERR_HIP;
   }
-  g_rccl.path = loaded; g_rccl.ok = true;
+  // the table is typed by the build-time rccl.h: refuse a library of another major version (the five calls used here have kept
+  // their signatures inside NCCL 2.x), and say which file was bound when the process maps torch but no RCCL was found mapped
+  // (torch linking RCCL statically / under another soname would make this a second copy: SSG_RCCL_PATH overrides)
+  g_rccl.GetVersion = reinterpret_cast<decltype(g_rccl.GetVersion)>(dlsym(h, "ncclGetVersion"));
+  int code = 0;
+  if (!g_rccl.GetVersion || g_rccl.GetVersion(&code) != ncclSuccess || rccl_major(code) != rccl_major(NCCL_VERSION_CODE)) {
+    ssg_set_error("RCCL at %s reports version code %d, this library was built against %d (another major version)", loaded.c_str(), code, (int)NCCL_VERSION_CODE);
+    return SSG_ERR_HIP;
+  }
+  if (getenv("SSG_COMM_VERBOSE")) fprintf(stderr, "[ssg_comm] bound to %s (version code %d, headers %d)\n", loaded.c_str(), code, (int)NCCL_VERSION_CODE);
+  g_rccl.path = loaded; g_rccl.version = code; g_rccl.ok = true;
   return SSG_OK;
 }
 }  // namespace

@@ -247,8 +247,10 @@ __global__ __launch_bounds__(1024) void source_vec_finish_kernel(const unsigned*
 }  // namespace ssg
 
 namespace ssg {
-// one wave per row: max |x| and the row's float32 norm (inflated by 1e-5 relative so that it is an UPPER bound whatever order
-// the float32 sum of squares is taken in); non-negative floats order like their bit patterns, NaN patterns sort above +inf
+// one wave per row: max |x| and the row's float32 norm, inflated so that it is an UPPER bound whatever order the float32 sum of
+// squares is taken in: a lane sums d/64 squares sequentially (each rounded once), six cross-lane adds follow -- relative error of the
+// sum <= (d/64 + 7) * 2^-24 * 1.01 -- and the square root adds half an ulp; the factor below covers twice that, with d (a fixed
+// 1 + 1e-5 was only rigorous up to d ~ 32 k).  Non-negative floats order like their bit patterns, NaN patterns sort above +inf
 __global__ __launch_bounds__(256) void range_stats_kernel(const float* __restrict__ a, int rows_a, const float* __restrict__ b, int rows_b, int d,
                                                           unsigned* __restrict__ out4) {
   // persistent waves over the rows; 16-byte loads when the rows allow it; one atomic per wave and statistic at the very end (a
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(256) void range_stats_kernel(const float* __restric
   unsigned best[4] = {0u, 0u, 0u, 0u};
   const bool vec = (d & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | (b ? reinterpret_cast<uintptr_t>(b) : 0)) & 15) == 0;
   const int rows = rows_a + rows_b;
+  const float inflate = 1.0f + ((float)(d / 64 + 8) * 5.9604645e-8f + 1e-6f);       // (d/64 + 8) * 2^-24 on the sum >= its effect on the root; + 1e-6 slack
   // four rows per trip: their loads are all in flight before the first reduction (one row per trip left the wave waiting on its own
   // 8 KB and on twelve dependent cross-lane steps per row)
   for (int r0 = wave * 4; r0 < rows; r0 += nwaves * 4) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(256) void range_stats_kernel(const float* __restric
     for (int u = 0; u < 4; u++) {
       if (r0 + u >= rows) break;
       const bool second = r0 + u >= rows_a;
-      const unsigned nb = __float_as_uint(sqrtf(sq[u]) * 1.00001f) & 0x7fffffffu;
+      const unsigned nb = __float_as_uint(sqrtf(sq[u]) * inflate) & 0x7fffffffu;
       unsigned& bm = best[second ? 1 : 0]; bm = mx[u] > bm ? mx[u] : bm;
       unsigned& bn = best[second ? 3 : 2]; bn = nb > bn ? nb : bn;
     }

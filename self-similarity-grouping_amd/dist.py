@@ -99,6 +99,65 @@ def gather_rows(t, group, n_total=None):
     return torch.cat([buf[:rem].reshape((rem * mx,) + tail), buf[rem:, :base].reshape(((ws - rem) * base,) + tail)], dim=0)
 
 
+def gather_packed(tables, group):
+    """ONE flat all-gather for several tables at once: every table has the same shape on every rank; returns, per table, the stacked
+    [world, *shape] tensor (a strided view into the receive buffer: index / reshape it, which copies what is used).  The tables' bytes
+    travel back to back (each part aligned to 16 bytes) -- the sharded re-rank ships its three tables of a stage (index / value /
+    length rows) as one collective instead of three (VERDICT r4 next #9)."""
+    if group is None:
+        return [t.unsqueeze(0) for t in tables]
+    import torch.distributed as dist
+    ws = dist.get_world_size(group)
+    parts, spans, off = [], [], 0
+    for t in tables:
+        t = t.contiguous()
+        nb = t.numel() * t.element_size()
+        pad = (-nb) % 16
+        b = t.reshape(-1).view(torch.uint8)
+        parts.append(b)
+        if pad:
+            parts.append(torch.zeros(pad, dtype=torch.uint8, device=t.device))
+        spans.append((off, nb, t.dtype, tuple(t.shape)))
+        off += nb + pad
+    send = torch.cat(parts) if len(parts) > 1 else parts[0]
+    recv = torch.empty(ws * off, dtype=torch.uint8, device=send.device)
+    _all_gather_into(recv, send, group)
+    recv = recv.view(ws, off)
+    out = []
+    for o, nb, dt, shape in spans:
+        if nb == 0:
+            out.append(torch.empty((ws,) + shape, dtype=dt, device=send.device))
+        else:
+            out.append(recv[:, o:o + nb].view(dt).view((ws,) + shape))
+    return out
+
+
+def gather_rows_packed(tables, group, n_total):
+    """`gather_rows` for several row-sharded tables [n_r, ...] in ONE collective: the `shard_bounds` blocks of n_total rows, padded to
+    the longest block, -> the list of [n_total, ...] tables in rank order"""
+    if group is None:
+        return list(tables)
+    import torch.distributed as dist
+    ws, rk = dist.get_world_size(group), dist.get_rank(group)
+    base, rem = divmod(int(n_total), ws)
+    mx, mine = base + (1 if rem else 0), base + (1 if rk < rem else 0)
+    padded = []
+    for t in tables:
+        if t.shape[0] != mine:
+            raise ValueError("gather_rows_packed: rank %d holds %d rows, its block of %d rows over %d ranks has %d" % (rk, t.shape[0], n_total, ws, mine))
+        if mine != mx:
+            t = torch.cat([t, torch.zeros((mx - mine,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)], dim=0)
+        padded.append(t)
+    out = []
+    for t, g in zip(padded, gather_packed(padded, group)):
+        tail = tuple(t.shape[1:])
+        if rem == 0:
+            out.append(g.reshape((ws * mx,) + tail).contiguous())      # (a view when mx == 1: the kernels take dense tables)
+        else:
+            out.append(torch.cat([g[:rem].reshape((rem * mx,) + tail), g[rem:, :base].reshape(((ws - rem) * base,) + tail)], dim=0))
+    return out
+
+
 def gather_counts(n, group, device=None):
     """row count of every rank as a python list: ONE flat all-gather of an int64 + one host read"""
     if group is None:

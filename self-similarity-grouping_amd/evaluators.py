@@ -50,10 +50,12 @@ class TensorBatchLoader(object):
     `(imgs [b,3,H,W], fnames, pids, camids)` in order, like the `DataLoader(Preprocessor(...), shuffle=False)` of
     selftraining.py:49-53.  `shard(rank, world)` returns the loader of this rank's contiguous block of batches."""
 
-    def __init__(self, images, batch_size=128, fnames=None, pids=None, first=0, count=None):
+    def __init__(self, images, batch_size=128, fnames=None, pids=None, first=0, count=None, base=0):
+        # base: index (in the loader's item numbering) of images[0] -- a rank that holds only ITS block of a sharded set passes the block
+        # with base = the block's first item and count = the size of the whole set; items outside the resident block cannot be iterated
         self.images, self.batch_size = images, int(batch_size)
-        self.first = int(first)
-        self.count = int(images.shape[0] - first if count is None else count)
+        self.first, self.base = int(first), int(base)
+        self.count = int(images.shape[0] + self.base - first if count is None else count)
         self.fnames, self.pids = fnames, pids
 
     def __len__(self):
@@ -67,7 +69,7 @@ class TensorBatchLoader(object):
         leave three ranks with half the work), re-batched locally -- an image's features do not depend on its batch"""
         from .dist import shard_bounds
         i0, i1 = shard_bounds(self.count, rank, world)
-        return TensorBatchLoader(self.images, self.batch_size, self.fnames, self.pids, self.first + i0, i1 - i0)
+        return TensorBatchLoader(self.images, self.batch_size, self.fnames, self.pids, self.first + i0, i1 - i0, self.base)
 
     def listing(self):
         """(fnames, pids) of every item in loader order, without touching the images"""
@@ -77,11 +79,14 @@ class TensorBatchLoader(object):
         return names, ids
 
     def __iter__(self):
+        if self.count > 0 and (self.first < self.base or self.first + self.count > self.base + self.images.shape[0]):
+            raise IndexError("TensorBatchLoader: items [%d, %d) requested, the resident block holds [%d, %d)"
+                             % (self.first, self.first + self.count, self.base, self.base + self.images.shape[0]))
         for b0 in range(self.first, self.first + self.count, self.batch_size):
             b1 = min(b0 + self.batch_size, self.first + self.count)
             names = self.fnames[b0:b1] if self.fnames is not None else ["%08d" % i for i in range(b0, b1)]
             ids = self.pids[b0:b1] if self.pids is not None else [0] * (b1 - b0)
-            yield self.images[b0:b1], names, ids, [0] * (b1 - b0)
+            yield self.images[b0 - self.base:b1 - self.base], names, ids, [0] * (b1 - b0)
 
 
 def _rank_batches(data_loader, group):
@@ -129,29 +134,85 @@ def extract_embeddings(model, data_loader, for_eval=False, print_freq=0, group=N
     # GpuBatchLoader); a torch DataLoader has __len__ too but may shuffle: per-batch check there.
     again = (hasattr(mine, "__len__") and hasattr(mine, "listing") and hasattr(m, "_overflowed")
              and os.environ.get("SSG_EXTRACT_CHECK_EACH", "0") != "1")
+    known = hasattr(data_loader, "shard") and hasattr(data_loader, "num_items") and hasattr(data_loader, "listing")
+    # C1 overlapped with the forwards (round 5): with a loader description every rank holds, batch i of every rank is all-gathered as
+    # soon as it is embedded -- asynchronously, on the communicator's own stream -- while batch i + 1 runs; the pieces are put into
+    # loader order at the end.  (One flat gather after the last batch left the xGMI links idle during the whole extraction.)
+    ov = None
+    if group is not None and gather and known and hasattr(mine, "batch_size") and os.environ.get("SSG_EXTRACT_OVERLAP", "1") != "0":
+        import torch.distributed as dist
+        from .dist import _flat_gather_supported
+        if _flat_gather_supported(group):
+            world = dist.get_world_size(group)
+            ov = {"world": world, "bs": int(mine.batch_size), "counts": [int(data_loader.shard(r, world).num_items()) for r in range(world)], "recv": [], "work": []}
+            ov["nb"] = max((c + ov["bs"] - 1) // ov["bs"] for c in ov["counts"])
+
+    def image_major(f):
+        return f.permute(1, 0, 2).contiguous() if f.dim() == 3 else f
+
+    def post(rows, tail=None):
+        """queue the all-gather of one batch's rows (padded to the batch size; `rows` None: this rank has no batch i, zeros travel)"""
+        import torch.distributed as dist
+        send = torch.zeros((ov["bs"],) + tuple(tail if rows is None else rows.shape[1:]), dtype=torch.float32, device=m.device)
+        if rows is not None:
+            send[: rows.shape[0]] = rows
+        recv = torch.empty((ov["world"] * ov["bs"],) + tuple(send.shape[1:]), dtype=torch.float32, device=m.device)
+        ov["work"].append(dist.all_gather_into_tensor(recv, send, group=group, async_op=True))
+        ov["recv"].append(recv)
+
     for i, batch in enumerate(mine):
         imgs, names, ids = batch[0], batch[1], batch[2]
         chunks.append(m.embed_with_flip(torch.as_tensor(imgs), for_eval=for_eval, check_overflow=False) if again
                       else m.embed_with_flip(torch.as_tensor(imgs), for_eval=for_eval))
         fnames.extend(list(names)); pids.extend(list(ids))
+        if ov is not None:
+            post(image_major(chunks[-1]))
         if print_freq and (i + 1) % print_freq == 0:
             print('Extract Features: [{}/{}]\tTime {:.3f}'.format(i + 1, nb, time.time() - t0))
-    if again and m._overflowed():          # (the fp32 twin warns when it is first built)
+    nsets = (m.num_split + 1) if m.num_split > 1 else 1
+    three = nsets > 1 and not for_eval
+    if ov is not None:
+        for _ in range(len(chunks), ov["nb"]):                 # ranks with fewer batches still take part in every collective
+            post(None, (nsets, 2048) if three else (nsets * 2048,))
+    redo = bool(again and m._overflowed()) if ov is None else False
+    if ov is not None and again:
+        # the range flag of EVERY rank (one small gather + the one read the deferred check costs anyway): the pieces already travelled,
+        # so a rank that has to recompute makes every rank gather again
+        from .dist import gather_rows
+        flag = m._ovf.view(1, 1) if (m.precision == "split" and getattr(m, "_ovf", None) is not None) else torch.zeros((1, 1), dtype=torch.int32, device=m.device)
+        flags = [int(x) for x in gather_rows(flag, group).flatten().tolist()]
+        import torch.distributed as dist
+        redo = bool(flags[dist.get_rank(group)])
+        if redo:
+            m._ovf.zero_()
+        if any(flags):
+            for w in ov["work"]:
+                w.wait()
+            ov = None                                           # fall back to the single gather below, on recomputed features
+    if redo:          # (the fp32 twin warns when it is first built)
         chunks.clear()                     # the first pass's features are discarded BEFORE the second pass allocates its own
         chunks = [m._f32_twin().embed_with_flip(torch.as_tensor(batch[0]), for_eval=for_eval) for batch in mine]
     if chunks:
         feats = torch.cat(chunks, dim=1 if chunks[0].dim() == 3 else 0)
     else:       # more ranks than batches: an empty share of the right shape
-        nsets = (m.num_split + 1) if m.num_split > 1 else 1
-        feats = torch.empty((nsets, 0, 2048) if (nsets > 1 and not for_eval) else (0, nsets * 2048), dtype=torch.float32, device=m.device)
+        feats = torch.empty((nsets, 0, 2048) if three else (0, nsets * 2048), dtype=torch.float32, device=m.device)
     if group is None or not gather:
         return feats, fnames, pids
     import torch.distributed as dist
     from .dist import gather_counts, gather_ragged
-    three = feats.dim() == 3
-    rows = feats.permute(1, 0, 2).contiguous() if three else feats          # image-major rows
     world = dist.get_world_size(group)
-    known = hasattr(data_loader, "shard") and hasattr(data_loader, "num_items") and hasattr(data_loader, "listing")
+    if ov is not None:
+        for w in ov["work"]:
+            w.wait()
+        bs, parts = ov["bs"], []
+        for r, c in enumerate(ov["counts"]):                    # loader order = rank order, batch order inside a rank
+            for i in range((c + bs - 1) // bs):
+                parts.append(ov["recv"][i][r * bs: r * bs + min(bs, c - i * bs)])
+        rows = torch.cat(parts, dim=0) if parts else image_major(feats)
+        feats = rows.permute(1, 0, 2).contiguous() if three else rows
+        fnames, pids = data_loader.listing()
+        return feats, fnames, pids
+    rows = image_major(feats)          # image-major rows
     if known:
         # every rank holds the same loader description: block lengths and names follow from it, no exchange and no host round trip
         counts = [int(data_loader.shard(r, world).num_items()) for r in range(world)]

@@ -304,10 +304,42 @@ def parse_batch_python(files):
     return P
 
 
-def decode_batch(files, device=None, packed=False):
-    """list of file contents (bytes) -> list of uint8 CUDA tensors [H, W, 3] (RGB), one per file, in order.
-    packed=True: when every file was decoded on the GPU and all share one size (a Market-1501 batch), ONE tensor [B, H, W, 3] is
-    returned instead of the list (no per-file views, no stack)."""
+class PendingDecode(object):
+    """A batch whose GPU decode has been QUEUED: the pixels stay on the device, the per-image status words travel to pinned host
+    memory behind the decode on the same stream, and `result()` waits for that copy only (an event recorded right behind it) --
+    not for whatever the caller queued afterwards.  A loader that queues batch k + 1 before it asks for batch k's result
+    (`GpuBatchLoader`) therefore never waits on the GPU in the common case: the host parse of the next batch overlaps the decode and
+    transform of this one, and the blocking read per batch that a damaged file (rare) needs costs nothing when no file is damaged."""
+
+    def __init__(self, files, device, P, out, rgb=None, status_host=None, event=None):
+        self.files, self.device, self.P, self.out, self.rgb, self.status_host, self.event = files, device, P, out, rgb, status_host, event
+
+    def result(self, packed=False):
+        """list of uint8 CUDA tensors [H, W, 3] in file order -- or, with packed=True and a batch of equally sized files that were all
+        decoded on the GPU, ONE tensor [B, H, W, 3]"""
+        P, out, files = self.P, self.out, self.files
+        if not P.kept:
+            return out
+        self.event.synchronize()
+        damaged = set(np.nonzero(self.status_host.numpy())[0].tolist())
+        if packed and not damaged and not P.fallback and all(dm == P.dims[0] for dm in P.dims):
+            stats["gpu"] += len(P.kept)
+            return self.rgb.view(len(P.kept), P.dims[0][0], P.dims[0][1], 3)
+        for k, i in enumerate(P.kept):
+            if k in damaged:
+                # short / corrupt entropy-coded data: Pillow decodes (or raises "image file is truncated") exactly like the reference
+                out[i] = torch.from_numpy(np.array(_pillow_rgb(files[i]))).to(self.device)
+                stats["pillow"] += 1; stats["damaged"] = stats.get("damaged", 0) + 1
+                continue
+            o = int(P.imgs[k, 7])
+            hh, ww = P.dims[k]
+            out[i] = self.rgb[o:o + ww * hh * 3].view(hh, ww, 3)
+        stats["gpu"] += len(P.kept) - len(damaged)
+        return out
+
+
+def decode_batch_async(files, device=None):
+    """host parse + upload + the decode kernels of one batch, queued on the current stream -> PendingDecode (no device -> host wait)"""
     L = _lib.lib()
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     out = [None] * len(files)
@@ -316,7 +348,7 @@ def decode_batch(files, device=None, packed=False):
         out[i] = torch.from_numpy(np.array(_pillow_rgb(files[i]))).to(device)
         stats["pillow"] += 1
     if not P.kept:
-        return out
+        return PendingDecode(files, device, P, out)
     d = lambda a: torch.from_numpy(np.array(a)).to(device)
     pool_d, segs_d, imgs_d = d(P.pool), d(P.segs), d(P.imgs)
     look_d, maxcode_d, valoff_d, vals_d, qts_d = d(P.look), d(P.maxcode), d(P.valoff), d(P.vals), d(P.qts)
@@ -326,18 +358,15 @@ def decode_batch(files, device=None, packed=False):
     status = torch.empty(len(P.kept), dtype=torch.int32, device=device)
     check(L.ssg_jpeg_decode_batch(ptr(pool_d), ptr(segs_d), int(P.segs.shape[0]), ptr(imgs_d), len(P.kept), ptr(look_d), ptr(maxcode_d), ptr(valoff_d), ptr(vals_d),
                                   ptr(qts_d), ptr(coef), P.blocks, P.max_blocks, ptr(planes), P.max_pixels, ptr(rgb), ptr(status), stream()), "ssg_jpeg_decode_batch")
-    damaged = set(torch.nonzero(status).flatten().tolist())     # one small read-back per batch (the pixels are consumed on the device)
-    if packed and not damaged and not P.fallback and all(dm == P.dims[0] for dm in P.dims):
-        stats["gpu"] += len(P.kept)
-        return rgb.view(len(P.kept), P.dims[0][0], P.dims[0][1], 3)
-    for k, i in enumerate(P.kept):
-        if k in damaged:
-            # short / corrupt entropy-coded data: Pillow decodes (or raises "image file is truncated") exactly like the reference
-            out[i] = torch.from_numpy(np.array(_pillow_rgb(files[i]))).to(device)
-            stats["pillow"] += 1; stats["damaged"] = stats.get("damaged", 0) + 1
-            continue
-        o = int(P.imgs[k, 7])
-        hh, ww = P.dims[k]
-        out[i] = rgb[o:o + ww * hh * 3].view(hh, ww, 3)
-    stats["gpu"] += len(P.kept) - len(damaged)
-    return out
+    status_host = torch.empty(len(P.kept), dtype=torch.int32, pin_memory=True)
+    status_host.copy_(status, non_blocking=True)       # behind the decode on this stream; the event marks the copy, not later work
+    event = torch.cuda.Event()
+    event.record()
+    return PendingDecode(files, device, P, out, rgb, status_host, event)
+
+
+def decode_batch(files, device=None, packed=False):
+    """list of file contents (bytes) -> list of uint8 CUDA tensors [H, W, 3] (RGB), one per file, in order.
+    packed=True: when every file was decoded on the GPU and all share one size (a Market-1501 batch), ONE tensor [B, H, W, 3] is
+    returned instead of the list (no per-file views, no stack).  (Blocking form: queue + wait; loaders use `decode_batch_async`.)"""
+    return decode_batch_async(files, device).result(packed)

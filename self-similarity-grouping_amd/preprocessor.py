@@ -148,25 +148,36 @@ class GpuBatchLoader(object):
         recs = [self.items.dataset[i] for i in range(self.first, self.first + self.count)]
         return [r[0] for r in recs], [r[1] for r in recs]
 
+    def _finish(self, recs, pix, dev):
+        """decoded pixels of one batch -> the loader's item (transform on the device)"""
+        names = [r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs]
+        if torch.is_tensor(pix):                               # a batch of equally sized baseline files: straight into the transform
+            return (preprocess_batch(pix, self.height, self.width, self.mean, self.std, dev),) + names
+        out = torch.empty((len(recs), 3, self.height, self.width), dtype=torch.float32, device=dev)
+        by_size = {}
+        for j, a in enumerate(pix):
+            by_size.setdefault(tuple(a.shape[:2]), []).append(j)
+        for _, js in by_size.items():
+            batch = torch.stack([pix[j] for j in js]) if self.decode == "gpu" else np.stack([pix[j] for j in js])
+            res = preprocess_batch(batch, self.height, self.width, self.mean, self.std, dev)
+            out[torch.as_tensor(js, device=dev)] = res
+        return (out,) + names
+
     def __iter__(self):
         n = self.first + self.count
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.device is None else torch.device(self.device)
+        ahead = None        # GPU decode: (records, PendingDecode) of the batch whose decode is queued but whose status words are unread
         for b0 in range(self.first, n, self.batch_size):
             recs = [self.items[i] for i in range(b0, min(n, b0 + self.batch_size))]
-            dev = torch.device("cuda", torch.cuda.current_device()) if self.device is None else torch.device(self.device)
             if self.decode == "gpu":
-                from .jpeg import decode_batch
-                pix = decode_batch([r[0] for r in recs], dev, packed=True)   # uint8 CUDA [H, W, 3] per file, or ONE [B, H, W, 3] tensor
-                if torch.is_tensor(pix):                               # a batch of equally sized baseline files: straight into the transform
-                    yield preprocess_batch(pix, self.height, self.width, self.mean, self.std, dev), [r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs]
-                    continue
+                # one batch of lookahead: batch k + 1 is parsed on the host and its decode queued BEFORE batch k's status words are
+                # looked at, so that look never waits for the GPU (uint8 CUDA [H, W, 3] per file, or ONE [B, H, W, 3] tensor)
+                from .jpeg import decode_batch_async
+                nxt = (recs, decode_batch_async([r[0] for r in recs], dev))
+                if ahead is not None:
+                    yield self._finish(ahead[0], ahead[1].result(packed=True), dev)
+                ahead = nxt
             else:
-                pix = [r[0] for r in recs]
-            out = torch.empty((len(recs), 3, self.height, self.width), dtype=torch.float32, device=dev)
-            by_size = {}
-            for j, a in enumerate(pix):
-                by_size.setdefault(tuple(a.shape[:2]), []).append(j)
-            for _, js in by_size.items():
-                batch = torch.stack([pix[j] for j in js]) if self.decode == "gpu" else np.stack([pix[j] for j in js])
-                res = preprocess_batch(batch, self.height, self.width, self.mean, self.std, dev)
-                out[torch.as_tensor(js, device=dev)] = res
-            yield out, [r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs]
+                yield self._finish(recs, [r[0] for r in recs], dev)
+        if ahead is not None:
+            yield self._finish(ahead[0], ahead[1].result(packed=True), dev)

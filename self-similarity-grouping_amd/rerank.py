@@ -48,18 +48,35 @@ class DistHandle:
     _error = None
     _redo = None
     _k1 = None
-    sparse = None          # the sparse copy S of J' (re_ranking_device), or None
-    sparse_ok = False      # S is complete (its pool did not overflow): known once the status words have been read
+    sparse = None          # the sparse copy S of J' (re_ranking_device), or None; its consumers gate on the device-side overflow word
 
     def validate(self):
         """Raise what the pipeline could only detect on the device.  The status words are read once (with the caller's host
         round trip); a failure is kept on the handle and raised again by every later call, so a caller that catches the
-        error cannot go on to cluster the NaN matrix."""
+        error cannot go on to cluster the NaN matrix.  Sharded rows: the words of every rank are gathered first (one small
+        collective), so that all ranks take the same decision (a redo of the query expansion runs collectives)."""
         if self._pending is not None:
-            self.resolve_pending(self.take_pending().tolist())
+            self.resolve_pending(self.global_status(self.take_pending()))
         if self._error is not None:
             raise self._error
         return self
+
+    def global_status(self, words, table=None, first=0):
+        """status words as python numbers with the cross-rank ones replaced by their maximum over the ranks: digit overflow, "a V row was
+        longer than the guess" and the longest V row must lead every rank to the same decision.  `words`: this rank's device tensor (read
+        here, sharded: after ONE gather of every rank's words) -- or `table`: rows already gathered and read by the caller (cluster.eps_rule
+        appends the words to its own status row; `first` = their offset in a row)."""
+        if table is None:
+            if self.group is None:
+                return words.tolist()
+            from .dist import gather_rows
+            table, first = gather_rows(words.view(1, -1), self.group).tolist(), 0
+        import torch.distributed as dist
+        vals = [int(x) for x in table[dist.get_rank(self.group)][first:]]
+        for j in (1, 2, 3):
+            if len(vals) > j:
+                vals[j] = max(int(r[first + j]) for r in table)
+        return vals
 
     def take_pending(self):
         """the device status words as ONE int64 tensor (or None when they were read already): a consumer that is about to read
@@ -81,14 +98,13 @@ class DistHandle:
             vmax_h, flag_h = int(values[0]), int(values[1])
             over, seen = (int(values[2]), int(values[3])) if len(values) >= 4 else (0, 0)
             self._pending = None
-            self.sparse_ok = self.sparse is not None and len(values) >= 6 and int(values[5]) == 0
             if seen > 0 and self._k1 is not None:
                 _QE_GUESS[self._k1] = max(32, ((seen * 5 // 4) + 7) // 8 * 8)       # + 25 %: the LDS staging (and the occupancy) follows the guess
             if over and self._redo is not None:
-                self._redo()
+                self._redo(seen)                     # (the sparse copy is rebuilt as well; its consumers gate on its device-side overflow word)
                 redone = True
-                if self.sparse is not None:          # the sparse copy was rebuilt as well: its overflow word is read on its own (rare path)
-                    self.sparse_ok = int(self.sparse["cursor"][1].item()) == 0
+            elif self.sparse is not None and len(values) >= 6 and int(values[5]) != 0:
+                self.sparse = None                   # the pool overflowed: S is unusable -- free it, later consumers take the dense entry points directly
             self._redo = None
             if flag_h:
                 self._error = _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
@@ -98,6 +114,11 @@ class DistHandle:
         if self._error is not None:
             raise self._error
         return redone
+
+    def sparse_complete(self):
+        """True when the handle holds a complete sparse copy S (its pool did not overflow).  Reads the device word: a blocking read,
+        for tests and diagnostics -- the product's consumers gate on that word on the device."""
+        return self.sparse is not None and int(self.sparse["cursor"][1].item()) == 0
 
     def final_dist(self):
         """float64 [nrows, N] device tensor (API materialisation, 8 bytes/entry)."""
@@ -253,7 +274,7 @@ def _original_distance(L, tgt, row0, nrows, max_abs, st, memory_save=False, flag
     return D, rowmax, flag
 
 
-from .dist import gather_rows as _gather_rows  # noqa: E402
+from .dist import gather_rows as _gather_rows, gather_rows_packed as _gather_rows_packed  # noqa: E402,F401
 
 
 RANK_MODES = ("introsort", "stable")
@@ -316,15 +337,13 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
             raise _lib.SSGError("ssg_gram_i8_encode: a feature did not fit the digit count chosen from max|feat| (internal error)")
         return DistHandle(N, 1, D, euclid=D, row0=row0, nrows=nrows, group=group)
 
-    # ---- source-domain term (rerank.py:35-40): v half [N]
-    rowmin = _gather_rows(source_vector(src, tgt, row0, nrows, stats=stats), group, N)
+    # ---- source-domain term (rerank.py:35-40): v half [N]; initial ranking (rerank.py:68-70): the columns that are ever read are
+    # [0, max(k1+1, k2)) (:76, :83, :97).  Sharded rows: the two row-block tables (source minima, rank lists) travel in ONE collective
+    K = min(max(k1 + 1, k2), N)
+    rowmin, rank = _gather_rows_packed([source_vector(src, tgt, row0, nrows, stats=stats), initial_rank(D, rowmax, N, nrows, K, rank_mode)], group, N)
     v = torch.empty(N, dtype=torch.float16, device=dev)
     vmax = status[0:1]
     check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
-
-    # ---- initial ranking (rerank.py:68-70): the columns that are ever read are [0, max(k1+1, k2)) (:76, :83, :97)
-    K = min(max(k1 + 1, k2), N)
-    rank = _gather_rows(initial_rank(D, rowmax, N, nrows, K, rank_mode), group, N)
 
     # ---- k-reciprocal encoding (rerank.py:74-92)
     capV = int(L.ssg_krecip_row_capacity(k1))
@@ -332,14 +351,15 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     v_val = torch.empty((nrows, capV), dtype=torch.float16, device=dev)
     v_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
     check(L.ssg_krecip(ptr(D), ptr(rowmax), ptr(rank), N, row0, nrows, K, k1, capV, ptr(v_idx), ptr(v_val), ptr(v_nnz), st), "ssg_krecip")
-    v_idx, v_val, v_nnz = _gather_rows(v_idx, group, N), _gather_rows(v_val, group, N), _gather_rows(v_nnz, group, N)
+    v_idx, v_val, v_nnz = _gather_rows_packed([v_idx, v_val, v_nnz], group, N)       # (index / value / length rows: one collective)
     om = L.ssg_double_to_half_bits(1.0 - float(lambda_value))
     Jp = torch.empty((nrows, N), dtype=torch.float16, device=dev)
     tables = {}
     # sparse copy S of J' (the columns a row's Jaccard walk touches; everything else is the constant J'(0) = half(1 - lambda)): what the
     # eps rule and the region query walk instead of the N x N matrix while their bound stays below J'(0)
     sparse = None
-    if os.environ.get("SSG_SPARSE", "1") != "0":
+    # (never usable for lambda > 1 -- J' would be negative, bit 15 is the kernel's "touched" marker -- or with the first-generation Jaccard kernel)
+    if os.environ.get("SSG_SPARSE", "1") != "0" and not (om & 0x8000) and os.environ.get("SSG_JACCARD_GEN", "2") == "2":
         nseg = int(L.ssg_jaccard_segments(N))
         s_cap = int(nrows) * int(min(N, int(os.environ.get("SSG_SPARSE_ROW_ENTRIES", "1024"))))
         vmin = torch.empty(1, dtype=torch.int32, device=dev)
@@ -361,7 +381,7 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
                                      ptr(q_nnz), ptr(over), st), "ssg_query_expand")
             # sharded rows: the fixed-capacity rows travel as they are (k2 * longest V row entries of 6 bytes; trimming them to the longest
             # V_qe row would cost an all-reduce and a blocking read per split for a few MB over xGMI)
-            q_idx, q_val, q_nnz = _gather_rows(q_idx, group, N), _gather_rows(q_val, group, N), _gather_rows(q_nnz, group, N)
+            q_idx, q_val, q_nnz = _gather_rows_packed([q_idx, q_val, q_nnz], group, N)
         else:
             capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
         # ---- inverted index + Jaccard rows (rerank.py:101-122)
@@ -385,19 +405,23 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
             tables.update(q_idx=q_idx, q_val=q_val, q_nnz=q_nnz, colptr=colptr, inv_row=inv_row, inv_val=inv_val)
 
     # ---- local query expansion (rerank.py:94-99) .. Jaccard rows.  The LDS staging and the row capacity of V_qe follow the longest V
-    # row.  One GPU: run on a GUESS (the longest row of the previous call + 25 %, 64 at first) and let the kernel report a longer row
+    # row.  Run on a GUESS (the longest row of the previous call + 25 %, 64 at first) and let the kernel report a longer row
     # through the status words that the consumer reads anyway (`validate`); a miss redoes this tail with the exact bound (rare; the
-    # result is the same either way).  Sharded rows: every rank must take the same branch, so the gathered v_nnz is read back (one
-    # blocking read, no collective of its own).
+    # result is the same either way).
     redo = None
     if k2 == 1:
         tail(capV, None)
-    elif group is None and os.environ.get("SSG_QE_GUESS", "1") != "0":
+    elif os.environ.get("SSG_QE_GUESS", "1") != "0":
+        # (sharded rows as well since round 5: every rank runs on the same guess, and the words that report a miss are combined over the
+        # ranks -- maximum -- when they are read, `DistHandle.global_status`, so that all ranks redo together; round 4 read the gathered
+        # v_nnz back here instead: one blocking read per split)
         guess = min(capV, _QE_GUESS.get(k1, 64))
         tail(guess, status[2:4])
-        redo = lambda: tail(capV, None)            # noqa: E731  (keeps the small tables alive, not D)
+        # a miss redoes the tail sized by the longest row the kernel REPORTED (status[3]: exact over the rows it staged), not by the worst-case
+        # capacity capV = (k1+1)(round(k1/2)+2) -- that one passes the 160 KB of LDS from k1 ~ 35 on; 0 (no report) falls back to a read of v_nnz
+        redo = lambda seen=0: tail(max(int(seen), 1) if seen else max(int(v_nnz.max().item()), 1), None)      # noqa: E731  (keeps the small tables alive, not D)
     else:
-        tail(max(int(v_nnz.max().item()), 1), None)  # host round trip 2 (sharded path)
+        tail(max(int(v_nnz.max().item()), 1), None)  # exact bound: one blocking read (v_nnz is the gathered table: the same on every rank)
 
     h = DistHandle(N, 0, Jp, v=v, lambda_value=lambda_value, euclid=D if keep_euclid else None, row0=row0, nrows=nrows, group=group)
     # the device-side status words (zero source vector -> the reference's NaN path; int8 digit overflow; a V row longer than the guess)

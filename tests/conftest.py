@@ -32,6 +32,38 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+def probed_introsort_threshold():
+    """insertion-sort threshold of the INSTALLED numpy's argsort on half keys (15 or 16: `pr - pl > t` is still partitioned), probed with
+    17-element tie patterns on which the oracle's two settings order differently; None when neither matches"""
+    from oracle import ssg_oracle as ora
+    ora.build()
+    rng = np.random.default_rng(11)
+    votes = {15: 0, 16: 0}
+    for _ in range(600):
+        h = (rng.integers(0, 4, 17) / 4.0).astype(np.float16)
+        a15, a16 = ora.argsort_half(h, small=15), ora.argsort_half(h, small=16)
+        if not np.array_equal(a15, a16):
+            got = np.argsort(h)
+            votes[15] += int(np.array_equal(got, a15)); votes[16] += int(np.array_equal(got, a16))
+    if votes[15] and not votes[16]:
+        return 15
+    if votes[16] and not votes[15]:
+        return 16
+    return None
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """one line in every log (also with -q, also in the -m gpu log of the GPU box): the numpy build whose introsort tie order the
+    default rank mode replays, and the threshold probed on it -- "bit-identical to the unmodified reference" is a statement about
+    THIS numpy"""
+    try:
+        thr = probed_introsort_threshold()
+    except Exception as e:       # noqa: BLE001  (the oracle could not be built: say so, do not fail the run)
+        thr = "probe failed: %s" % (e,)
+    terminalreporter.write_line("ssg: numpy %s, probed introsort insertion threshold %s (kernel / oracle / goldens: 15); python %s"
+                                % (np.__version__, thr, sys.version.split()[0]))
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -39,6 +39,15 @@ def _cpu_worker(rank, world, port, q):
         ok = ok and torch.equal(sd.gather_rows(table[lo:hi].clone(), g, n), table)
         vec = torch.arange(n, dtype=torch.float16)
         ok = ok and torch.equal(sd.gather_rows(vec[lo:hi].clone(), g, n), vec)
+        # round 5: the same blocks of SEVERAL tables (different dtypes / row widths, incl. an odd byte count) in ONE collective
+        idx = torch.arange(n * 5, dtype=torch.int32).view(n, 5); val = (torch.arange(n * 5, dtype=torch.float32).view(n, 5) / 7).to(torch.float16)
+        nnz = torch.arange(n, dtype=torch.int32) + 3; by = (torch.arange(n * 3) % 251).to(torch.uint8).view(n, 3)
+        got = sd.gather_rows_packed([idx[lo:hi].clone(), val[lo:hi].clone(), nnz[lo:hi].clone(), by[lo:hi].clone()], g, n)
+        ok = ok and len(got) == 4 and all(torch.equal(a, b) and a.is_contiguous() for a, b in zip(got, (idx, val, nnz, by)))
+    # equally shaped per-rank tables stacked by rank (the sharded DBSCAN ships count + neighbour counts + edge list like this)
+    st = sd.gather_packed([torch.tensor([rank * 10 + 1], dtype=torch.int64), torch.full((4, 2), rank, dtype=torch.int32), torch.zeros((0, 2), dtype=torch.int32)], g)
+    ok = ok and [int(x) for x in st[0].flatten()] == [r * 10 + 1 for r in range(world)] and st[1].shape == (world, 4, 2) and st[2].shape == (world, 0, 2)
+    ok = ok and all(int(st[1][r].min()) == int(st[1][r].max()) == r for r in range(world))
     try:
         sd.gather_rows(torch.zeros((5, 2)), g, 11 if world == 2 and rank == 0 else 12)   # a block of the wrong size is refused
         ok = False
@@ -88,6 +97,12 @@ def _gpu_worker(rank, world, port, q, N, Ns, d):
     import ssg_amd  # noqa: F401
     from ssg_amd import compute_dist, generate_selflabel
     from ssg_amd import dist as sd
+    if N == 1533:
+        # round 5: the sharded path runs the query expansion on a guessed row capacity too.  Force a miss (4 entries): the words that
+        # report it are combined over the ranks when the eps rule reads them, every rank redoes the tail together (its collectives stay
+        # matched), and the result equals the unsharded one
+        from ssg_amd import rerank
+        rerank._QE_GUESS[20] = 4
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -113,7 +128,7 @@ def _gpu_worker(rank, world, port, q, N, Ns, d):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,N", [(2, 1536), (8, 1531), (8, 30003)])
+@pytest.mark.parametrize("world,N", [(2, 1536), (3, 1533), (8, 1531), (8, 30003)])
 def test_sharded_pipeline_matches_unsharded(world, N):
     """compute_dist -> generate_selflabel, 3 feature splits, rows sharded over `world` processes (gloo; they share the
     test box's single GPU) with ragged row blocks (1531 = 8*191 + 3; 30003 = BASELINE configs[3]'s MSMT17-size problem, three
@@ -232,6 +247,20 @@ def test_loader_shards_are_balanced_by_image():
     names, pids = full.listing()
     assert len(names) == 12936 and names[:2] == ["00000000", "00000001"] and pids[:3] == [0, 0, 0]
     assert sum((p.listing()[0] for p in parts), []) == names
+    # round 5: a rank that holds only ITS block of the set (bench.py generates one block per rank): same description, resident slice
+    whole = torch.arange(37 * 2, dtype=torch.float32).view(37, 2)
+    lo, hi = ev.TensorBatchLoader(whole, 5).shard(1, 3).first, None
+    for r in range(3):
+        sh = ev.TensorBatchLoader(whole, 5).shard(r, 3)
+        lo, hi = sh.first, sh.first + sh.count
+        part = ev.TensorBatchLoader(whole[lo:hi].clone(), 5, count=37, base=lo)
+        assert part.num_items() == 37 and part.listing() == ev.TensorBatchLoader(whole, 5).listing()
+        mine = part.shard(r, 3)
+        got = torch.cat([b[0] for b in mine]); names = sum((list(b[1]) for b in mine), [])
+        assert torch.equal(got, whole[lo:hi]) and names == ["%08d" % i for i in range(lo, hi)]
+        if r != 1:
+            with pytest.raises(IndexError):
+                list(part.shard(1, 3))
     ds = [("f%03d.jpg" % i, i % 5, i % 2) for i in range(37)]
     g = GpuBatchLoader(ds, root="/nonexistent", batch_size=8, decode="pillow")
     sub = [g.shard(r, 3) for r in range(3)]

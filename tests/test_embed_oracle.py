@@ -19,6 +19,26 @@ def test_embed_restatement_matches_reference_golden(golden):
         assert np.allclose(np.linalg.norm(mine, axis=2), 1.0, atol=1e-5)
 
 
+def test_embed_restatement_matches_the_wide_reference_goldens(golden):
+    """round 5: the 16-image fixture and the checkpoint-like-BatchNorm fixture, both written by the REAL reference model
+    (tools/make_golden.py --only-embed-wide); the restatement is checked on the first two images of each (CPU time)."""
+    import ssg_amd
+    from oracle import embed_oracle
+    from synth import checkpoint_like_state_dict
+    for fname, mk in (("embed_ref16.npz", lambda s: ssg_amd.synthetic_state_dict(seed=s)), ("embed_ckpt_ref.npz", checkpoint_like_state_dict)):
+        g = golden(fname)
+        n = int(g["n"])
+        sd = mk(int(g["weight_seed"]))
+        imgs = torch.randn(n, 3, 256, 128, generator=torch.Generator().manual_seed(int(g["image_seed"])))
+        mine = torch.stack(embed_oracle.embed_with_flip(sd, imgs[:2], 2)).numpy()
+        ref = g["feats_S2"]
+        assert ref.shape == (3, n, 2048) and np.allclose(np.linalg.norm(ref, axis=2), 1.0, atol=1e-5)
+        assert np.abs(mine - ref[:, :2]).max() < 2e-6, fname
+    sd = checkpoint_like_state_dict(7)
+    sc = (sd["base.layer2.0.bn2.weight"] / torch.sqrt(sd["base.layer2.0.bn2.running_var"] + 1e-5)).abs()
+    assert float(sc.max() / sc.min()) > 1e3          # the point of the second fixture: per-channel scales spanning decades
+
+
 def test_state_dict_surface():
     import ssg_amd
     m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False)

@@ -684,6 +684,37 @@ def test_embedding_vs_reference_golden(golden, dev, precision):
             assert cat.shape == (2, (S + 1) * 2048)
 
 
+@pytest.mark.parametrize("precision", ["split", "f32"])
+def test_embedding_vs_wide_reference_goldens(golden, dev, precision):
+    """round 5: 16 images under the seeded Kaiming weights, and 8 images under checkpoint-like BatchNorm statistics
+    (folded per-channel scales spanning > 10^4) -- both fixtures written by the REAL reference model (reid.models.create +
+    reid.evaluators.extract_features, tools/make_golden.py --only-embed-wide).  The split-half default and the fp32-MFMA path must
+    both stay inside 5e-6 absolute on the unit-norm features; no overflow fallback may be needed."""
+    import warnings
+    import ssg_amd
+    from synth import checkpoint_like_state_dict
+    for fname, mk in (("embed_ref16.npz", lambda s: ssg_amd.synthetic_state_dict(seed=s)), ("embed_ckpt_ref.npz", checkpoint_like_state_dict)):
+        g = golden(fname)
+        n = int(g["n"])
+        imgs = torch.randn(n, 3, 256, 128, generator=torch.Generator().manual_seed(int(g["image_seed"])))
+        m = ssg_amd.create("resnet50", num_classes=0, num_split=2, cluster=False, pretrained=False, precision=precision).cuda().eval()
+        m.load_state_dict(mk(int(g["weight_seed"])), strict=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            got = m.embed_with_flip(imgs).cpu().numpy()
+        ref = g["feats_S2"]
+        assert got.shape == ref.shape
+        err = float(np.abs(got - ref).max())
+        print("embedding %s precision=%s: max |err| vs the reference model %.3g" % (fname, precision, err))
+        assert err < 5e-6, (fname, err)
+        # the dictionary surface on uneven batches gives the same rows (reid/evaluators.py:18-60)
+        if precision == "split":
+            names = ["f%d" % i for i in range(n)]
+            loader = [(imgs[:5], names[:5], list(range(5)), [0] * 5), (imgs[5:], names[5:], list(range(5, n)), [0] * (n - 5))]
+            feats, _ = ssg_amd.extract_features(m, loader, print_freq=0, for_eval=False)
+            assert all(np.array_equal(feats[f][s].numpy(), got[s, i]) for i, f in enumerate(names) for s in range(3))
+
+
 def test_embed_with_flip_on_two_streams_equals_one_stream(dev):
     """`embed_with_flip` runs the original and the flipped forward on two HIP streams (resnet.py, flip_streams): the result must be
     bit-identical to the one-stream order, also over back-to-back calls of different batches and sizes (tensors allocated on a side
@@ -815,14 +846,14 @@ def test_jaccard_second_generation_and_sparse_copy(dev, ora, monkeypatch):
             # rows with more than 3072 touched columns (the LDS list overflows: dense patch pass): the default pool (1024 entries per row)
             # cannot hold them -- S is marked unusable and the consumers go dense; a pool of N entries per row holds everything
             h0 = rerank.re_ranking_device(s_d, t_d, **kw)
-            assert torch.equal(h1.M.view(torch.int16), h0.M.view(torch.int16)) and not h0.sparse_ok
+            assert torch.equal(h1.M.view(torch.int16), h0.M.view(torch.int16)) and not h0.sparse_complete()
             assert cluster.eps_rule(h0, 1.6e-3) == e1
             assert np.array_equal(cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h0), l1)
             monkeypatch.setenv("SSG_SPARSE_ROW_ENTRIES", str(N))
         h2 = rerank.re_ranking_device(s_d, t_d, **kw)
         monkeypatch.delenv("SSG_SPARSE_ROW_ENTRIES", raising=False)
         assert torch.equal(h1.M.view(torch.int16), h2.M.view(torch.int16)), name
-        assert h2.sparse_ok, name
+        assert h2.sparse_complete(), name
         _check_sparse_copy(h2, N)
         assert cluster.eps_rule(h2, 1.6e-3) == e1, name
         assert np.array_equal(cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h2), l1), name
@@ -834,7 +865,7 @@ def test_jaccard_second_generation_and_sparse_copy(dev, ora, monkeypatch):
         monkeypatch.setenv("SSG_SPARSE_ROW_ENTRIES", "8")
         h3 = rerank.re_ranking_device(s_d, t_d, **kw)
         monkeypatch.delenv("SSG_SPARSE_ROW_ENTRIES")
-        assert torch.equal(h1.M.view(torch.int16), h3.M.view(torch.int16)) and not h3.sparse_ok
+        assert torch.equal(h1.M.view(torch.int16), h3.M.view(torch.int16)) and not h3.sparse_complete()
         assert cluster.eps_rule(h3, 1.6e-3) == e1
         assert np.array_equal(cluster.DBSCAN(eps=e1[0], min_samples=4, metric="precomputed").fit_predict(h3), l1)
         del h1, h2, h3
@@ -852,7 +883,7 @@ def test_sparse_passes_mixed_rows_equal_dense(dev):
     lam = 0.3
     h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), lambda_value=lam)
     sp = h.sparse
-    assert sp is not None and h.sparse_ok
+    assert sp is not None and h.sparse_complete()
     N = h.N
     v = h.v.cpu().numpy(); jp0 = np.uint16(sp["jp0"]).view(np.float16)
     floors = jp0.astype(np.float64) + (v + v.min()).astype(np.float16).astype(np.float64) * lam        # f64(J'(0)) + f64(half(v_i + vmin)) * lambda
@@ -1114,24 +1145,9 @@ def test_rerank_plain_ties_and_chunks_vs_oracle(dev, ora):
 
 # ------------------------------------------------------------------ split-half embedding on checkpoint-like weights
 def _checkpoint_like_state_dict(seed):
-    """Kaiming convolutions + BatchNorm statistics with the spread of a trained, folded checkpoint: per-channel scales
-    gamma / sqrt(var + eps) log-normal over ~3 decades (rms 1 per layer so the network neither explodes nor dies),
-    running_var log-uniform in [1e-3, 1e2], non-zero running_mean / beta."""
-    import ssg_amd
-    sd = ssg_amd.synthetic_state_dict(seed=seed)
-    g = torch.Generator().manual_seed(seed + 100)
-    for k in list(sd):
-        if k.endswith("running_var") and k.startswith("base."):
-            p = k[: -len("running_var")]
-            n = sd[k].numel()
-            var = torch.exp(torch.empty(n).uniform_(float(np.log(1e-3)), float(np.log(1e2)), generator=g))
-            s = torch.exp(2.3 * torch.randn(n, generator=g))
-            s = s / s.pow(2).mean().sqrt()
-            sd[p + "running_var"] = var
-            sd[p + "weight"] = s * torch.sqrt(var + 1e-5)
-            sd[p + "running_mean"] = 0.1 * torch.randn(n, generator=g)
-            sd[p + "bias"] = 0.05 * torch.randn(n, generator=g)
-    return sd
+    """tools/synth.checkpoint_like_state_dict: Kaiming convolutions + BatchNorm statistics with the spread of a trained, folded checkpoint"""
+    from synth import checkpoint_like_state_dict
+    return checkpoint_like_state_dict(seed)
 
 
 def test_split_half_on_checkpoint_like_weights(dev):

@@ -189,6 +189,40 @@ def embed_fixture():
     return ok
 
 
+def embed_fixture_wide():
+    """Two more embedding goldens from the REAL reference model:
+      embed_ref16.npz     -- 16 seeded images (SURVEY.md 8c allows up to 16), seeded Kaiming weights, S = 2;
+      embed_ckpt_ref.npz  -- 8 seeded images under checkpoint-like BatchNorm statistics (tools/synth.checkpoint_like_state_dict: folded
+                             per-channel scales spanning > 10^3), S = 2: the split-half path pinned by the reference itself on realistic
+                             weights, not only by the builder's restatement."""
+    import torch
+    import ssg_amd
+    from oracle import embed_oracle
+    from synth import checkpoint_like_state_dict
+    reid = import_reid()
+    ok = True
+    for fname, sd, wseed, iseed, n, kind in (("embed_ref16.npz", ssg_amd.synthetic_state_dict(seed=1), 1, 16, 16, "kaiming"),
+                                             ("embed_ckpt_ref.npz", checkpoint_like_state_dict(7), 7, 17, 8, "checkpoint-like")):
+        torch.manual_seed(0)
+        model = reid.models.create('resnet50', num_classes=0, num_split=2, cluster=False)
+        missing = model.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys, missing
+        model.eval()
+        imgs = torch.randn(n, 3, 256, 128, generator=torch.Generator().manual_seed(iseed))
+        names = ["f%d" % i for i in range(n)]
+        loader = [(imgs[:5], names[:5], list(range(5)), [0] * 5), (imgs[5:], names[5:], list(range(5, n)), [0] * (n - 5))]
+        feats, _ = reid.evaluators.extract_features(model, loader, for_eval=False)
+        ref = torch.stack([torch.stack(feats[f]) for f in names], 1)                     # [3, n, 2048]
+        mine = torch.stack(embed_oracle.embed_with_flip(sd, imgs, 2))
+        err = (ref - mine).abs().max().item()
+        sc = (sd["base.layer2.0.bn2.weight"] / torch.sqrt(sd["base.layer2.0.bn2.running_var"] + 1e-5)).abs()
+        print("embed %s (%d images, %s weights, layer2.0.bn2 scale spread %.1e): torch-restatement vs reference max|diff| = %.3e"
+              % (fname, n, kind, float(sc.max() / sc.min()), err))
+        ok = ok and err < 2e-6
+        np.savez_compressed(os.path.join(OUT, fname), image_seed=iseed, weight_seed=wseed, n=n, weights=kind, feats_S2=ref.numpy())
+    return ok
+
+
 def eval_fixture():
     """Retrieval metrics (reid/evaluators.py:88-129 evaluate_all -> reid/evaluation_metrics/ranking.py cmc, mean_ap with
     sklearn's average_precision_score): random query x gallery float32 distance blocks with Market-like id / camera
@@ -604,6 +638,10 @@ def main():
         ok = selftraining_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
         sys.exit(0 if ok else 1)
+    if "--only-embed-wide" in sys.argv:   # regenerate just tests/golden/embed_ref16.npz and embed_ckpt_ref.npz
+        ok = embed_fixture_wide()
+        print("ALL OK" if ok else "ORACLE MISMATCH")
+        sys.exit(0 if ok else 1)
     if "--only-eval" in sys.argv:         # regenerate just tests/golden/eval_cases.npz
         ok = eval_fixture()
         print("ALL OK" if ok else "ORACLE MISMATCH")
@@ -729,6 +767,7 @@ def main():
 
     ok = init_fixture(mod) and ok
     ok = embed_fixture() and ok
+    ok = embed_fixture_wide() and ok
     ok = eval_fixture() and ok
     ok = pairwise_fixture() and ok
     ok = jpeg_fixture() and ok

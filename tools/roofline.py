@@ -64,11 +64,16 @@ def grouping_roofline(tot, N, nrows, Ns, world, steps, d=2048):
         if k in tot:
             n, ms = tot[k]
             gbs = byt * n / (ms * 1e-3) / 1e9
+            if k.endswith("_s"):
+                # the sparse passes do not stream the matrix: no bandwidth figure, no roofline fraction -- the bytes they no longer move
+                hbm.append({"kernel": k, "bound": "latency (L2 round trips over a few hundred packed words + gathers of v per row)", "what": what, "launches": n,
+                            "avg_launch_ms": round(ms / n, 4), "bytes_avoided": int(byt), "unit": "B per launch not streamed",
+                            "dense_pass_time_at_hbm_peak_ms": round(byt / (PEAK_HBM_GBS * 1e9) * 1e3, 4), "frac": None,
+                            "note": "walks the sparse copy S instead of the N x N matrix; `bytes_avoided` = the algorithmic bytes of the dense pass it replaces "
+                                    "(SURVEY.md 8d); a roofline fraction of bytes that are not moved would be meaningless (it exceeded 1 in round 4)"})
+                continue
             hbm.append({"kernel": k, "bound": "hbm", "what": what, "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(gbs, 1),
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})
-            if k.endswith("_s"):
-                hbm[-1]["note"] = ("walks the sparse copy S (a few hundred packed words per row) instead of streaming the matrix: `achieved` = the ALGORITHMIC "
-                                   "bytes of the pass (SURVEY.md 8d) over its time, not bytes moved -- it can exceed the HBM rate")
     # the self term computes only the upper-triangle tiles when one GPU holds the whole matrix (mirrored on store)
     t128 = (N + 127) // 128
     self_flop = (t128 * (t128 + 1) // 2) * 128 * 128 * 2.0 * d if world == 1 else 2.0 * nrows * N * d

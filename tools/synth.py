@@ -39,3 +39,26 @@ def hard_clustered(N, d, seed, intra=0.5, frac_single=0.15, sizes=(2, 3, 4, 8, 1
     perm = rng.permutation(N)
     x = np.ascontiguousarray(x[perm], dtype=np.float32)
     return (x, ids[perm]) if return_ids else x
+
+
+def checkpoint_like_state_dict(seed):
+    """Kaiming convolutions + BatchNorm statistics with the spread of a trained, folded checkpoint: per-channel scales
+    gamma / sqrt(var + eps) log-normal over ~3 decades (rms 1 per layer so the network neither explodes nor dies),
+    running_var log-uniform in [1e-3, 1e2], non-zero running_mean / beta.  Shared by the GPU tests and by tools/make_golden.py
+    (tests/golden/embed_ckpt_ref.npz: the REAL reference model under these statistics)."""
+    import torch
+    import ssg_amd
+    sd = ssg_amd.synthetic_state_dict(seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    for k in list(sd):
+        if k.endswith("running_var") and k.startswith("base."):
+            p = k[: -len("running_var")]
+            n = sd[k].numel()
+            var = torch.exp(torch.empty(n).uniform_(float(np.log(1e-3)), float(np.log(1e2)), generator=g))
+            s = torch.exp(2.3 * torch.randn(n, generator=g))
+            s = s / s.pow(2).mean().sqrt()
+            sd[p + "running_var"] = var
+            sd[p + "weight"] = s * torch.sqrt(var + 1e-5)
+            sd[p + "running_mean"] = 0.1 * torch.randn(n, generator=g)
+            sd[p + "bias"] = 0.05 * torch.randn(n, generator=g)
+    return sd
