@@ -301,8 +301,8 @@ def main():
         h = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
                                      row0=row0, nrows=nrows, group=group)
         ev[2].record()
-        eps, cnt, top = cluster.eps_rule(h, args.rho)
-        labels = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h)
+        # eps rule + DBSCAN as the product's generate_selflabel runs them at iteration 0 (selftraining.py:289-306): one device chain, one read
+        eps, cnt, top, labels, _ = cluster.eps_rule_dbscan(h, args.rho, min_samples=4)
         ev[3].record()
         return ev, eps, labels
 
@@ -365,9 +365,9 @@ def main():
         other = "separable" if args.track_g == "hard" else "hard"
         so, to = (torch.from_numpy(a).to(dev) for a in emb_np[other])
         def grouping_other():
-            ho = rerank.re_ranking_device(so, to, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False)
-            e_, _, _ = cluster.eps_rule(ho, args.rho)
-            return e_, cluster.DBSCAN(eps=e_, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(ho)
+            ho = rerank.re_ranking_device(so, to, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False)
+            e_, _, _, l_, _ = cluster.eps_rule_dbscan(ho, args.rho, min_samples=4)
+            return e_, l_
         t_other = timed_ms(grouping_other, reps=2)
         e_o, l_o = grouping_other()
         extras["grouping_other_track"] = {"track": other, "rerank_dbscan_ms": round(t_other, 3), "clusters": int(l_o.max() + 1),
@@ -428,14 +428,13 @@ def main():
         h_ = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
                                       row0=row0, nrows=nrows, group=group)
         n_rr = sc.n
-        e_, _, _ = cluster.eps_rule(h_, args.rho)
-        n_eps = sc.n - n_rr
-        cluster.DBSCAN(eps=e_, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h_)
-        n_db = sc.n - n_rr - n_eps
+        cluster.eps_rule_dbscan(h_, args.rho, min_samples=4)
+        n_ed = sc.n - n_rr
     del h_
-    host_syncs = {"rerank": n_rr, "eps_rule": n_eps, "dbscan": n_db, "per_split": n_rr + n_eps + n_db, "world": world,
-                  "what": "blocking device->host reads (item/tolist/cpu) of one grouping leg on rank 0: value ranges of the features (re-rank; sharded: + longest "
-                          "sparse row), candidate count + status words + eps (eps rule; sharded: + block sizes of the candidate gather), labels + edge count (DBSCAN)"}
+    host_syncs = {"rerank": n_rr, "eps_rule_dbscan": n_ed, "per_split": n_rr + n_ed, "world": world,
+                  "what": "blocking device->host reads (item/tolist/cpu) of one grouping leg on rank 0: value ranges of the features (re-rank); ONE read for "
+                          "eps rule + DBSCAN on one GPU (labels, neighbour counts, eps, check words, the re-rank's status words -- cluster.eps_rule_dbscan); "
+                          "sharded rows run the two-call form: status table + eps (eps rule), edge counts + labels (DBSCAN)"}
     collectives = cc.summary()
     collectives["what"] = ("torch.distributed collectives of one grouping leg on rank 0 (all-gathers of the row-block tables: source minima, rank lists, V, V_qe, "
                            "eps candidates, neighbour counts, edges; all-reduces of the eps histograms / counters); bytes = this rank's contribution / what it receives")

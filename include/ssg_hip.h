@@ -193,6 +193,14 @@ int ssg_eps_compact_below_s(const void* M, const uint16_t* v, int N, int row0, i
 int ssg_half_min(const uint16_t* v, int N, uint32_t* out_bits, ssg_stream_t stream);
 int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t value, ssg_stream_t stream);
 int ssg_sort_u64(uint64_t* buf, uint64_t n_pow2, ssg_stream_t stream); /* ascending, n = 2^k >= 2048 */
+/* round 5: the same sort with the number of keys left on the device (*n_dev, the compaction pass's cursor word): the network is launched
+ * for the capacity n_cap (2^k >= 2048) but works on the power of two >= max(*n_dev, 2048) only; [*n_dev, that) is filled with ~0 first */
+int ssg_sort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, ssg_stream_t stream);
+/* round 5: the a-posteriori checks of the sampled eps rule on the device (selftraining.py:289-293 stays exact): top = rint(rho * (upper_total -
+ * cursor[1])) == top_guess (the tree ssg_eps_mean_run summed), cursor[0] <= n_cap keys collected, >= top of them, the top-th sorted key below
+ * the float32 threshold thr3[0] by its margin.  status6 = {ok, got, zeros, top, top-th key bits, threshold bits}; on failure eps2[0] := NaN */
+int ssg_eps_check(const uint64_t* sorted_keys, const uint64_t* cursor, const uint64_t* thr3, double rho, uint64_t upper_total, int64_t top_guess,
+                  uint64_t n_cap, double* eps2, uint64_t* status6, ssg_stream_t stream);
 size_t ssg_eps_mean_workspace_bytes(int64_t top);
 /* out2[0] = mean of the first `top` sorted keys with numpy's pairwise summation (mode 0: f64;
  * mode 1: float32 sum of half values -> half, out2[1] = its bits) */
@@ -212,6 +220,14 @@ int ssg_region_query_s(const void* M, const uint16_t* v, int N, int row0, int nr
                        const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
                        uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
                        ssg_stream_t stream);
+/* round 5: both region queries with eps read from device memory (*eps_dev, e.g. out2[0] of ssg_eps_mean_run after ssg_eps_check): the eps rule,
+ * the region query and the components run back to back, the host reads eps with the labels.  *eps_dev = NaN: no hit */
+int ssg_region_query_dev(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, const double* eps_dev,
+                         int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, ssg_stream_t stream);
+int ssg_region_query_s_dev(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, const double* eps_dev, const uint32_t* s_pool,
+                           const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
+                           uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
+                           ssg_stream_t stream);
 size_t ssg_dbscan_cc_workspace_bytes(int N);
 /* cnt is the FULL [N] table, edges the concatenated edge list: labels[N] int64, -1 = noise */
 int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,

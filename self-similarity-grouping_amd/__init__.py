@@ -8,14 +8,14 @@ this package is the thin host-side mirror of the reference interface.
 from . import _lib  # noqa: F401
 from ._lib import SSGError, available  # noqa: F401
 
-__all__ = ["re_ranking", "re_ranking_device", "DBSCAN", "eps_rule", "compute_dist", "generate_selflabel", "SSGError", "available"]
+__all__ = ["re_ranking", "re_ranking_device", "DBSCAN", "eps_rule", "eps_rule_dbscan", "compute_dist", "generate_selflabel", "SSGError", "available"]
 
 
 def __getattr__(name):   # lazy: torch import only when the compute surface is touched
     if name in ("re_ranking", "re_ranking_device", "re_ranking_init", "re_ranking_init_dist", "DistHandle", "ReRankNaNError"):
         from . import rerank
         return getattr(rerank, name)
-    if name in ("DBSCAN", "eps_rule", "as_handle"):
+    if name in ("DBSCAN", "eps_rule", "eps_rule_dbscan", "as_handle"):
         from . import cluster
         return getattr(cluster, name)
     if name in ("compute_dist", "generate_selflabel", "select_labeled", "generate_dataset"):

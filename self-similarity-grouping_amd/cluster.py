@@ -204,6 +204,118 @@ def eps_rule(X, rho):
     return eps, count, top
 
 
+_EPS_TREES = {}     # (top, device index) -> workspace with the pairwise-summation tables of `top` summands already uploaded (they depend on top only)
+
+
+def _eps_tree(L, top, dev, st):
+    key = (int(top), dev.index)
+    ws = _EPS_TREES.get(key)
+    if ws is None:
+        ws_bytes = int(L.ssg_eps_mean_workspace_bytes(top))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        check(L.ssg_eps_mean_prepare(top, ptr(ws), ws_bytes, st), "ssg_eps_mean_prepare")      # blocks on the stream: once per (top, device)
+        if len(_EPS_TREES) >= 8:
+            _EPS_TREES.pop(next(iter(_EPS_TREES)))
+        _EPS_TREES[key] = ws
+    return ws
+
+
+def eps_rule_dbscan(X, rho, min_samples=4):
+    """selftraining.py:289-306 in ONE device-resident chain (round 5): eps rule -> region query -> connected components with eps, the
+    candidate count and the edge count left on the device, and ONE blocking read at the end (labels, neighbour counts, eps, the check
+    words and the re-rank's status words).  Returns (eps, count, top, labels, core_sample_indices) -- exactly what
+    `eps_rule(X, rho)` followed by `DBSCAN(eps, min_samples, metric='precomputed').fit(X)` returns; that two-call form stays the
+    API (and the fallback of every case this chain does not cover: sharded rows, the radix-select path, a failed check).
+
+    What the host decides BEFORE the data is seen, and the device verifies: the number of summands top = round(rho * count) assumes no
+    zero entry in the strict upper triangle (count = N(N-1)/2; a zero -- duplicate images -- makes `ssg_eps_check` fail and the
+    two-call path runs instead); the sort runs on the device's own candidate count inside a buffer sized by the sampling bound."""
+    import os
+    L = _lib.lib()
+    h = as_handle(X)
+    rho = float(rho)
+    if not isinstance(min_samples, numbers.Integral) or min_samples < 1:
+        raise ValueError("The 'min_samples' parameter of DBSCAN must be an int in the range [1, inf). Got %r instead." % (min_samples,))
+
+    def two_calls():
+        eps, count, top = eps_rule(h, rho)
+        est = DBSCAN(eps=eps, min_samples=min_samples, metric="precomputed").fit(h)
+        return eps, count, top, est.labels_, est.core_sample_indices_
+
+    N = h.N
+    upper_total = N * (N - 1) // 2
+    top_guess = int(np.round(rho * upper_total))
+    if (h.group is not None or os.environ.get("SSG_EPS_PATH", "sampled") != "sampled" or os.environ.get("SSG_EPS_FUSED", "1") == "0" or not rho > 0
+            or N < 64 or top_guess <= 0):
+        return two_calls()
+    dev, st = h.device, stream()
+    args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
+    # ---- the sampled threshold and the one full pass, exactly as _eps_rule_sampled queues them
+    stride = max(1, h.nrows // 192)
+    hist = torch.zeros(2 * 4097, dtype=torch.int64, device=dev)
+    hist1, hist2 = hist[:4097], hist[4097:]
+    check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist1), st), "ssg_eps_sample_hist")
+    thr3 = torch.zeros(5, dtype=torch.int64, device=dev)
+    check(L.ssg_eps_select_threshold(ptr(hist1), 1.3 * rho, ptr(thr3), st), "ssg_eps_select_threshold")
+    check(L.ssg_eps_sample_hist(*args, stride, ptr(thr3), ptr(hist2), st), "ssg_eps_sample_hist")
+    check(L.ssg_eps_refine_threshold(ptr(hist2), ptr(thr3), st), "ssg_eps_refine_threshold")
+    cap = max(6 * top_guess * h.nrows // N + (1 << 16), 1 << 16)
+    n_cap = max(2048, 1 << (cap - 1).bit_length())
+    buf = torch.empty(n_cap, dtype=torch.int64, device=dev)
+    cursor = torch.zeros(3, dtype=torch.int64, device=dev)
+    sp = getattr(h, "sparse", None) if h.mode == 0 else None
+    if sp is not None:
+        check(L.ssg_eps_compact_below_s(ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.lambda_value, ptr(thr3), ptr(buf), n_cap, ptr(cursor), ptr(sp["pool"]),
+                                        ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), st),
+              "ssg_eps_compact_below_s")
+    else:
+        check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
+    # ---- sort (device-sized), numpy's pairwise mean of the first top_guess keys, the checks -- no read-back
+    tree = _eps_tree(L, top_guess, dev, st)
+    eps2 = torch.zeros(2, dtype=torch.float64, device=dev)
+    status6 = torch.zeros(6, dtype=torch.int64, device=dev)
+    check(L.ssg_sort_u64_dev(ptr(buf), n_cap, ptr(cursor), st), "ssg_sort_u64_dev")
+    check(L.ssg_eps_mean_run(ptr(buf), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), st), "ssg_eps_mean_run")
+    check(L.ssg_eps_check(ptr(buf), ptr(cursor), ptr(thr3), rho, upper_total, top_guess, n_cap, ptr(eps2), ptr(status6), st), "ssg_eps_check")
+    # ---- region query with eps read from the device, components, labels
+    cnt = torch.empty(h.nrows, dtype=torch.int32, device=dev)
+    ecap = max(64 * h.nrows, 1 << 16)
+    ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
+    ws_buf = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    labels = torch.empty(N, dtype=torch.int64, device=dev)
+    edges = torch.empty((ecap, 2), dtype=torch.int32, device=dev)
+    ecur = torch.zeros(2, dtype=torch.int64, device=dev)
+    if sp is not None:
+        check(L.ssg_region_query_s_dev(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.lambda_value, ptr(eps2), ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]),
+                                       sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), ptr(cnt), ptr(edges), ecap, ptr(ecur), st),
+              "ssg_region_query_s_dev")
+    else:
+        check(L.ssg_region_query_dev(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, ptr(eps2), ptr(cnt), ptr(edges), ecap, ptr(ecur), st),
+              "ssg_region_query_dev")
+    check(L.ssg_dbscan_cc_dev(ptr(cnt), ptr(edges), ptr(ecur), ecap, N, int(min_samples), ptr(ws_buf), ws_bytes, ptr(labels), st), "ssg_dbscan_cc_dev")
+    pend = h.take_pending() if hasattr(h, "take_pending") else None
+    npend = int(pend.numel()) if pend is not None else 0
+    host = torch.cat([ecur[:1], status6, eps2.view(torch.int64)] + ([pend.to(torch.int64)] if pend is not None else []) + [labels, cnt.to(torch.int64)]).cpu().numpy()   # THE read
+    ne, ok, got, zeros, top = int(host[0]), int(host[1]), int(host[2]), int(host[3]), int(host[4])
+    eps_f64, eps_hbits = float(host[7:8].view(np.float64)[0]), int(host[8:9].view(np.float64)[0]) if ok else 0
+    o = 9
+    if pend is not None:
+        if h.resolve_pending([int(x) for x in host[o:o + npend]]):
+            return eps_rule_dbscan(h, rho, min_samples)      # the query expansion had run on too small a guess: the matrix was rebuilt, run again (once)
+        h.validate()
+        o += npend
+    if not ok:
+        return two_calls()                                    # zeros in the triangle, or the sample missed: the two-call path decides (exactly)
+    count = upper_total - zeros
+    eps = np.uint16(eps_hbits).view(np.float16) if h.mode == 1 else eps_f64
+    if ne > ecap:                                             # the edge list was too small: eps is known now, the region query is redone with the exact size
+        est = DBSCAN(eps=eps, min_samples=min_samples, metric="precomputed").fit(h)
+        return eps, count, top, est.labels_, est.core_sample_indices_
+    lab = host[o:o + N].copy()
+    core = np.nonzero(host[o + N:o + N + h.nrows] >= int(min_samples))[0]
+    return eps, count, top, lab, core
+
+
 class DBSCAN:
     """sklearn.cluster.DBSCAN look-alike for metric='precomputed' running on the GPU."""
 

@@ -753,11 +753,13 @@ __device__ __forceinline__ unsigned rq_decide(const MatView& mv, unsigned flags,
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
+__global__ __launch_bounds__(256) void region_query_kernel(MatView mv, double eps_arg, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
                                                            unsigned long long cap, unsigned long long* __restrict__ cursor,
-                                                           const unsigned long long* __restrict__ gate, const unsigned char* __restrict__ rowmask) {
+                                                           const unsigned long long* __restrict__ gate, const unsigned char* __restrict__ rowmask,
+                                                           const double* __restrict__ eps_dev) {
   __shared__ Edge sbuf[4][STAGE_CAP];
   if (gate && *gate == 0ull) return;          // the sparse pass queued in front of this launch has done every row
+  const double eps = eps_dev ? *eps_dev : eps_arg;     // round 5: eps left on the device by the eps rule queued in front (NaN = "no eps": no hit)
   const int lane = lane_id();
   WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
   Edge* eout = reinterpret_cast<Edge*>(edges);
@@ -911,10 +913,11 @@ __global__ __launch_bounds__(256) void eps_compact_sparse_kernel(MatView mv, Spa
 
 // region query on S: row i is walked through S when floor_i = f64(J'(0)) + f64(half(v_i + vmin)) * lambda > eps (no column outside S can
 // be a neighbour then); other rows (all rows when S is unusable) get rowmask = 1 and raise cursor[1] for the dense pass behind this launch
-__global__ __launch_bounds__(256) void region_query_sparse_kernel(MatView mv, SparseView sv, double eps, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
+__global__ __launch_bounds__(256) void region_query_sparse_kernel(MatView mv, SparseView sv, double eps_arg, int32_t* __restrict__ cnt, int32_t* __restrict__ edges,
                                                                   unsigned long long cap, unsigned long long* __restrict__ cursor,
-                                                                  unsigned char* __restrict__ rowmask) {
+                                                                  unsigned char* __restrict__ rowmask, const double* __restrict__ eps_dev) {
   __shared__ Edge sbuf[4][SPARSE_STAGE];
+  const double eps = eps_dev ? *eps_dev : eps_arg;
   const int lane = lane_id();
   WaveStage<Edge> st{sbuf[threadIdx.x >> 6], 0};
   Edge* eout = reinterpret_cast<Edge*>(edges);
@@ -1181,6 +1184,126 @@ extern "C" int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t va
   return SSG_OK;
 }
 
+// ---- round 5: the eps rule without a host round trip between its full pass and the mean -------------------------------------------
+// The number of collected keys stays on the device (cursor[0] of the compaction pass).  The sort network is LAUNCHED for the capacity
+// n_cap (a power of two) but every kernel works on n_eff = the power of two >= max(*n_dev, SORT_CH) only: merge levels k > n_eff and
+// workgroups past n_eff exit at once (a handful of empty launches of ~2 us instead of a blocking read + a restart of the launch queue).
+__device__ __forceinline__ unsigned long long sort_n_eff(const unsigned long long* n_dev, unsigned long long n_cap) {
+  unsigned long long n = *n_dev, e = (unsigned long long)SORT_CH;
+  if (n > n_cap) n = n_cap;                     // (overflow of the compaction buffer: the check kernel reports it, the result is discarded)
+  while (e < n) e <<= 1;
+  return e;
+}
+__global__ void fill_u64_dev_kernel(unsigned long long* p, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap, unsigned long long v) {
+  const unsigned long long n1 = sort_n_eff(n_dev, n_cap);
+  unsigned long long n0 = *n_dev; if (n0 > n_cap) n0 = n_cap;
+  for (unsigned long long i = n0 + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; i < n1; i += (unsigned long long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ __launch_bounds__(1024) void bitonic_local_dev_kernel(unsigned long long* __restrict__ a, unsigned long long k_first, unsigned long long k_last,
+                                                                 const unsigned long long* __restrict__ n_dev, unsigned long long n_cap) {
+  __shared__ unsigned long long s[SORT_CH];
+  const unsigned long long n_eff = sort_n_eff(n_dev, n_cap);
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * SORT_CH;
+  if (g0 >= n_eff || k_first > n_eff) return;           // (uniform per workgroup)
+  const int t = (int)threadIdx.x;
+  s[t] = a[g0 + t]; s[t + 1024] = a[g0 + t + 1024];
+  __syncthreads();
+  for (unsigned long long k = k_first; k <= k_last; k <<= 1) {
+    for (unsigned long long j = (k >> 1) < (unsigned long long)(SORT_CH / 2) ? (k >> 1) : (unsigned long long)(SORT_CH / 2); j > 0; j >>= 1) {
+      const unsigned long long i = ((unsigned long long)t / j) * (2 * j) + ((unsigned long long)t % j);
+      const bool up = (((g0 + i) & k) == 0);
+      unsigned long long x = s[i], y = s[i + j];
+      cswap(x, y, up);
+      s[i] = x; s[i + j] = y;
+      __syncthreads();
+    }
+  }
+  a[g0 + t] = s[t]; a[g0 + t + 1024] = s[t + 1024];
+}
+template <int NS>
+__global__ __launch_bounds__(256) void bitonic_global_dev_kernel(unsigned long long* __restrict__ a, unsigned long long k, unsigned long long j,
+                                                                 const unsigned long long* __restrict__ n_dev, unsigned long long n_cap) {
+  constexpr int NE = 1 << NS;
+  const unsigned long long n_eff = sort_n_eff(n_dev, n_cap);
+  if (k > n_eff) return;
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_eff / NE) return;
+  const unsigned long long jl = j >> (NS - 1);
+  const unsigned long long base = (t / jl) * (NE * jl) + (t % jl);
+  const bool up = ((base & k) == 0);
+  unsigned long long e[NE];
+#pragma unroll
+  for (int b = 0; b < NE; b++) e[b] = a[base + (unsigned long long)b * jl];
+#pragma unroll
+  for (int s = NS - 1; s >= 0; s--) {
+#pragma unroll
+    for (int b = 0; b < NE; b++)
+      if (!(b & (1 << s))) cswap(e[b], e[b | (1 << s)], up);
+  }
+#pragma unroll
+  for (int b = 0; b < NE; b++) a[base + (unsigned long long)b * jl] = e[b];
+}
+// ascending sort of buf[0 .. *n_dev) inside a buffer of n_cap entries (n_cap = power of two >= 2048); entries [*n_dev, n_eff) are
+// overwritten with ~0 first.  After the call buf[0 .. *n_dev) is sorted (when *n_dev <= n_cap).
+extern "C" int ssg_sort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, hipStream_t stream) {
+  if (n_cap < (uint64_t)SORT_CH || (n_cap & (n_cap - 1)) || !n_dev) { ssg_set_error("ssg_sort_u64_dev: n_cap must be a power of two >= %d, n_dev non-null", SORT_CH); return SSG_ERR_INVALID; }
+  unsigned long long* a = (unsigned long long*)buf;
+  const unsigned long long* nd = (const unsigned long long*)n_dev;
+  const unsigned long long n = n_cap;
+  hipLaunchKernelGGL(fill_u64_dev_kernel, dim3(256), dim3(256), 0, stream, a, nd, n, ~0ULL);
+  hipLaunchKernelGGL(bitonic_local_dev_kernel, dim3((unsigned)(n / SORT_CH)), dim3(1024), 0, stream, a, 2ULL, (unsigned long long)SORT_CH, nd, n);
+  for (unsigned long long k = 2ULL * SORT_CH; k <= n; k <<= 1) {
+    unsigned long long j = k >> 1;
+    while (j >= (unsigned long long)SORT_CH) {
+      int ns = 0;
+      for (unsigned long long q = j; q >= (unsigned long long)SORT_CH && ns < 3; q >>= 1) ns++;
+      const unsigned long long thr = n >> ns;
+      const unsigned blocks = (unsigned)((thr + 255) / 256);
+      if (ns == 3) hipLaunchKernelGGL(bitonic_global_dev_kernel<3>, dim3(blocks), dim3(256), 0, stream, a, k, j, nd, n);
+      else if (ns == 2) hipLaunchKernelGGL(bitonic_global_dev_kernel<2>, dim3(blocks), dim3(256), 0, stream, a, k, j, nd, n);
+      else hipLaunchKernelGGL(bitonic_global_dev_kernel<1>, dim3(blocks), dim3(256), 0, stream, a, k, j, nd, n);
+      j >>= ns;
+    }
+    hipLaunchKernelGGL(bitonic_local_dev_kernel, dim3((unsigned)(n / SORT_CH)), dim3(1024), 0, stream, a, k, k, nd, n);
+  }
+  SSG_LAUNCH_CHECK("bitonic sort (device-sized)");
+  return SSG_OK;
+}
+
+// The a-posteriori checks of the sampled eps rule (ssg_amd/cluster.py _eps_rule_sampled) on the device, one thread:
+//   count = upper_total - zeros;  top = rint(rho * count) (np.round: half to even, selftraining.py:292) must equal the top_guess the
+//   summation tree was built for;  every collected key fits (got <= n_cap), at least `top` were collected, the threshold is finite and
+//   the top-th sorted key lies below it by the float32 surrogate's margin (=> the `top` smallest are all among the collected keys).
+// status6 = {ok, got, zeros, top, bits of the top-th key, threshold bits};  eps2[0] (the mean ssg_eps_mean_run left there) is replaced
+// by NaN when a check fails, so that a region query queued behind finds nothing and the caller falls back.
+__global__ void eps_check_kernel(const unsigned long long* __restrict__ sorted, const unsigned long long* __restrict__ cursor, const unsigned long long* __restrict__ thr3,
+                                 double rho, unsigned long long upper_total, long long top_guess, unsigned long long n_cap, double* __restrict__ eps2,
+                                 unsigned long long* __restrict__ status6) {
+  if (blockIdx.x || threadIdx.x) return;
+  const unsigned long long got = cursor[0], zeros = cursor[1];
+  const long long count = (long long)(upper_total - zeros);
+  const long long top = (long long)rint(rho * (double)count);
+  const double thr = (double)__uint_as_float((unsigned)(thr3[0] & 0xffffffffull));
+  bool ok = top == top_guess && top > 0 && got <= n_cap && got >= (unsigned long long)top && isfinite(thr);
+  unsigned long long kb = 0;
+  if (ok) {
+    kb = sorted[top - 1];
+    const double key_top = __longlong_as_double((long long)kb);
+    ok = key_top < thr - 1e-6 * (1.0 + fabs(thr));
+  }
+  status6[0] = ok ? 1ull : 0ull; status6[1] = got; status6[2] = zeros; status6[3] = (unsigned long long)top; status6[4] = kb; status6[5] = thr3[0];
+  if (!ok) eps2[0] = __longlong_as_double(0x7ff8000000000000ll);
+}
+extern "C" int ssg_eps_check(const uint64_t* sorted_keys, const uint64_t* cursor, const uint64_t* thr3, double rho, uint64_t upper_total, int64_t top_guess,
+                             uint64_t n_cap, double* eps2, uint64_t* status6, hipStream_t stream) {
+  if (!sorted_keys || !cursor || !thr3 || !eps2 || !status6) { ssg_set_error("ssg_eps_check: null argument"); return SSG_ERR_INVALID; }
+  hipLaunchKernelGGL(eps_check_kernel, dim3(1), dim3(64), 0, stream, (const unsigned long long*)sorted_keys, (const unsigned long long*)cursor,
+                     (const unsigned long long*)thr3, rho, (unsigned long long)upper_total, (long long)top_guess, (unsigned long long)n_cap, eps2,
+                     (unsigned long long*)status6);
+  SSG_LAUNCH_CHECK("eps_check_kernel");
+  return SSG_OK;
+}
+
 // workspace bytes for ssg_eps_mean: recursion tables + node values for `top` summands
 extern "C" size_t ssg_eps_mean_workspace_bytes(int64_t top) { const size_t nl = (size_t)(top / 32 + 64); return nl * 64 + 1024; }
 
@@ -1270,33 +1393,58 @@ extern "C" int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, 
   return rc ? rc : ssg_eps_mean_run(sorted_keys, top, mode, ws, ws_bytes, out2, stream);
 }
 
-extern "C" int ssg_region_query(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps,
-                                int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
+static int region_query_impl(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps, const double* eps_dev,
+                             int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
   int rc = check_view("ssg_region_query", M, v, N, row0, nrows, mode); if (rc) return rc;
 #define SSG_RQ(MD) hipLaunchKernelGGL(region_query_kernel<MD>, dim3(stream_grid(nrows)), dim3(256), 0, stream, make_view(M, v, N, row0, nrows, mode, lambda_value), eps, \
-                     cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor, (const unsigned long long*)nullptr, (const unsigned char*)nullptr)
+                     cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor, (const unsigned long long*)nullptr, (const unsigned char*)nullptr, eps_dev)
   if (mode == 0) SSG_RQ(0); else if (mode == 1) SSG_RQ(1); else SSG_RQ(2);
 #undef SSG_RQ
   SSG_LAUNCH_CHECK("region_query_kernel");
   return SSG_OK;
 }
+extern "C" int ssg_region_query(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, double eps,
+                                int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
+  return region_query_impl(M, v, N, row0, nrows, mode, lambda_value, eps, nullptr, cnt, edges, cap_edges, cursor, stream);
+}
+// round 5: eps is read from device memory (what ssg_eps_check left there), so that eps rule -> region query -> components run back
+// to back without the host seeing eps in between; a NaN there means "the eps rule's fast path did not verify": no hit, the caller redoes
+extern "C" int ssg_region_query_dev(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, const double* eps_dev,
+                                    int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor, hipStream_t stream) {
+  if (!eps_dev) { ssg_set_error("ssg_region_query_dev: null eps"); return SSG_ERR_INVALID; }
+  return region_query_impl(M, v, N, row0, nrows, mode, lambda_value, 0.0, eps_dev, cnt, edges, cap_edges, cursor, stream);
+}
 
 // Region query through the sparse copy S of J': cursor2 = {edges counted, dense pass needed} zeroed by the caller, rowmask = nrows bytes
 // of workspace.  Row i goes through S when J'(0) + lambda * half(v_i + vmin) > eps; the other rows (all of them when S overflowed) are
 // flagged and done by the dense pass queued behind, gated on cursor2[1].  Same outputs as ssg_region_query.
-extern "C" int ssg_region_query_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
-                                  const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
-                                  uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
-                                  hipStream_t stream) {
+static int region_query_s_impl(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const double* eps_dev,
+                               const uint32_t* s_pool, const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
+                               uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2, hipStream_t stream) {
   int rc = check_view("ssg_region_query_s", M, v, N, row0, nrows, 0); if (rc) return rc;
   if (!s_pool || !seg_off || !seg_len || nseg <= 0 || !s_cursor || !vmin || !rowmask) { ssg_set_error("ssg_region_query_s: no sparse copy"); return SSG_ERR_INVALID; }
   const MatView mv = make_view(M, v, N, row0, nrows, 0, lambda_value);
   hipLaunchKernelGGL(region_query_sparse_kernel, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, make_sparse(s_pool, seg_off, seg_len, nseg, s_cursor, vmin, jp0_half),
-                     eps, cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor2, rowmask);
+                     eps, cnt, edges, (unsigned long long)cap_edges, (unsigned long long*)cursor2, rowmask, eps_dev);
   hipLaunchKernelGGL(region_query_kernel<0>, dim3(stream_grid(nrows)), dim3(256), 0, stream, mv, eps, cnt, edges, (unsigned long long)cap_edges,
-                     (unsigned long long*)cursor2, (const unsigned long long*)(cursor2 + 1), (const unsigned char*)rowmask);
+                     (unsigned long long*)cursor2, (const unsigned long long*)(cursor2 + 1), (const unsigned char*)rowmask, eps_dev);
   SSG_LAUNCH_CHECK("region_query_sparse_kernel");
   return SSG_OK;
+}
+extern "C" int ssg_region_query_s(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, double eps, const uint32_t* s_pool,
+                                  const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
+                                  uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
+                                  hipStream_t stream) {
+  return region_query_s_impl(M, v, N, row0, nrows, lambda_value, eps, nullptr, s_pool, seg_off, seg_len, nseg, s_cursor, vmin, jp0_half, rowmask, cnt, edges, cap_edges,
+                             cursor2, stream);
+}
+extern "C" int ssg_region_query_s_dev(const void* M, const uint16_t* v, int N, int row0, int nrows, double lambda_value, const double* eps_dev, const uint32_t* s_pool,
+                                      const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
+                                      uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
+                                      hipStream_t stream) {
+  if (!eps_dev) { ssg_set_error("ssg_region_query_s_dev: null eps"); return SSG_ERR_INVALID; }
+  return region_query_s_impl(M, v, N, row0, nrows, lambda_value, 0.0, eps_dev, s_pool, seg_off, seg_len, nseg, s_cursor, vmin, jp0_half, rowmask, cnt, edges, cap_edges,
+                             cursor2, stream);
 }
 
 // workspace: parent[N] int32 | lab[N] int32 | rootflag[N] int32 | rootid[N+1] int64

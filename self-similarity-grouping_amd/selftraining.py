@@ -12,7 +12,7 @@ return structure so that selftraining.py can import them instead of its own defi
 import numpy as np
 import torch
 
-from .cluster import DBSCAN, as_handle, eps_rule
+from .cluster import DBSCAN, as_handle, eps_rule, eps_rule_dbscan  # noqa: F401
 from .rerank import DeviceBackedArray, re_ranking_device
 
 
@@ -57,14 +57,18 @@ def generate_selflabel(e_dist, r_dist, n_iter, args, cluster_list=[]):   # noqa:
     for s in range(len(r_dist)):
         tmp_dist = e_dist[s] if args.no_rerank else r_dist[s]
         if n_iter == 0:
-            eps, _, _ = eps_rule(tmp_dist, args.rho)
+            # eps rule + first fit as ONE device chain with one read-back (cluster.eps_rule_dbscan: the same eps, labels and core samples
+            # as eps_rule followed by DBSCAN.fit); the estimator is cached with its eps exactly like selftraining.py:283-298
+            eps, _, _, labels, core = eps_rule_dbscan(tmp_dist, args.rho, min_samples=4)
             print('eps in cluster: {:.3f}'.format(eps))
             cluster = DBSCAN(eps=eps, min_samples=4, metric='precomputed', n_jobs=8)
+            cluster.labels_, cluster.core_sample_indices_, cluster.n_features_in_ = labels, core, len(labels)
             cluster_list.append(cluster)
+            print('Clustering and labeling...')
         else:
             cluster = cluster_list[s]
-        print('Clustering and labeling...')
-        labels = cluster.fit_predict(tmp_dist)
+            print('Clustering and labeling...')
+            labels = cluster.fit_predict(tmp_dist)
         num_ids = len(set(labels.tolist())) - 1
         print('Iteration {} have {} training ids'.format(n_iter + 1, num_ids))
         labels_list.append(labels)

@@ -213,6 +213,80 @@ def test_query_expansion_guess_miss_is_redone(golden, dev, ora):
     assert np.array_equal(h4.final_dist().cpu().numpy(), g["final"])
 
 
+def test_eps_rule_dbscan_chain_equals_the_two_calls(dev, monkeypatch):
+    """round 5: cluster.eps_rule_dbscan (eps rule -> region query -> components on the device, ONE read-back) against eps_rule followed
+    by DBSCAN.fit on the same handle: eps, count, top, labels, core samples -- re-rank handles with and without the sparse copy, the half
+    matrix of the no-rerank path, an uploaded float64 matrix, duplicate rows (zeros in the triangle: the device check fails, the
+    two-call path answers), an edge list that is too small (the region query is redone), a missed query-expansion guess (the matrix is
+    rebuilt and the chain runs again), a rho whose top is not the guessed one."""
+    from ssg_amd import rerank, cluster
+    rho = 1.6e-3
+
+    def both(h, r=rho, ms=4):
+        e0 = cluster.eps_rule(h, r)
+        est = cluster.DBSCAN(eps=e0[0], min_samples=ms, metric="precomputed").fit(h)
+        got = cluster.eps_rule_dbscan(h, r, min_samples=ms)
+        assert bits(np.asarray(got[0])) == bits(np.asarray(e0[0])) if isinstance(e0[0], np.float16) else got[0] == e0[0], (got[0], e0[0])
+        assert got[1:3] == e0[1:3]
+        assert np.array_equal(got[3], est.labels_) and np.array_equal(got[4], est.core_sample_indices_)
+        return got
+
+    tgt = hard_clustered(3000, 96, 31); src = hard_clustered(900, 96, 32, intra=0.7)
+    s_d, t_d = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    h = rerank.re_ranking_device(s_d, t_d, lambda_value=0.3)
+    assert h.sparse is not None
+    g = both(h)
+    assert g[3].max() > 3 and (g[3] < 0).any()
+    both(h, ms=2)
+    monkeypatch.setenv("SSG_SPARSE", "0")
+    both(rerank.re_ranking_device(s_d, t_d, lambda_value=0.3))
+    monkeypatch.delenv("SSG_SPARSE")
+    he = rerank.re_ranking_device(s_d, t_d, no_rerank=True)                  # half matrix (mode 1): eps is a numpy float16
+    ge = both(he)
+    assert isinstance(ge[0], np.float16)
+    both(h.final_dist().cpu().numpy())                                       # an uploaded float64 matrix (mode 2)
+    # duplicates: exact zeros in the strict upper triangle -> count < N(N-1)/2, the guessed top may differ: the fallback answers
+    td = tgt.copy(); td[10:40] = td[100:130]
+    hd = rerank.re_ranking_device(s_d, torch.from_numpy(td).to(dev), no_rerank=True)
+    gd = both(hd)
+    assert gd[1] < 3000 * 2999 // 2
+    # an edge list that is too small: large eps through rho (many neighbours per row)
+    both(h, r=0.05)
+    # the chain as the FIRST consumer of a handle whose query expansion ran on too small a guess
+    old = dict(rerank._QE_GUESS)
+    try:
+        rerank._QE_GUESS[20] = 4
+        hm = rerank.re_ranking_device(s_d, t_d, lambda_value=0.3, validate=False)
+        assert hm._pending is not None
+        gm = cluster.eps_rule_dbscan(hm, rho)
+        assert hm._pending is None and gm[0] == g[0] and np.array_equal(gm[3], g[3])
+    finally:
+        rerank._QE_GUESS.clear(); rerank._QE_GUESS.update(old)
+    # host round trips of the chain: ONE
+    import bench
+    hc = rerank.re_ranking_device(s_d, t_d, lambda_value=0.3, validate=False)
+    cluster.eps_rule_dbscan(hc, rho)                                         # (tables cached)
+    hc = rerank.re_ranking_device(s_d, t_d, lambda_value=0.3, validate=False)
+    with bench.SyncCounter() as sc:
+        cluster.eps_rule_dbscan(hc, rho)
+    assert sc.n == 1, sc.n
+
+
+def test_sort_u64_dev_sorts_the_device_count(dev):
+    """ssg_sort_u64_dev: buf[0 .. *n_dev) sorted inside a buffer of n_cap entries for counts around the powers of two, 0 and n_cap"""
+    from ssg_amd import _lib
+    from ssg_amd._lib import check, ptr, stream
+    L = _lib.lib()
+    n_cap = 1 << 15
+    g = torch.Generator().manual_seed(3)
+    for n in (0, 1, 5, 2047, 2048, 2049, 4096, 5000, 8193, 20000, n_cap - 1, n_cap):
+        keys = torch.randint(0, 1 << 62, (n_cap,), generator=g, dtype=torch.int64)
+        buf = keys.to(dev)
+        nd = torch.tensor([n, 7, 9], dtype=torch.int64, device=dev)
+        check(L.ssg_sort_u64_dev(ptr(buf), n_cap, ptr(nd), stream()), "ssg_sort_u64_dev")
+        assert torch.equal(buf[:n].cpu(), torch.sort(keys[:n]).values), n
+
+
 def test_range_stats_kernel(dev):
     """ssg_range_stats_f32 (one launch for the four value ranges the host decides on) against torch: maxima exact, norms upper bounds
     within 2e-5 relative; NaN propagates."""

@@ -12,7 +12,8 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec
 
 K5_K12 = ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_jaccard_rows2", "ssg_half_min",
           "ssg_eps_hist", "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_refine_threshold", "ssg_eps_compact_below",
-          "ssg_eps_compact_below_s", "ssg_fill_u64", "ssg_sort_u64", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_region_query_s", "ssg_dbscan_cc",
+          "ssg_eps_compact_below_s", "ssg_fill_u64", "ssg_sort_u64", "ssg_sort_u64_dev", "ssg_eps_check", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_region_query_s",
+          "ssg_region_query_dev", "ssg_region_query_s_dev", "ssg_dbscan_cc",
           "ssg_dbscan_cc_dev")
 
 
@@ -59,12 +60,15 @@ def grouping_roofline(tot, N, nrows, Ns, world, steps, d=2048):
                          ("ssg_eps_compact_below_s", nn2 / 2, "eps rule, the one full pass, through the sparse copy S of J' where the threshold lies below the row's floor "
                           "(dense scan of the other rows): listed against the N^2 B of the upper triangle it replaces"),
                          ("ssg_region_query", nn2, "reads J' (2*N^2 B)"),
+                         ("ssg_region_query_dev", nn2, "reads J' (2*N^2 B); eps read from device memory"),
+                         ("ssg_region_query_s_dev", nn2, "region query through the sparse copy S of J' where eps (read from device memory) lies below the row's floor "
+                          "(dense scan of the other rows): listed against the 2*N^2 B it replaces"),
                          ("ssg_region_query_s", nn2, "region query through the sparse copy S of J' where eps lies below the row's floor (dense scan of the other rows): "
                           "listed against the 2*N^2 B it replaces")):
         if k in tot:
             n, ms = tot[k]
             gbs = byt * n / (ms * 1e-3) / 1e9
-            if k.endswith("_s"):
+            if k.endswith("_s") or k.endswith("_s_dev"):
                 # the sparse passes do not stream the matrix: no bandwidth figure, no roofline fraction -- the bytes they no longer move
                 hbm.append({"kernel": k, "bound": "latency (L2 round trips over a few hundred packed words + gathers of v per row)", "what": what, "launches": n,
                             "avg_launch_ms": round(ms / n, 4), "bytes_avoided": int(byt), "unit": "B per launch not streamed",
