@@ -75,6 +75,7 @@ struct Ctl {
   uint32_t xp;                           // raw half of the current pivot
   int ntail;                             // split mode: ranges handed to the tail kernel (they stay on `tail`, same triples)
   int tail[STACK * 3];
+  uint32_t ov_el, ov_e2;                 // streamed partition: what the median-of-3 step leaves at positions 0 and pm of the (read-only) source
 };
 
 // Split mode (default): the workgroup kernel only runs the partitions of ranges longer than `tailn` entries and hands every
@@ -443,11 +444,11 @@ __device__ __forceinline__ Split split_ranges(int pl, int pr, int pi) {
 // tailn > 0: split mode -- ranges of at most tailn entries are recorded in sh->tail (sh->ntail) instead of being finished here;
 // tailn == 0: everything is finished in this kernel (ranges of at most WAVE_N entries by wave 0 alone, the round-2 behaviour).
 template <int NT, class Arena>
-__device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int N, int K, int tailn PROF_ARG) {
+__device__ __forceinline__ void sort_prefix(const Arena& A, Ctl* sh, const Masks& mk, float fmx, int N, int K, int tailn, int cd0 PROF_ARG) {
   const int tid = (int)threadIdx.x, lane = lane_id(), wav = tid >> 6;
   const int wave_n = tailn > 0 ? tailn : WAVE_N;
   int sp = 0, ntail = 0;
-  int pl = 0, pr = N - 1, cd = 2 * (31 - __clz(N));
+  int pl = 0, pr = N - 1, cd = cd0;      // cd0 = 2 * floor(log2 N) for a whole row (numpy's depth budget)
   bool have = true;
   for (;;) {
     if (!have) {
@@ -558,7 +559,8 @@ __device__ __forceinline__ void sort_tail(const Arena& A, Ctl* sh, const Masks& 
 template <bool LDS, int NT>
 __global__ __launch_bounds__(NT) void topk_introsort_kernel(const hbits* __restrict__ D, const unsigned* __restrict__ rowmax, int N, int nrows,
                                                             int K, int wcap, uint32_t* __restrict__ arena, size_t arena_stride,
-                                                            int32_t* __restrict__ rank, int tailn, uint32_t* __restrict__ tails, size_t tail_stride) {
+                                                            int32_t* __restrict__ rank, int tailn, uint32_t* __restrict__ tails, size_t tail_stride,
+                                                            const int* __restrict__ only) {
   extern __shared__ __align__(16) unsigned char smem[];
   Ctl* sh = reinterpret_cast<Ctl*>(smem);
   Masks mk;
@@ -568,6 +570,7 @@ __global__ __launch_bounds__(NT) void topk_introsort_kernel(const hbits* __restr
   uint32_t* ent = mk.P + wcap;            // wcap is a multiple of 4: 16-byte aligned
   const int tid = (int)threadIdx.x;
   for (int row = (int)blockIdx.x; row < nrows; row += (int)gridDim.x) {
+    if (only && only[row] == 0) continue;   // (uniform) fallback launch behind the streamed kernel: only the rows it flagged
 #ifdef SSG_INTRO_PROF
     ProfAcc pacc_;
 #pragma unroll
@@ -636,12 +639,12 @@ __global__ __launch_bounds__(NT) void topk_introsort_kernel(const hbits* __restr
     };
     if (LDS) {
       LdsArena A{ent + first};
-      sort_prefix<NT>(A, sh, mk, fmx, N, K, tailn PROF_PASS);
+      sort_prefix<NT>(A, sh, mk, fmx, N, K, tailn, 2 * (31 - __clz(N)) PROF_PASS);
       PROF(9);
       finish(A);
     } else {
       GlobalArena A{dst + first};
-      sort_prefix<NT>(A, sh, mk, fmx, N, K, tailn PROF_PASS);
+      sort_prefix<NT>(A, sh, mk, fmx, N, K, tailn, 2 * (31 - __clz(N)) PROF_PASS);
       finish(A);
     }
     __syncthreads();
@@ -691,6 +694,429 @@ __global__ __launch_bounds__(64) void topk_introsort_tail_kernel(const uint32_t*
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: rows that do not fit in LDS (N > ~36 k) -- the first levels of the walk as OUT-OF-PLACE, streamed partitions.
+//
+// The in-place kernel above keeps such a row in a global arena and performs every swap of every level there: N/4 random 4-byte
+// read-modify-writes of a 512 KB row at level 1 alone (configs[4], N = 128 000: 350 ms, 0.012 of the HBM rate of the bytes it reads).
+// On the main path of the walk only the LEFT child of a partition is needed (every range that intersects columns [0, K) starts at 0
+// until a pivot lands inside [0, K)), and after the m swaps the left child is
+//     left[0] = the smallest median candidate;  left[p] = A[p] for p <= p* that are not L-stoppers;
+//     left[p] = A[R_k] for the k-th L-stopper from the left (R_k = the k-th R-stopper from the right),
+// where A is the source as the median-of-3 step leaves it (positions 0 and pm overridden).  So a level READS its source in order (the
+// row of D itself at level 1: 2 bytes per column, entries are built on the fly -- the row is never materialised at full length),
+// builds the stopper masks as bytes (8 positions per lane and 16-byte load), and WRITES the left child once: into LDS when it fits
+// (then the LDS code above takes over), else into one of two global buffers of the workgroup.  The pairing goes through a staging
+// buffer in LDS, RBUF ranks at a time: pass X collects the R-stoppers of ranks [k0, k1] in rank order from the mask words at the right
+// end, pass Y hands them to the L-stoppers of the same ranks at the left end -- both passes touch whole mask words with one lane per
+// bit, every global access is coalesced, and no rank -> position search runs per element.
+// tools/introsort_model.py (stream_partition_left) states the same computation word by word and is checked against the in-place model.
+// A pivot that lands inside [0, K) (both children matter) is not handled here: the row is flagged and redone by the in-place kernel.
+#ifndef SSG_STREAM_RBUF
+#define SSG_STREAM_RBUF 8192
+#endif
+#ifndef SSG_STREAM_SU
+#define SSG_STREAM_SU 4
+#endif
+#ifndef SSG_STREAM_SX
+#define SSG_STREAM_SX 8
+#endif
+constexpr int RBUF = SSG_STREAM_RBUF;  // ranks per staging pass (32 KB of LDS; 4096: +4 % time at N = 128 000, 8192 leaves 22 k entries of LDS for the row)
+constexpr int SU = SSG_STREAM_SU;      // 8-entry groups a thread keeps in flight in passes B1 / E1
+constexpr int SX = SSG_STREAM_SX;      // mask words a wave keeps in flight in passes X / Y
+
+// What a streamed level reads; position p lives at index q = p + qs.  Two kinds, a compile-time switch (a run-time branch in front of
+// every load made hipcc wait for each load before it issued the next: the loads of a batch must be straight-line code):
+//   DROW: the row of D itself, halves, through a buffer resource that starts at the row's 16-byte-aligned base and ends with the
+//         matrix (reads past the end return 0: the last group of the last row needs no special case); entries are built on the fly;
+//   else: materialised entries arr[q] in one of the workgroup's global buffers (always read in bounds).
+struct Raw8 { uint4 a, b; };
+template <bool DROW> struct Src {
+  const uint32_t* arr; __amdgpu_buffer_rsrc_t rs; int qs;
+  __device__ __forceinline__ uint32_t get(int p) const {
+    const int q = p + qs;
+    if constexpr (DROW) {
+      const uint32_t raw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, q * 2, 0, 0) & 0x7fffu;
+      return (raw << IDX_BITS) | ((uint32_t)p & IDX_MASK);
+    } else return arr[q];
+  }
+  __device__ __forceinline__ void load8(int c, Raw8& r) const {
+    if constexpr (DROW) {
+      typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+      const v4u_ x = __builtin_amdgcn_raw_buffer_load_b128(rs, c * 16, 0, 0);
+      r.a = make_uint4(x[0], x[1], x[2], x[3]);
+    } else { r.a = *reinterpret_cast<const uint4*>(arr + (size_t)c * 8); r.b = *reinterpret_cast<const uint4*>(arr + (size_t)c * 8 + 4); }
+  }
+  __device__ __forceinline__ void decode8(int c, const Raw8& r, uint32_t (&e)[8]) const {
+    if constexpr (DROW) {
+      const unsigned w[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
+#pragma unroll
+      for (int i = 0; i < 8; i++) e[i] = (((w[i >> 1] >> ((i & 1) * 16)) & 0x7fffu) << IDX_BITS) | ((uint32_t)(c * 8 + i - qs) & IDX_MASK);
+    } else { e[0] = r.a.x; e[1] = r.a.y; e[2] = r.a.z; e[3] = r.a.w; e[4] = r.b.x; e[5] = r.b.y; e[6] = r.b.z; e[7] = r.b.w; }
+  }
+  // stopper bits of the 8 positions of a group, no per-position range / override checks (the caller redoes the few groups that need them):
+  // raw >= tlo <=> bit 15 of (raw | 0x8000) - tlo;  raw <= thi <=> bit 15 of (thi | 0x8000) - raw  (raw, tlo, thi < 0x8000) -- two halves per
+  // dword for the row of D (no borrow crosses the halves: the low half's difference is never negative)
+  __device__ __forceinline__ void stopper_bits8(const Raw8& r, uint32_t tlo, uint32_t thi, unsigned& lb, unsigned& rb) const {
+    lb = 0; rb = 0;
+    if constexpr (DROW) {
+      const unsigned w[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
+      const uint32_t tl2 = tlo * 0x10001u, th2 = (thi | 0x8000u) * 0x10001u;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t x = w[j] & 0x7fff7fffu;
+        const uint32_t tL = (x | 0x80008000u) - tl2, tR = th2 - x;
+        lb |= (((tL >> 15) & 1u) | ((tL >> 30) & 2u)) << (2 * j);
+        rb |= (((tR >> 15) & 1u) | ((tR >> 30) & 2u)) << (2 * j);
+      }
+    } else {
+      const uint32_t e[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+      const uint32_t th = thi | 0x8000u;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t x = e[i] >> IDX_BITS;
+        lb |= ((((x | 0x8000u) - tlo) >> 15) & 1u) << i;
+        rb |= (((th - x) >> 15) & 1u) << i;
+      }
+    }
+  }
+};
+
+// word holding the r-th (1-based, from the left) stopper, two ballots instead of word_of_rank's dependent binary searches: the chunk is
+// the last one whose exclusive offset (lane c of `ex`) is below r, the word inside it the first whose running count reaches r - offset
+template <bool RIGHT>
+__device__ __forceinline__ int word_of_rank_ballot(const uint32_t* P, uint32_t ex, int W, int cs, int nch, uint32_t r) {
+  const int lane = lane_id();
+  const int ch = __popcll(__ballot(lane < nch && ex < r)) - 1;            // (ex[0] = 0 < r)
+  const uint32_t rr = r - (uint32_t)__builtin_amdgcn_readlane((int)ex, ch);
+  const int w = (ch << cs) + lane;
+  const bool valid = lane < (1 << cs) && w < W;
+  const uint32_t pw = valid ? P[w] : 0u;
+  const uint32_t c = RIGHT ? (pw >> 16) : (pw & 0xffffu);
+  return (ch << cs) + __popcll(__ballot(valid && c < rr));
+}
+
+// passes E1 / X / Y of a streamed partition: the left child [0, pi) into tgt (index q = p + qs; LDS or global memory)
+template <int NT, bool DROW, class Tgt>
+__device__ __forceinline__ void stream_emit(const Src<DROW>& s, Tgt tgt, uint32_t* rbuf, const Masks& mk, int n, int W, int cs, int nch, uint32_t exL, uint32_t exR,
+                                            uint32_t totR, uint32_t m, int pstar, int pm, uint32_t el, uint32_t e2 PROF_ARG) {
+  constexpr int NW = NT / 64;
+  const int tid = (int)threadIdx.x, lane = lane_id(), wav = __builtin_amdgcn_readfirstlane(tid >> 6), qs = s.qs;
+  PROF_DECL;
+  // E1: every position of the left child from the source (coalesced); the L-stopper positions are overwritten by pass Y.  The two
+  // positions the median-of-3 step changed (0 and pm) are patched by the thread that stored their group, right behind its store.
+  const int clast = (pstar + qs) >> 3;
+  const int c_pm = pm <= pstar ? ((pm + qs) >> 3) : -1;
+  for (int c0 = tid; c0 <= clast; c0 += SU * NT) {
+    Raw8 raw[SU];
+#pragma unroll
+    for (int u = 0; u < SU; u++) s.load8(min(c0 + u * NT, clast), raw[u]);          // (clamped, unconditional: straight-line loads)
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const int c = c0 + u * NT;
+      if (c <= clast) {
+        uint32_t e[8];
+        s.decode8(c, raw[u], e);
+        *reinterpret_cast<uint4*>(&tgt[c * 8]) = make_uint4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<uint4*>(&tgt[c * 8 + 4]) = make_uint4(e[4], e[5], e[6], e[7]);
+        if (c == c_pm) tgt[pm + qs] = e2;
+        if (c == 0) tgt[qs] = el;
+      }
+    }
+  }
+  __syncthreads();
+  PROF(4);
+  const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+  for (uint32_t k0 = 1; k0 <= m; k0 += RBUF) {          // (m is workgroup-uniform: every thread runs the same barriers)
+    const uint32_t k1 = min(m, k0 + RBUF - 1u);
+    // X: the R-stoppers of ranks k0..k1 from the right = left ranks totR-k1+1 .. totR-k0+1, in rank order into rbuf.  SX mask words per
+    // trip and wave: mask words first (LDS broadcasts), then every lane's global read (unconditional, clamped), then the LDS stores
+    const int wa = uni(word_of_rank_ballot<true>(mk.P, exR, W, cs, nch, totR - k1 + 1u));
+    const int wb = uni(word_of_rank_ballot<true>(mk.P, exR, W, cs, nch, totR - k0 + 1u));
+    PROF(8);
+    for (int w0 = wa + wav; w0 <= wb; w0 += SX * NW) {
+      uint64_t rm[SX]; uint32_t pw[SX];
+#pragma unroll
+      for (int u = 0; u < SX; u++) { const int w = min(w0 + u * NW, wb); rm[u] = mk.R[w]; pw[u] = mk.P[w]; }
+      uint32_t val[SX];
+#pragma unroll
+      for (int u = 0; u < SX; u++) val[u] = s.get(min(max((min(w0 + u * NW, wb) << 6) + lane - qs, 0), n - 1));
+#pragma unroll
+      for (int u = 0; u < SX; u++) {
+        const int w = w0 + u * NW;
+        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exR, min(w, wb) >> cs) + (pw[u] >> 16) - (uint32_t)__popcll(rm[u]);
+        const uint32_t kk = totR - (before + (uint32_t)__popcll(rm[u] & le)) + 1u;
+        if (w <= wb && ((rm[u] >> lane) & 1ull) && kk >= k0 && kk <= k1) rbuf[kk - k0] = ((w << 6) + lane - qs == pm) ? e2 : val[u];
+      }
+    }
+    PROF(9);
+    __syncthreads();
+    PROF(5);
+    // Y: the L-stoppers of ranks k0..k1 take them
+    const int wc = uni(word_of_rank_ballot<false>(mk.P, exL, W, cs, nch, k0));
+    const int wd = uni(word_of_rank_ballot<false>(mk.P, exL, W, cs, nch, k1));
+    PROF(10);
+    for (int w0 = wc + wav; w0 <= wd; w0 += SX * NW) {
+      uint64_t lm[SX]; uint32_t pw[SX];
+#pragma unroll
+      for (int u = 0; u < SX; u++) { const int w = min(w0 + u * NW, wd); lm[u] = mk.L[w]; pw[u] = mk.P[w]; }
+      uint32_t val[SX]; uint32_t kk[SX];
+#pragma unroll
+      for (int u = 0; u < SX; u++) {
+        const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)exL, min(w0 + u * NW, wd) >> cs) + (pw[u] & 0xffffu) - (uint32_t)__popcll(lm[u]);
+        kk[u] = before + (uint32_t)__popcll(lm[u] & le);
+        val[u] = rbuf[min(max(kk[u], k0), k1) - k0];                 // (unconditional, clamped: straight-line LDS reads)
+      }
+#pragma unroll
+      for (int u = 0; u < SX; u++) {
+        const int w = w0 + u * NW;
+        if (w <= wd && ((lm[u] >> lane) & 1ull) && kk[u] >= k0 && kk[u] <= k1) tgt[(w << 6) + lane] = val[u];
+      }
+    }
+    PROF(11);
+    __syncthreads();
+    PROF(6);
+  }
+}
+
+// One streamed partition of the n entries of `s` (n > SMALL + 1).  Returns the pivot position pi = the length of the left child, which is
+// written to `lds` (index q; *to_lds = true) when pi + qs + 8 <= lds_cap entries, else to `glob`.
+template <int NT, bool DROW>
+__device__ __forceinline__ int stream_partition(const Src<DROW>& s, int n, Ctl* sh, const Masks& mk, uint32_t* rbuf, float fmx, uint32_t* lds, int lds_cap,
+                                                uint32_t* glob, bool& to_lds PROF_ARG) {
+  constexpr int NW = NT / 64;
+  const int tid = (int)threadIdx.x, lane = lane_id(), wav = __builtin_amdgcn_readfirstlane(tid >> 6), qs = s.qs;
+  PROF_DECL;
+  const int pr = n - 1, pm = pr >> 1, s0 = 1, s1 = pr - 2;
+  const int W = (n + qs + 63) >> 6;
+  int cs = 2;
+  while (((W + (1 << cs) - 1) >> cs) > MAXCH) cs++;
+  const int nch = (W + (1 << cs) - 1) >> cs;
+  // ---- A: median of three on keys (quicksort.cpp), recorded as overrides of the read-only source: A[0] = el, A[pm] = e2 (the old
+  //         A[pr-1]); the pivot is parked at pr-1 and A[pr] = er -- both outside everything a left child reads
+  if (tid == 0) {
+    uint32_t el = s.get(0), em = s.get(pm), er = s.get(pr), t;
+    const uint32_t e2 = s.get(pr - 1);
+    uint32_t kl = norm_key(eraw(el), fmx), km = norm_key(eraw(em), fmx), kr = norm_key(eraw(er), fmx);
+    if (km < kl) { t = em; em = el; el = t; t = km; km = kl; kl = t; }
+    if (kr < km) { t = er; er = em; em = t; t = kr; kr = km; km = t; }
+    if (km < kl) { t = em; em = el; el = t; }
+    sh->ov_el = el; sh->ov_e2 = e2; sh->xp = eraw(em);
+  }
+  __syncthreads();
+  const uint32_t el = uni(sh->ov_el), e2 = uni(sh->ov_e2);
+  uint32_t tlo, thi;
+  key_class(uni(sh->xp), fmx, tlo, thi);
+  tlo = uni(tlo); thi = uni(thi);
+  PROF(0);
+  // ---- B1: stopper masks, one BYTE per lane and 8 positions (bit q of the mask arrays <-> position q - qs; zero outside the scan region)
+  {
+    uint8_t* Lb = reinterpret_cast<uint8_t*>(mk.L);
+    uint8_t* Rb = reinterpret_cast<uint8_t*>(mk.R);
+    const int ngroups = (n + qs + 7) >> 3;
+    // groups that hold a position outside the scan region [s0, s1] or the overridden position pm take the per-position path
+    const int c_lo = (s0 + qs) >> 3, c_hi = (s1 + qs - 7) >> 3, c_pm = (pm + qs) >> 3;      // groups c_lo < c <= c_hi are wholly inside
+    for (int c0 = tid; c0 < W * 8; c0 += SU * NT) {
+      Raw8 raw[SU];
+#pragma unroll
+      for (int u = 0; u < SU; u++) s.load8(min(c0 + u * NT, ngroups - 1), raw[u]);      // (clamped, unconditional)
+#pragma unroll
+      for (int u = 0; u < SU; u++) {
+        const int c = c0 + u * NT;
+        if (c < W * 8) {
+          unsigned lb = 0, rb = 0;
+          if (c < ngroups) {
+            if (c > c_lo && c <= c_hi && c != c_pm) s.stopper_bits8(raw[u], tlo, thi, lb, rb);
+            else {
+              uint32_t e[8];
+              s.decode8(c, raw[u], e);
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                const int p = c * 8 + i - qs;
+                const uint32_t x = eraw(p == pm ? e2 : e[i]);
+                const bool in = p >= s0 && p <= s1;
+                lb |= (in && x >= tlo ? 1u : 0u) << i;
+                rb |= (in && x <= thi ? 1u : 0u) << i;
+              }
+            }
+          }
+          Lb[c] = (uint8_t)lb; Rb[c] = (uint8_t)rb;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  PROF(1);
+  // ---- B2: running stopper counts inside each chunk of 2^cs words (<= 64: one lane per word) and the chunk totals
+  for (int ch = wav; ch < nch; ch += NW) {
+    const int w = (ch << cs) + lane;
+    const bool valid = lane < (1 << cs) && w < W;
+    const uint32_t cl = valid ? (uint32_t)__popcll(mk.L[w]) : 0u, cr = valid ? (uint32_t)__popcll(mk.R[w]) : 0u;
+    const uint32_t il = wave_incl_scan(cl), ir = wave_incl_scan(cr);
+    if (valid) mk.P[w] = il | (ir << 16);
+    if (lane == 63) { sh->ctotL[ch] = il; sh->ctotR[ch] = ir; }
+  }
+  __syncthreads();
+  PROF(2);
+  // ---- C: chunk prefix in registers, crossing word (as in partition())
+  const uint32_t cL = lane < nch ? sh->ctotL[lane] : 0u, cR = lane < nch ? sh->ctotR[lane] : 0u;
+  const uint32_t inL = wave_incl_scan(cL), inR = wave_incl_scan(cR);
+  const uint32_t exL = inL - cL, exR = inR - cR;
+  const uint32_t totL = (uint32_t)__builtin_amdgcn_readlane((int)inL, 63), totR = (uint32_t)__builtin_amdgcn_readlane((int)inR, 63);
+  int wstar = 0;
+  for (int wb = 0; wb < W; wb += 64) {
+    const int w = wb + lane;
+    const bool valid = w < W;
+    const int wc = valid ? w : W - 1;
+    const uint32_t oL = (uint32_t)__shfl((int)exL, wc >> cs), oR = (uint32_t)__shfl((int)exR, wc >> cs);
+    const uint32_t pw = mk.P[wc];
+    const bool g = valid && (totR - ((pw >> 16) + oR)) >= ((pw & 0xffffu) + oL);
+    const int pc = __popcll(__ballot(g));
+    wstar += pc;
+    if (pc != 64) break;
+  }
+  // ---- D: number of swaps m and p* (bits outside the scan region are zero in both masks: p* is clamped to [s0 - 1, s1] afterwards)
+  uint32_t m;
+  int pstar;
+  if (wstar >= W) {
+    m = totL; pstar = s1;
+  } else {
+    const uint64_t lm = uni(mk.L[wstar]), rm = uni(mk.R[wstar]);
+    const int ch = wstar >> cs;
+    const uint32_t pw = uni(mk.P[wstar]);
+    const uint32_t pL = (pw & 0xffffu) + uni((uint32_t)__shfl((int)exL, ch)), pR = (pw >> 16) + uni((uint32_t)__shfl((int)exR, ch));
+    const uint32_t cumL = pL - (uint32_t)__popcll(lm);
+    const uint32_t cumR = totR - pR;
+    const uint64_t le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const uint32_t f = cumL + (uint32_t)__popcll(lm & le);
+    const uint32_t g = cumR + (uint32_t)__popcll(rm & ~le);
+    const uint64_t bal = __ballot(g >= f);
+    if (bal == 0) {
+      m = cumL; pstar = (wstar << 6) - 1 - qs;
+    } else {
+      const int b = 63 - __clzll((long long)bal);
+      const uint64_t leb = (b == 63) ? ~0ull : ((2ull << b) - 1ull);
+      m = cumL + (uint32_t)__popcll(lm & leb);
+      pstar = (wstar << 6) + b - qs;
+    }
+  }
+  m = uni(m);
+  pstar = uni(pstar);
+  pstar = max(s0 - 1, min(pstar, s1));
+  const int pi = pstar + 1;
+  to_lds = pi + qs + 8 <= lds_cap;
+  PROF(3);
+  if (to_lds) stream_emit<NT, DROW>(s, lds, rbuf, mk, n, W, cs, nch, exL, exR, totR, m, pstar, pm, el, e2 PROF_PASS);
+  else stream_emit<NT, DROW>(s, glob, rbuf, mk, n, W, cs, nch, exL, exR, totR, m, pstar, pm, el, e2 PROF_PASS);
+  return pi;
+}
+
+// split-mode hand-over of a finished LDS row (or the K ranks when there is no tail kernel)
+template <int NT, class Arena>
+__device__ __forceinline__ void hand_over(const Arena& A, Ctl* sh, int row, int K, int tailn, uint32_t* __restrict__ tails, size_t tail_stride,
+                                          int32_t* __restrict__ rank) {
+  const int tid = (int)threadIdx.x;
+  if (tailn == 0) {
+    if (tid < K) rank[(int64_t)row * K + tid] = (int32_t)(A.get(tid) & IDX_MASK);
+    return;
+  }
+  const int nt = sh->ntail;
+  int hi = K;
+  for (int q = 0; q < nt; q++) hi = max(hi, sh->tail[3 * q + 1] + 1);
+  uint32_t* trow = tails + (size_t)row * tail_stride;
+  if (tid == 0) { trow[0] = (uint32_t)nt; trow[1] = (uint32_t)hi; }
+  for (int q = tid; q < 3 * nt; q += NT) trow[4 + q] = (uint32_t)sh->tail[q];
+  for (int j = tid; j < hi; j += NT) trow[TAIL_HDR_WORDS + j] = A.get(j);
+}
+
+// LDS: Ctl | L[wcap] R[wcap] P[wcap] | rbuf[RBUF] | entries[lds_cap].  Persistent workgroups (one per CU: the LDS is full), two global
+// buffers of entry_words(N) words each per workgroup for left children that do not fit yet.
+template <int NT>
+__global__ __launch_bounds__(NT) void topk_introsort_stream_kernel(const hbits* __restrict__ D, const unsigned* __restrict__ rowmax, int N, int nrows, int K,
+                                                                   int wcap, uint32_t* __restrict__ bufs, size_t buf_stride, int lds_cap,
+                                                                   int32_t* __restrict__ rank, int tailn, uint32_t* __restrict__ tails, size_t tail_stride,
+                                                                   int* __restrict__ redo) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  Ctl* sh = reinterpret_cast<Ctl*>(smem);
+  Masks mk;
+  mk.L = reinterpret_cast<uint64_t*>(smem + ((sizeof(Ctl) + 15) & ~(size_t)15));
+  mk.R = mk.L + wcap;
+  mk.P = reinterpret_cast<uint32_t*>(mk.R + wcap);
+  uint32_t* rbuf = mk.P + wcap;
+  uint32_t* ent = rbuf + RBUF;
+  uint32_t* gb[2] = {bufs + (size_t)blockIdx.x * 2 * buf_stride, bufs + ((size_t)blockIdx.x * 2 + 1) * buf_stride};
+  const int tid = (int)threadIdx.x;
+  const int64_t total = (int64_t)nrows * N;
+  for (int row = (int)blockIdx.x; row < nrows; row += (int)gridDim.x) {
+    const float fmx = h2f((hbits)rowmax[row]);
+    const int64_t base = (int64_t)row * N;
+    const int64_t al = base & ~(int64_t)7;
+    const int first = (int)(base - al);
+    // level 1 reads the row of D through a buffer resource (from the row's aligned base to the end of the matrix, at most 4 GB)
+    const int64_t rs_bytes = (total - al) * 2;
+    Src<true> drow{nullptr, __builtin_amdgcn_make_buffer_rsrc(const_cast<hbits*>(D + al), 0, (int)(rs_bytes > 0x7ffffff0ll ? 0x7ffffff0ll : rs_bytes), 0x00020000), first};
+    int n = N, cd = 2 * (31 - __clz(N)), which = 0, level = 0;
+    bool in_lds = false, bad = false;
+#ifdef SSG_INTRO_PROF
+    ProfAcc pacc_;
+#pragma unroll
+    for (int i_ = 0; i_ < 16; i_++) pacc_.a[i_] = 0;
+    unsigned long long prof_lds_ = 0;
+#endif
+    while (n + first + 8 > lds_cap) {
+      bool to_lds;
+      int pi;
+      if (level == 0) pi = stream_partition<NT, true>(drow, n, sh, mk, rbuf, fmx, ent, lds_cap, gb[which], to_lds PROF_PASS);
+      else {
+        const Src<false> arr{gb[which ^ 1], drow.rs, first};
+        pi = stream_partition<NT, false>(arr, n, sh, mk, rbuf, fmx, ent, lds_cap, gb[which], to_lds PROF_PASS);
+      }
+      --cd; ++level;
+      if (pi + 1 < K) { bad = true; break; }        // the right child intersects [0, K) as well: (rare) redone by the in-place kernel
+      n = pi;
+      if (to_lds) { in_lds = true; break; }
+      which ^= 1;
+      __syncthreads();                                // the left child in global memory is complete (and visible to every wave) before it is read
+    }
+    if (bad) {
+      if (tid == 0) redo[row] = 1;
+      __syncthreads();
+      continue;
+    }
+    if (!in_lds) {                                    // the range fits from the start (a short row forced onto this path): into LDS as it is
+      for (int c = tid; c <= ((n - 1 + first) >> 3); c += NT) {
+        uint32_t e[8];
+        Raw8 r8;
+        drow.load8(c, r8);
+        drow.decode8(c, r8, e);
+        *reinterpret_cast<uint4*>(ent + c * 8) = make_uint4(e[0], e[1], e[2], e[3]);
+        *reinterpret_cast<uint4*>(ent + c * 8 + 4) = make_uint4(e[4], e[5], e[6], e[7]);
+      }
+    }
+    __syncthreads();
+    LdsArena A{ent + first};
+#ifdef SSG_INTRO_PROF
+    prof_lds_ = clock64();
+    ProfAcc pdummy_;        // (the LDS stage's own phase slots are not wanted here: one total)
+#pragma unroll
+    for (int i_ = 0; i_ < 16; i_++) pdummy_.a[i_] = 0;
+    { ProfAcc& pacc2_ = pdummy_; (void)pacc2_; }
+    sort_prefix<NT>(A, sh, mk, fmx, n, K, tailn, cd, pdummy_);
+#else
+    sort_prefix<NT>(A, sh, mk, fmx, n, K, tailn, cd);
+#endif
+    hand_over<NT>(A, sh, row, K, tailn, tails, tail_stride, rank);
+    __syncthreads();
+#ifdef SSG_INTRO_PROF
+    pacc_.a[7] += clock64() - prof_lds_;
+    if (tid == 0) {
+#pragma unroll
+      for (int i_ = 0; i_ < 16; i_++) if (pacc_.a[i_]) atomicAdd(&g_prof[i_], pacc_.a[i_]);
+    }
+#endif
+  }
+}
+
 constexpr size_t LDS_LIMIT = 160 * 1024;
 __host__ inline int mask_words(int N) { return (((N + 63) / 64 + 1) + 3) & ~3; }          // padded to the flag pass's 4-word groups
 __host__ inline size_t entry_words(int N) { return (size_t)((N + 7 + 7) / 8) * 8; }         // whole 8-entry groups incl. the alignment shift
@@ -707,13 +1133,54 @@ __host__ inline int tail_threshold() {
 __host__ inline size_t tail_stride_words(int tailn) { return (size_t)TAIL_HDR_WORDS + (size_t)((64 + tailn + 3) & ~3); }
 __host__ inline size_t tail_bytes(int nrows) { const int t = tail_threshold(); return t > 0 ? (size_t)nrows * tail_stride_words(t) * 4 : 0; }
 
+// streamed kernel geometry: persistent workgroups (one per CU), LDS entry capacity, fallback arena blocks
+__host__ inline int stream_nt() { const char* e_ = getenv("SSG_INTRO_STREAM_NT"); const int v = e_ ? atoi(e_) : 1024; return v == 512 ? 512 : 1024; }
+__host__ inline int stream_lds_cap(int N);
+__host__ inline size_t stream_lds_bytes(int N);
+// persistent workgroups: as many per CU as the LDS (and the 2048 threads of a CU) hold
+__host__ inline int stream_blocks(int N, int nrows) {
+  int per_cu = (int)(LDS_LIMIT / stream_lds_bytes(N));
+  if (per_cu > 2048 / stream_nt()) per_cu = 2048 / stream_nt();
+  if (per_cu < 1) per_cu = 1;
+  return nrows < 256 * per_cu ? nrows : 256 * per_cu;
+}
+__host__ inline int fallback_blocks(int nrows) { return nrows < 64 ? nrows : 64; }
+__host__ inline int stream_lds_cap(int N) {
+  const size_t fixed = lds_fixed_bytes(N) + (size_t)RBUF * 4;
+  long cap = fixed + 64 < LDS_LIMIT ? (long)((LDS_LIMIT - fixed) / 4) & ~7L : 0;
+  const char* e_ = getenv("SSG_INTRO_STREAM_CAP");      // tests: a small capacity makes short rows take several streamed levels (read per call)
+  const long lim = e_ ? atol(e_) : 0;
+  if (lim > 0 && lim < cap) cap = lim & ~7L;
+  return (int)cap;
+}
+__host__ inline size_t stream_lds_bytes(int N) { return lds_fixed_bytes(N) + (size_t)RBUF * 4 + (size_t)stream_lds_cap(N) * 4; }
+__host__ inline bool stream_enabled(int N) {
+  const char* e_ = getenv("SSG_INTRO_STREAM");          // 0: the in-place arena kernel of rounds 2-4 (read per call)
+  return (e_ ? atoi(e_) : 1) != 0 && N >= 4096 && stream_lds_cap(N) >= 2048;
+}
+
 template <bool LDS, int NT>
-__host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, uint32_t* arena, uint32_t* tails, hipStream_t stream) {
+__host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, uint32_t* arena, uint32_t* tails, hipStream_t stream,
+                    uint32_t* sbufs = nullptr, int* redo = nullptr) {
   const size_t lds = lds_fixed_bytes(N) + (LDS ? entry_words(N) * 4 : 0);
   const int tailn = tails ? tail_threshold() : 0;             // no hand-over buffer: the unsplit single-launch kernel
+  if (!LDS && sbufs) {
+    // rows that do not fit in LDS: streamed out-of-place levels first (one workgroup per CU), then the in-place kernel for the rows it flagged
+    const int cap = stream_lds_cap(N);
+    const size_t slds = stream_lds_bytes(N);
+    SSG_HIP(hipMemsetAsync(redo, 0, (size_t)nrows * sizeof(int), stream));
+    SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_introsort_stream_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+    hipLaunchKernelGGL((topk_introsort_stream_kernel<NT>), dim3(stream_blocks(N, nrows)), dim3(NT), slds, stream, D, rowmax, N, nrows, K, mask_words(N), sbufs,
+                       entry_words(N), cap, rank, tailn, tails, tail_stride_words(tailn), redo);
+    SSG_LAUNCH_CHECK("topk_introsort_stream_kernel");
+    SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_introsort_kernel<false, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((topk_introsort_kernel<false, NT>), dim3(fallback_blocks(nrows)), dim3(NT), lds, stream, D, rowmax, N, nrows, K,
+                       mask_words(N), arena, entry_words(N), rank, tailn, tails, tail_stride_words(tailn), (const int*)redo);
+  } else {
   SSG_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_introsort_kernel<LDS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((topk_introsort_kernel<LDS, NT>), dim3(LDS ? nrows : arena_blocks(nrows)), dim3(NT), lds, stream, D, rowmax, N, nrows, K,
-                     mask_words(N), arena, entry_words(N), rank, tailn, tails, tail_stride_words(tailn));
+                     mask_words(N), arena, entry_words(N), rank, tailn, tails, tail_stride_words(tailn), (const int*)nullptr);
+  }
   if (tailn > 0) {
     SSG_LAUNCH_CHECK("topk_introsort_kernel");
     const int head = 64 + tailn;                               // entries a row's tail can cover
@@ -733,9 +1200,16 @@ __host__ int launch(const uint16_t* D, const uint32_t* rowmax, int N, int nrows,
 using namespace ssg;
 
 // workspace = [hand-over records of the tail kernel (split mode) | global arena (only when a row does not fit in LDS)]
+// arena = streamed path (default): two left-child buffers per persistent workgroup + the in-place arena of the fallback blocks + one flag
+//         per row;  in-place path (SSG_INTRO_STREAM=0, short rows): one row per arena block
+static size_t intro_arena_only_bytes(int N, int nrows) {
+  if (intro::stream_enabled(N))
+    return ((size_t)intro::stream_blocks(N, nrows) * 2 + (size_t)intro::fallback_blocks(nrows)) * intro::entry_words(N) * sizeof(uint32_t) + (size_t)nrows * sizeof(int);
+  return (size_t)intro::arena_blocks(nrows) * intro::entry_words(N) * sizeof(uint32_t);
+}
 extern "C" size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows) {
   if (N <= 0 || nrows <= 0) return 0;
-  return intro::tail_bytes(nrows) + (size_t)intro::arena_blocks(nrows) * intro::entry_words(N) * sizeof(uint32_t);
+  return intro::tail_bytes(nrows) + intro_arena_only_bytes(N, nrows);
 }
 extern "C" size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows) {
   if (N <= 0 || nrows <= 0) return 0;
@@ -760,6 +1234,13 @@ extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax
   }
   uint32_t* tails = split ? (uint32_t*)ws : nullptr;
   uint32_t* ar = arena ? (uint32_t*)((unsigned char*)ws + (split ? tb : 0)) : nullptr;
+  // streamed path: [2 buffers per persistent workgroup | fallback arena | flags]
+  uint32_t* sbufs = nullptr; int* redo = nullptr;
+  if (arena && intro::stream_enabled(N)) {
+    sbufs = ar;
+    ar = sbufs + (size_t)intro::stream_blocks(N, nrows) * 2 * intro::entry_words(N);
+    redo = (int*)(ar + (size_t)intro::fallback_blocks(nrows) * intro::entry_words(N));
+  }
   static int nt = -1;
   if (nt < 0) { const char* e_ = getenv("SSG_INTRO_NT"); nt = e_ ? atoi(e_) : 512; }
   int rc;
@@ -767,6 +1248,9 @@ extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax
     rc = nt == 1024 ? intro::launch<true, 1024>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream)
        : nt == 256 ? intro::launch<true, 256>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream)
                    : intro::launch<true, 512>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream);
+  } else if (sbufs) {
+    rc = intro::stream_nt() == 512 ? intro::launch<false, 512>(D, rowmax, N, nrows, K, rank, ar, tails, stream, sbufs, redo)
+                    : intro::launch<false, 1024>(D, rowmax, N, nrows, K, rank, ar, tails, stream, sbufs, redo);
   } else {
     rc = nt == 1024 ? intro::launch<false, 1024>(D, rowmax, N, nrows, K, rank, ar, tails, stream)
        : nt == 256 ? intro::launch<false, 256>(D, rowmax, N, nrows, K, rank, ar, tails, stream)

@@ -346,6 +346,40 @@ def test_introsort_rank_vs_numpy_argsort(N, dev, ora):
         assert np.array_equal(got[r], np.argsort(keys[r].view(np.float16), kind="stable")[:K]), (N, r)
 
 
+@pytest.mark.parametrize("N,cap", [(5000, 2048), (16523, 2400), (40000, 3000), (40000, 0), (70001, 9000)])
+def test_introsort_streamed_levels_vs_numpy_argsort(N, cap, dev, monkeypatch):
+    """round 5: rows that do not fit in LDS take their first levels as OUT-OF-PLACE streamed partitions (csrc/topk_intro.hip
+    stream_partition: the row of D is only read, the left child is written once).  A small SSG_INTRO_STREAM_CAP forces several
+    streamed levels (through the two global buffers, then into LDS) on rows of any length: np.argsort's order must come out for
+    tie-heavy, constant, sorted, reversed, tie-free and adversarial rows, unaligned row starts (odd N), K = 1 / 21 / 64 -- including
+    rows whose first pivot lands inside [0, K) (flagged and redone by the in-place kernel) -- and equal the in-place arena path."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN), "..", "tools"))
+    from antiqsort import killer_keys
+    rng = np.random.default_rng(N + cap)
+    rows = [rng.integers(0, nv, N) for nv in (1, 2, 7, 300, 5000)]
+    rows.append(np.sort(rng.integers(0, 50, N)))
+    rows.append(np.sort(rng.integers(0, 50, N))[::-1])
+    rows.append(rng.permutation(N) % 15000)
+    bad = np.full(N, 1000); bad[0] = 0; bad[(N - 1) >> 1] = 0; bad[N - 1] = 1       # the first pivot (key 0) lands at the front: both children matter
+    rows.append(bad)
+    bad2 = rng.integers(5, 9000, N); bad2[[0, (N - 1) >> 1, N - 1]] = (3, 2, 4); bad2[rng.integers(1, N - 2, 9)] = 1   # pivot key 3 with ~10 smaller keys: pi ~ 10 < 21
+    rows.append(bad2)
+    kk = killer_keys(min(N, 6000)); rows.append(np.concatenate([kk, np.full(N - len(kk), 20000)]))
+    keys = np.stack(rows).astype(np.uint16)
+    if cap:
+        monkeypatch.setenv("SSG_INTRO_STREAM_CAP", str(cap))
+    force = N <= 36000
+    for K in (1, 21, 64):
+        got = _rank_rows(keys, K, dev, force_arena=force)
+        for r in range(keys.shape[0]):
+            assert np.array_equal(got[r], np.argsort(keys[r].view(np.float16))[:K]), (N, cap, K, r)
+    monkeypatch.setenv("SSG_INTRO_STREAM", "0")
+    old = _rank_rows(keys, 21, dev, force_arena=force)
+    monkeypatch.delenv("SSG_INTRO_STREAM")
+    assert np.array_equal(old, _rank_rows(keys, 21, dev, force_arena=force))
+
+
 def test_introsort_rank_without_workspace(dev):
     """the pre-round-3 calling convention (ws = NULL for rows that fit in LDS) still works -- the replay then runs unsplit
     in the single-launch kernel -- and gives the same ranking as the split (workspace) path."""

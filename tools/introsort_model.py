@@ -118,3 +118,116 @@ def argsort_topk(key, K):
             order = np.argsort(key[seg], kind="stable")     # insertion sort == stable sort of the range
             a[pl:pr + 1] = seg[order]
     return a[:K]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 5: the OUT-OF-PLACE form of a partition for rows that do not fit in LDS (csrc/topk_intro.hip, stream_partition).
+#
+# The in-place replay above swaps entries of the row where it lies (a 512 KB global arena at N = 128 000: every swap is a random
+# access).  On the main path of the walk only the LEFT child of a partition is ever needed (the ranges that intersect columns [0, K)
+# all start at 0 until the pivot itself lands inside [0, K)), and the left child after the m swaps is
+#       left[0]  = the smallest of the three median candidates,
+#       left[p]  = A[p]                          for the positions p <= p* that are not L-stoppers,
+#       left[p]  = A[R_k]   (k = rank of p)      for the k-th L-stopper from the left: the k-th R-stopper from the RIGHT,
+# with A = the source array as the median-of-3 step left it (two overridden positions inside the part that is read: 0 and pm).
+# So the source is only READ (streaming, coalesced), the left child is WRITTEN once (to LDS when it fits, else to a second global
+# buffer), and the pairing goes through a rank-chunked staging buffer: for ranks [k0, k1] the R-stoppers are collected in rank order
+# (pass X: mask words from the right end), then handed to the L-stoppers of the same ranks (pass Y: mask words from the left end).
+# This function states that computation at the level of the kernel's 64-bit mask words, in the kernel's "q space" (bit q = p + qs:
+# the source starts qs entries into its first 8-entry group), and is checked against partition_parallel above.
+
+def _popc(x):
+    return bin(x).count("1")
+
+
+def stream_partition_left(key, a, n, qs=0, C=64):
+    """left child [0, pi) of the Hoare partition of a[0:n] as the streamed kernel computes it -> (pi, left array)"""
+    pr = n - 1
+    pm = pr >> 1
+    k = lambda e: key[e]
+    el, em, er, e2 = int(a[0]), int(a[pm]), int(a[pr]), int(a[pr - 1])
+    if k(em) < k(el): el, em = em, el
+    if k(er) < k(em): er, em = em, er
+    if k(em) < k(el): el, em = em, el
+    vp = k(em)
+
+    def A(p):                      # the source as the median-of-3 step leaves it, for the positions that are ever read (p <= pr - 2)
+        return el if p == 0 else (e2 if p == pm else int(a[p]))
+    s0, s1 = 1, pr - 2
+    W = (n + qs + 63) >> 6
+    L = [0] * W; R = [0] * W
+    for p in range(s0, s1 + 1):
+        q = p + qs
+        x = k(A(p))
+        if x >= vp: L[q >> 6] |= 1 << (q & 63)
+        if x <= vp: R[q >> 6] |= 1 << (q & 63)
+    cL = [_popc(w) for w in L]; cR = [_popc(w) for w in R]
+    totL, totR = sum(cL), sum(cR)
+    beforeL = [0] * W; beforeR = [0] * W            # stoppers in words < w
+    for w in range(1, W):
+        beforeL[w] = beforeL[w - 1] + cL[w - 1]; beforeR[w] = beforeR[w - 1] + cR[w - 1]
+    # crossing word: number of leading words at whose END g >= f still holds
+    wstar = 0
+    while wstar < W and (totR - (beforeR[wstar] + cR[wstar])) >= (beforeL[wstar] + cL[wstar]):
+        wstar += 1
+    if wstar >= W:
+        m, pstar = totL, s1
+    else:
+        best = -1
+        for b in range(64):
+            le = (2 << b) - 1
+            f = beforeL[wstar] + _popc(L[wstar] & le)
+            g = (totR - beforeR[wstar] - cR[wstar]) + _popc(R[wstar] & ~le & ((1 << 64) - 1))
+            if g >= f:
+                best = b
+        if best < 0:
+            m, pstar = beforeL[wstar], (wstar << 6) - 1 - qs
+        else:
+            m, pstar = beforeL[wstar] + _popc(L[wstar] & ((2 << best) - 1)), (wstar << 6) + best - qs
+    pstar = max(s0 - 1, min(pstar, s1))
+    pi = pstar + 1
+    left = np.empty(pi, dtype=np.int64)
+    for p in range(0, pi):                              # pass E1: everything, L-stopper positions are overwritten below
+        left[p] = A(p)
+    for k0 in range(1, m + 1, C):                       # rank chunks
+        k1 = min(m, k0 + C - 1)
+        buf = [None] * (k1 - k0 + 1)
+        for w in range(W):                              # pass X (the kernel visits only the words that hold these ranks)
+            for b in range(64):
+                if (R[w] >> b) & 1:
+                    leftrank = beforeR[w] + _popc(R[w] & ((2 << b) - 1))
+                    kk = totR - leftrank + 1
+                    if k0 <= kk <= k1:
+                        buf[kk - k0] = A((w << 6) + b - qs)
+        for w in range(W):                              # pass Y
+            for b in range(64):
+                if (L[w] >> b) & 1:
+                    kk = beforeL[w] + _popc(L[w] & ((2 << b) - 1))
+                    if k0 <= kk <= k1:
+                        left[(w << 6) + b - qs] = buf[kk - k0]
+    return pi, left
+
+
+def _self_test_stream(trials=400, seed=7):
+    rng = np.random.default_rng(seed)
+    for t in range(trials):
+        n = int(rng.integers(17, 700))
+        kind = t % 5
+        if kind == 0: key = rng.integers(0, 4, n)
+        elif kind == 1: key = rng.integers(0, 1000, n)
+        elif kind == 2: key = np.sort(rng.integers(0, 50, n))
+        elif kind == 3: key = np.sort(rng.integers(0, 50, n))[::-1].copy()
+        else: key = np.full(n, 3)
+        key = key.astype(np.int64)
+        a = rng.permutation(n).astype(np.int64)
+        ref = a.copy()
+        pi_ref = partition_parallel(key, ref, 0, n - 1)
+        for qs in (0, 3, 7):
+            pi, left = stream_partition_left(key, a.copy(), n, qs=qs, C=int(rng.integers(1, 90)))
+            assert pi == pi_ref, (n, kind, qs, pi, pi_ref)
+            assert np.array_equal(left, ref[:pi]), (n, kind, qs)
+    return True
+
+
+if __name__ == "__main__":
+    print("stream_partition_left == partition_parallel (left child):", _self_test_stream())

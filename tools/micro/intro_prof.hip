@@ -33,7 +33,9 @@ int main(int argc, char** argv) {
 #ifdef SSG_INTRO_PROF
     unsigned long long p[16];
     hipMemcpyFromSymbol(p, HIP_SYMBOL(ssg::intro::g_prof), sizeof(p));
-    const char* names[16] = {"load", "A", "B", "C", "D", "E", "F", "-", "insertion", "sort_total(incl. above)", "-", "wA", "wB", "wC", "wD", "wE"};
+    const char* names_lds[16] = {"load", "A", "B", "C", "D", "E", "F", "-", "insertion", "sort_total(incl. above)", "-", "wA", "wB", "wC", "wD", "wE"};
+    const char* names_str[16] = {"s:A+keyclass", "s:B1 masks", "s:B2 counts", "s:C/D", "s:E1 copy", "s:X gather", "s:Y scatter", "LDS stage (sort_prefix + hand-over)", "s:X rank search", "s:X loop", "s:Y rank search", "s:Y loop", "-", "-", "-", "-"};
+    const char** names = (ssg_topk_rank_introsort_ws_bytes(N, nrows) > (size_t)nrows * 9000 ? names_str : names_lds);
     for (int i = 0; i < 16; i++) if (p[i]) printf("  %-24s %10.1f cycles/row\n", names[i], (double)p[i] / nrows);
 #endif
   }

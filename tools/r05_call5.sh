@@ -1,0 +1,9 @@
+#!/bin/bash
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r05e; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "introsort" > $O/tests_a.log 2>&1; tail -4 $O/tests_a.log
+timeout 600 python tools/time_rank.py 40000 128000 > $O/rank_a.log 2>&1; grep N= $O/rank_a.log
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DSSG_INTRO_PROF -I self-similarity-grouping_amd/csrc tools/micro/intro_prof.hip -o /tmp/intro_prof 2> /dev/null
+/tmp/intro_prof 128000 4096 > $O/prof_128k.log 2>&1; head -9 $O/prof_128k.log
