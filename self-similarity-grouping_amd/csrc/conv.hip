@@ -591,15 +591,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   // and a lane's address is its tap-(0,0) offset + one uniform delta (out-of-range taps: the offset is replaced, not clamped).
   const int nk = p.Kpad / CBK;
   int dn = 0, dr = 0, ds = 0, dch = 0;
+#ifndef SSG_DMA_AUX_A
+#define SSG_DMA_AUX_A 0        /* cache policy of the activation DMA (2 = nt): A/B knob, measured neutral */
+#endif
+#ifndef SSG_DMA_AUX_W
+#define SSG_DMA_AUX_W 0
+#endif
 #define SSG_DMA_A(J, ST)                                                                                             \
   {                                                                                                                  \
     if (!DUAL || dn < nkA) {                                                                                          \
       const bool ok = ab##J >= 0 && (unsigned)(ah##J + dr) < (unsigned)p.H && (unsigned)(aw##J + ds) < (unsigned)p.W;  \
       const unsigned aoff = ok ? (unsigned)(abase##J + ddelta_) : 0x80000000u;                                        \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, 0);   \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, SSG_DMA_AUX_A);   \
     } else {                                                                                                          \
       const unsigned aoff = a2b##J + (unsigned)((dn - nkA) * CBK * 4);                                                 \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(in2_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, 0);  \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(in2_rsrc, SSG_LDSP(ST + (wave * ABLK + J) * 1024), 16, aoff, 0, 0, SSG_DMA_AUX_A);  \
     }                                                                                                                 \
   }
 #define SSG_DMA_NEXT(ST)                                                                                             \
@@ -607,8 +613,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
     const int ddelta_ = ((dr * p.W + ds) * p.Cin + dch * 32 + (dn & 1) * 16) * 4;                                     \
     SSG_DMA_A(0, ST) if (ABLK == 2) SSG_DMA_A(1, ST)                                                                  \
     const unsigned kb_ = (unsigned)(dn * CBK * 4);                                                                    \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * (1024 * WBLK)), 16, wo0 + kb_, 0, 0, 0);   \
-    if (WBLK == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, 0); \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * (1024 * WBLK)), 16, wo0 + kb_, 0, 0, SSG_DMA_AUX_W);   \
+    if (WBLK == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, SSG_LDSP(ST + BM * 64 + wave * 2048 + 1024), 16, wo1 + kb_, 0, 0, SSG_DMA_AUX_W); \
     {                                        /* branch-free advance; the tail re-fetches the last tile (harmless, keeps the vmcnt accounting uniform) */ \
       const int adv_ = dn < nk - 1 ? 1 : 0;                                                                          \
       dn += adv_;                                                                                                    \

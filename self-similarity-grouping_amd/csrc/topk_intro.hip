@@ -711,7 +711,8 @@ __global__ __launch_bounds__(64) void topk_introsort_tail_kernel(const uint32_t*
 // end, pass Y hands them to the L-stoppers of the same ranks at the left end -- both passes touch whole mask words with one lane per
 // bit, every global access is coalesced, and no rank -> position search runs per element.
 // tools/introsort_model.py (stream_partition_left) states the same computation word by word and is checked against the in-place model.
-// A pivot that lands inside [0, K) (both children matter) is not handled here: the row is flagged and redone by the in-place kernel.
+// A pivot that lands inside [0, K) (it is an output itself, and the right child may matter too) is not handled here: the row is flagged
+// and redone by the in-place kernel.
 #ifndef SSG_STREAM_RBUF
 #define SSG_STREAM_RBUF 8192
 #endif
@@ -1072,7 +1073,9 @@ __global__ __launch_bounds__(NT) void topk_introsort_stream_kernel(const hbits* 
         pi = stream_partition<NT, false>(arr, n, sh, mk, rbuf, fmx, ent, lds_cap, gb[which], to_lds PROF_PASS);
       }
       --cd; ++level;
-      if (pi + 1 < K) { bad = true; break; }        // the right child intersects [0, K) as well: (rare) redone by the in-place kernel
+      // pi < K: the pivot itself is an output column (it sits at position pi, which no left child holds), and for pi + 1 < K the right
+      // child matters as well: (rare) the row is redone by the in-place kernel
+      if (pi < K) { bad = true; break; }
       n = pi;
       if (to_lds) { in_lds = true; break; }
       which ^= 1;

@@ -365,6 +365,10 @@ def test_introsort_streamed_levels_vs_numpy_argsort(N, cap, dev, monkeypatch):
     rows.append(bad)
     bad2 = rng.integers(5, 9000, N); bad2[[0, (N - 1) >> 1, N - 1]] = (3, 2, 4); bad2[rng.integers(1, N - 2, 9)] = 1   # pivot key 3 with ~10 smaller keys: pi ~ 10 < 21
     rows.append(bad2)
+    for kq in (21, 64):        # the first pivot lands EXACTLY at column K - 1: it is the last output itself (no child holds it)
+        row = rng.integers(100, 9000, N); row[[0, (N - 1) >> 1, N - 1]] = (50, 70, 90)
+        row[rng.choice(np.arange(1, N - 1)[np.arange(1, N - 1) != ((N - 1) >> 1)], kq - 2, replace=False)] = rng.integers(1, 69, kq - 2)   # kq - 1 keys below the pivot (70)
+        rows.append(row)
     kk = killer_keys(min(N, 6000)); rows.append(np.concatenate([kk, np.full(N - len(kk), 20000)]))
     keys = np.stack(rows).astype(np.uint16)
     if cap:
@@ -378,6 +382,29 @@ def test_introsort_streamed_levels_vs_numpy_argsort(N, cap, dev, monkeypatch):
     old = _rank_rows(keys, 21, dev, force_arena=force)
     monkeypatch.delenv("SSG_INTRO_STREAM")
     assert np.array_equal(old, _rank_rows(keys, 21, dev, force_arena=force))
+
+
+@pytest.mark.parametrize("N,d", [(6000, 64), (20000, 128)])
+def test_introsort_streamed_levels_on_real_distance_rows(N, d, dev, monkeypatch):
+    """the streamed levels on rows of a REAL original-distance matrix (row maxima != 1: keys are half(raw / rowmax), ties as the
+    pipeline produces them) for several LDS capacities == the rows-in-LDS kernel (which the reference goldens pin) == np.argsort on a
+    sample of rows.  (N = 20 000 at a capacity of 12 000 entries has a row whose first pivot lands exactly at column K - 1: the case
+    that exposed a missing output column during development.)"""
+    from ssg_amd import rerank, _lib
+    tgt = rerank._as_dev_f32(clustered(N, d, 1), dev)
+    D, rowmax, _ = rerank._original_distance(_lib.lib(), tgt, 0, N, float(tgt.abs().max()), _lib.stream())
+    want = rerank.initial_rank(D, rowmax, N, N, 21, "introsort")
+    for cap in (2048, 5000, 12000):
+        monkeypatch.setenv("SSG_INTRO_STREAM_CAP", str(cap))
+        got = rerank.initial_rank(D, rowmax, N, N, 21, "introsort", force_arena=True)
+        assert torch.equal(got, want), (N, cap, int((got != want).any(dim=1).sum()))
+    monkeypatch.delenv("SSG_INTRO_STREAM_CAP")
+    rows = np.random.default_rng(0).choice(N, 40, replace=False)
+    Dh = D[torch.from_numpy(rows).to(dev)].cpu().numpy(); rm = rowmax.cpu().numpy().astype(np.uint16).view(np.float16)
+    w = want.cpu().numpy()
+    for q, r in enumerate(rows):
+        key = (Dh[q].astype(np.float32) / np.float32(rm[r])).astype(np.float16)
+        assert np.array_equal(np.argsort(key)[:21], w[r]), r
 
 
 def test_introsort_rank_without_workspace(dev):
