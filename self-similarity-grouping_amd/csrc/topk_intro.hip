@@ -1136,30 +1136,45 @@ __host__ inline int tail_threshold() {
 __host__ inline size_t tail_stride_words(int tailn) { return (size_t)TAIL_HDR_WORDS + (size_t)((64 + tailn + 3) & ~3); }
 __host__ inline size_t tail_bytes(int nrows) { const int t = tail_threshold(); return t > 0 ? (size_t)nrows * tail_stride_words(t) * 4 : 0; }
 
-// streamed kernel geometry: persistent workgroups (one per CU), LDS entry capacity, fallback arena blocks
-__host__ inline int stream_nt() { const char* e_ = getenv("SSG_INTRO_STREAM_NT"); const int v = e_ ? atoi(e_) : 1024; return v == 512 ? 512 : 1024; }
-__host__ inline int stream_lds_cap(int N);
-__host__ inline size_t stream_lds_bytes(int N);
-// persistent workgroups: as many per CU as the LDS (and the 2048 threads of a CU) hold
-__host__ inline int stream_blocks(int N, int nrows) {
-  int per_cu = (int)(LDS_LIMIT / stream_lds_bytes(N));
-  if (per_cu > 2048 / stream_nt()) per_cu = 2048 / stream_nt();
-  if (per_cu < 1) per_cu = 1;
-  return nrows < 256 * per_cu ? nrows : 256 * per_cu;
+// streamed kernel geometry.  Measured (profiles/r05_introsort_stream_timing.txt): two 512-thread workgroups per CU beat one of 1024 while
+// the half-LDS entry capacity stays useful (N = 24 000 ... 70 000: -5 ... -18 %), one 1024-thread workgroup with the whole LDS wins when
+// the masks alone take most of half the LDS (N = 128 000).  SSG_INTRO_STREAM_CAP / SSG_INTRO_STREAM_NT override (tests, sweeps).
+__host__ inline int stream_cap_for(int N, int per_cu) {
+  const size_t fixed = lds_fixed_bytes(N) + (size_t)RBUF * 4, budget = LDS_LIMIT / (size_t)per_cu;
+  return fixed + 64 < budget ? (int)(((budget - fixed) / 4) & ~(size_t)7) : 0;
 }
-__host__ inline int fallback_blocks(int nrows) { return nrows < 64 ? nrows : 64; }
+__host__ inline bool stream_two_per_cu(int N) { return getenv("SSG_INTRO_STREAM_CAP") == nullptr && getenv("SSG_INTRO_STREAM_NT") == nullptr && stream_cap_for(N, 2) >= 4096; }
+__host__ inline int stream_nt(int N) {
+  const char* e_ = getenv("SSG_INTRO_STREAM_NT");
+  const int v = e_ ? atoi(e_) : (stream_two_per_cu(N) ? 512 : 1024);
+  return v == 512 ? 512 : 1024;
+}
 __host__ inline int stream_lds_cap(int N) {
-  const size_t fixed = lds_fixed_bytes(N) + (size_t)RBUF * 4;
-  long cap = fixed + 64 < LDS_LIMIT ? (long)((LDS_LIMIT - fixed) / 4) & ~7L : 0;
+  long cap = stream_cap_for(N, stream_two_per_cu(N) ? 2 : 1);
   const char* e_ = getenv("SSG_INTRO_STREAM_CAP");      // tests: a small capacity makes short rows take several streamed levels (read per call)
   const long lim = e_ ? atol(e_) : 0;
   if (lim > 0 && lim < cap) cap = lim & ~7L;
   return (int)cap;
 }
 __host__ inline size_t stream_lds_bytes(int N) { return lds_fixed_bytes(N) + (size_t)RBUF * 4 + (size_t)stream_lds_cap(N) * 4; }
+// persistent workgroups: as many per CU as the LDS (and the 2048 threads of a CU) hold
+__host__ inline int stream_blocks(int N, int nrows) {
+  int per_cu = (int)(LDS_LIMIT / stream_lds_bytes(N));
+  if (per_cu > 2048 / stream_nt(N)) per_cu = 2048 / stream_nt(N);
+  if (per_cu < 1) per_cu = 1;
+  return nrows < 256 * per_cu ? nrows : 256 * per_cu;
+}
+__host__ inline int fallback_blocks(int nrows) { return nrows < 64 ? nrows : 64; }
 __host__ inline bool stream_enabled(int N) {
   const char* e_ = getenv("SSG_INTRO_STREAM");          // 0: the in-place arena kernel of rounds 2-4 (read per call)
   return (e_ ? atoi(e_) : 1) != 0 && N >= 4096 && stream_lds_cap(N) >= 2048;
+}
+// rows-in-LDS kernel: two rows per CU (512 threads each) up to N ~ 18 000; beyond that ONE row per CU -- there the streamed kernel with two
+// workgroups per CU is faster (N = 24 000: 3.85 -> 3.17 ms, 30 000: 5.49 -> 4.71, 36 000: 7.42 -> 6.53), so it takes over
+__host__ inline bool lds_two_rows(int N) { return 2 * (lds_fixed_bytes(N) + entry_words(N) * 4) <= LDS_LIMIT; }
+__host__ inline bool use_stream(int N) {
+  if (!fits_lds(N)) return true;                        // (in-place arena kernel when streaming is switched off)
+  return !lds_two_rows(N) && stream_enabled(N) && getenv("SSG_INTRO_STREAM_MIDN") == nullptr;     // (SSG_INTRO_STREAM_MIDN set: rows in LDS whenever they fit)
 }
 
 template <bool LDS, int NT>
@@ -1216,7 +1231,7 @@ extern "C" size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows) {
 }
 extern "C" size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows) {
   if (N <= 0 || nrows <= 0) return 0;
-  return intro::fits_lds(N) ? intro::tail_bytes(nrows) : ssg_topk_rank_introsort_arena_bytes(N, nrows);
+  return intro::use_stream(N) ? ssg_topk_rank_introsort_arena_bytes(N, nrows) : intro::tail_bytes(nrows);
 }
 
 extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws,
@@ -1226,7 +1241,9 @@ extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax
     return SSG_ERR_INVALID;
   }
   const size_t tb = intro::tail_bytes(nrows), full = ssg_topk_rank_introsort_arena_bytes(N, nrows);
-  const bool arena = !intro::fits_lds(N) || (ws != nullptr && ws_bytes >= full);       // (a caller may force the arena path by passing its size)
+  // rows that do not fit in LDS -- or a caller passing the arena size: that is how rows that fit only ONE per CU get the (faster) streamed
+  // kernel: ssg_topk_rank_introsort_ws_bytes() asks for the arena there (use_stream); without it they still run from LDS
+  const bool arena = !intro::fits_lds(N) || (ws != nullptr && ws_bytes >= full);
   // LDS-resident rows need no workspace at all: without one (ws == NULL or too small for the hand-over records) the whole replay
   // runs in the single-launch kernel, as before round 3 (slower: one wave finishes each row's tail); only the arena is mandatory
   const bool split = tb > 0 && ws != nullptr && ws_bytes >= (arena ? full : tb);
@@ -1252,7 +1269,7 @@ extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax
        : nt == 256 ? intro::launch<true, 256>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream)
                    : intro::launch<true, 512>(D, rowmax, N, nrows, K, rank, nullptr, tails, stream);
   } else if (sbufs) {
-    rc = intro::stream_nt() == 512 ? intro::launch<false, 512>(D, rowmax, N, nrows, K, rank, ar, tails, stream, sbufs, redo)
+    rc = intro::stream_nt(N) == 512 ? intro::launch<false, 512>(D, rowmax, N, nrows, K, rank, ar, tails, stream, sbufs, redo)
                     : intro::launch<false, 1024>(D, rowmax, N, nrows, K, rank, ar, tails, stream, sbufs, redo);
   } else {
     rc = nt == 1024 ? intro::launch<false, 1024>(D, rowmax, N, nrows, K, rank, ar, tails, stream)
