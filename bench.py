@@ -62,7 +62,7 @@ def embed_fingerprint():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_pmc_conv_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_conv_traffic.json")
 
 
 def pmc_traffic(path, build, batch, launches_per_forward):

@@ -7,6 +7,7 @@ import sys
 
 def main():
     db, out, cmd = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+    note = sys.argv[4] if len(sys.argv) > 4 else ""
     c = sqlite3.connect(db)
     rows = list(c.execute("select name, count(*), sum(duration), avg(duration) from kernels group by name order by sum(duration) desc"))
     unit = "ns"   # rocpd `kernels.duration` = end - start in nanoseconds
@@ -15,6 +16,8 @@ def main():
     with open(out, "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats summary\n\n")
         f.write("command: `%s`\n\nsource: %s (view `kernels`, grouped by kernel name), durations in %s; total kernel time %.3f ms\n\n" % (cmd, db, unit, tot / 1e6))
+        if note:
+            f.write("**%s**\n\n" % note)
         f.write("| kernel | calls | total (ms) | avg (us) | % |\n|---|---:|---:|---:|---:|\n")
         for r in rows:
             if r[4] < 0.001 and r[1] < 2:

@@ -30,8 +30,7 @@ def group_roofline(src, tgt, lam, rho, splits=1):
     try:
         timer.on = True
         h = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=lam, keep_euclid=False, validate=False)
-        eps, _, _ = cluster.eps_rule(h, rho)
-        cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h)
+        cluster.eps_rule_dbscan(h, rho, min_samples=4)          # the product's chain (generate_selflabel, iteration 0): one read-back
         tot = timer.totals()
     finally:
         _lib._lib = real
@@ -55,6 +54,14 @@ def group(src, tgt, lam, rho, no_rerank=False, reps=2):
         t3 = sync()
         r = dict(dist_ms=round((t1 - t0) * 1e3, 2), eps_ms=round((t2 - t1) * 1e3, 2), dbscan_ms=round((t3 - t2) * 1e3, 2),
                  total_s=round(t3 - t0, 4), eps=float(eps), clusters=int(lab.max() + 1), noise=int((lab < 0).sum()))
+        # the same leg the way the product runs it (no sync between the stages, eps rule + DBSCAN as one device chain)
+        del h
+        t4 = sync()
+        h = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=lam, no_rerank=no_rerank, keep_euclid=no_rerank, validate=False)
+        e2, _, _, l2, _ = cluster.eps_rule_dbscan(h, rho, min_samples=4)
+        t5 = sync()
+        r["fused_total_s"] = round(t5 - t4, 4)
+        r["fused_equal"] = bool(float(e2) == float(eps)) and bool((l2 == lab).all())
         del h
         if best is None or r["total_s"] < best["total_s"]:
             best = r
