@@ -7,7 +7,7 @@ set -x
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r05z; mkdir -p $O
 cd $R
-PARTS=${PARTS:-"pmc bench prof2 prof1 layer configs"}
+PARTS=${PARTS:-"pmc bench prof2 prof1 layer configs pmcgroup"}
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has pmc; then PMC_PREFIX=r05 timeout 900 bash tools/pmc_embed.sh > $O/pmc_embed.log 2>&1; tail -2 $O/pmc_embed.log; cp $R/gpurun_out/r05_pmc_conv_traffic.json $R/gpurun_out/r05_pmc_conv_traffic.md $R/profiles/; fi
 if has bench; then timeout 1200 python bench.py --steps 5 --warmup 2 > $O/bench_final.json 2> $O/bench_final.err; tail -2 $O/bench_final.err; cut -c1-300 $O/bench_final.json; fi
@@ -23,3 +23,10 @@ fi
 cd $R
 if has layer; then timeout 600 python tools/layer_table.py --reps 5 > $O/layer_table.md 2>&1; tail -2 $O/layer_table.md; fi
 if has configs; then timeout 1500 python tools/run_configs.py > $O/configs.jsonl 2> $O/configs.err; cut -c1-400 $O/configs.jsonl; tail -2 $O/configs.err; fi
+if has pmcgroup; then
+  # HBM traffic of the grouping kernels (FETCH_SIZE counts half of wide coalesced reads on gfx950: see MI355X_MICROARCH.md) at the bench size and at N = 128 000
+  timeout 600 tools/pmc_generic.sh r05_group "FETCH_SIZE" "WRITE_SIZE" -- python $R/tools/time_stages.py --track hard --lam 0.3 --reps 1 > $O/pmc_group_hard.txt 2>&1
+  grep -v "at::native" $O/pmc_group_hard.txt | grep -i "jaccard\|region\|compact\|gram_i8_kernel\|introsort\|sbound\|bitonic" | cut -c1-150 | head -30
+  timeout 900 tools/pmc_generic.sh r05_n128k "FETCH_SIZE" "WRITE_SIZE" -- python $R/tools/time_rank.py 128000 > $O/pmc_rank_n128k.txt 2>&1
+  grep -i "introsort" $O/pmc_rank_n128k.txt | cut -c1-150
+fi
