@@ -78,6 +78,29 @@ __global__ __launch_bounds__(256) void source_refine_kernel(const float* __restr
 }
 }  // namespace ssg
 
+// round 5: |x|^2 of every row AND the scaled half copy the one-product bound pass multiplies, in ONE pass over the features (they were two
+// launches per operand set: 237 MB read twice).  The squared norm is summed in exactly row_sqnorm_kernel's order (lane c % 64 takes columns
+// c, c + 64, ... in order, then the xor tree: the bound pass's tolerance and the refine pass were derived for it) and the halves are the
+// values f32_to_f16_scaled_kernel writes, so every result downstream is unchanged.
+__global__ __launch_bounds__(256) void encode_sqnorm_kernel(const float* __restrict__ x, int rows, int d, float scale, _Float16* __restrict__ x16,
+                                                            float* __restrict__ out) {
+  const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  if (row >= rows) return;
+  const int lane = lane_id();
+  float s = 0.f;
+  const float* xr = x + (int64_t)row * d;
+  _Float16* hr = x16 + (int64_t)row * d;
+  for (int c0 = lane; c0 < d; c0 += 512) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = xr[min(c0 + 64 * u, d - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; u++) if (c0 + 64 * u < d) { s += v[u] * v[u]; hr[c0 + 64 * u] = (_Float16)(v[u] * scale); }
+  }
+  for (int sh = 1; sh < 64; sh <<= 1) s += __shfl_xor(s, sh, 64);
+  if (lane == 0) out[row] = s;
+}
+
 // Source-term row minimum (reid/rerank.py:36-37,39) by filter-and-refine: a float32 MFMA pass bounds every
 // target-source distance (per row and 8-source granule), a float64 pass re-evaluates only the granules within `tol`
 // of the row's bound.  Same result as ssg_source_rowmin_f16 (exact min of the half-rounded float64 distances)
@@ -94,11 +117,14 @@ static int source_rowmin_filtered_impl(const float* tgt, const float* src, int n
   }
   float* rowterm = ws; float* colterm = ws + nrows; float* tilemin = colterm + Ns_pad;
   int ntiles = Ns_pad / 8;   // 8-source granules
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
-  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
-  if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
   const bool split = scale_t > 0.f && scale_s > 0.f;
-  if (split && one_product && (Ns_pad % 128) == 0 && (d % sbound::BK) == 0) {
+  const bool one = split && one_product && (Ns_pad % 128) == 0 && (d % sbound::BK) == 0;
+  if (!one) {        // (the one-product path computes the norms together with its half copies, below)
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
+    if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
+  }
+  if (one) {
     // bound pass as a plain fp16 GEMM on half copies of the scaled operands (source_bound.hip): 2 bytes per element, 1 product
     static int sb_dma = -1;                 // SSG_SB_DMA=0: the register-staged 128 x 128 kernel
     if (sb_dma < 0) { const char* e = getenv("SSG_SB_DMA"); sb_dma = e ? atoi(e) : 1; }
@@ -113,8 +139,18 @@ static int source_rowmin_filtered_impl(const float* tgt, const float* src, int n
     if (gran4) ntiles = Ns_pad / 4;
     uintptr_t a = (uintptr_t)(tilemin + (int64_t)nrows * ntiles); a = (a + 15) & ~(uintptr_t)15;
     _Float16* x16 = (_Float16*)a; _Float16* y16 = x16 + (int64_t)nrows * d;
-    hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, tgt, x16, (int64_t)nrows * d / 4, scale_t);
-    hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, src, y16, (int64_t)Ns_pad * d / 4, scale_s);
+    static int fused_enc = -1;              // SSG_SB_FUSED_ENC=0: separate norm and conversion launches (rounds 2-4)
+    if (fused_enc < 0) { const char* e = getenv("SSG_SB_FUSED_ENC"); fused_enc = e ? atoi(e) : 1; }
+    if (fused_enc) {
+      hipLaunchKernelGGL(encode_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, scale_t, x16, rowterm);
+      hipLaunchKernelGGL(encode_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, scale_s, y16, colterm);
+    } else {
+      hipLaunchKernelGGL(row_sqnorm_kernel, dim3((nrows + 3) / 4), dim3(256), 0, stream, tgt, nrows, d, 1.f, rowterm);
+      hipLaunchKernelGGL(row_sqnorm_kernel, dim3((Ns_pad + 3) / 4), dim3(256), 0, stream, src, Ns_pad, d, 1.f, colterm);
+      hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, tgt, x16, (int64_t)nrows * d / 4, scale_t);
+      hipLaunchKernelGGL(sbound::f32_to_f16_scaled_kernel, dim3(4096), dim3(256), 0, stream, src, y16, (int64_t)Ns_pad * d / 4, scale_s);
+    }
+    if (Ns_pad > Ns) SSG_HIP(hipMemsetAsync(colterm + Ns, 0x7f, (size_t)(Ns_pad - Ns) * sizeof(float), stream));   // 0x7f7f7f7f = 3.4e38: padding never wins
     if (sb_dma && (int64_t)nrows * d * 2 < 0x7fffffffLL && (int64_t)Ns_pad * d * 2 < 0x7fffffffLL) {     // (operands go through 2 GiB buffer resources)
       const int tiles = ((nrows + sbound::TB - 1) / sbound::TB) * ((Ns_pad + sbound::TB - 1) / sbound::TB);
       hipLaunchKernelGGL(sbound::source_bound_dma_kernel, dim3(tiles), dim3(512), 0, stream, x16, y16, nrows, Ns_pad, d, rowterm, colterm,
