@@ -793,7 +793,12 @@ __device__ __forceinline__ int word_of_rank_ballot(const uint32_t* P, uint32_t e
   return (ch << cs) + __popcll(__ballot(valid && c < rr));
 }
 
-// passes E1 / X / Y of a streamed partition: the left child [0, pi) into tgt (index q = p + qs; LDS or global memory)
+// passes E1 / X / Y of a streamed partition: the left child [0, pi) into tgt (index q = p + qs; LDS or global memory).
+// (PMC at N = 128 000: 160 GB fetched + 102 GB written per launch for 2 N^2 = 32.8 GB of D: every level reads its source twice -- masks,
+// then the copy -- plus the sparse gather, and pass Y's 4-byte stores hit half of the lines pass E1 has just written.  A single pass that
+// writes every position of the child once -- the L-stoppers' staged partners and the other positions' own entries, 64 consecutive entries
+// per wave store -- was built and measured: 76 -> 81 ms; per-lane 2- / 4-byte source reads for ALL positions cost more than the 16-byte
+// vector copy + the scattered stores they replace.)
 template <int NT, bool DROW, class Tgt>
 __device__ __forceinline__ void stream_emit(const Src<DROW>& s, Tgt tgt, uint32_t* rbuf, const Masks& mk, int n, int W, int cs, int nch, uint32_t exL, uint32_t exR,
                                             uint32_t totR, uint32_t m, int pstar, int pm, uint32_t el, uint32_t e2 PROF_ARG) {
