@@ -34,7 +34,9 @@ constexpr int GI_T = 64;          // workgroup tile (4 waves, 32x32 outputs each
 // instead of 64 pieces of 96 bytes that are 6 KB apart and straddle 128-byte lines -- the texture addresser works through a wave's
 // load line by line, and with the row-major layout the global -> register staging alone cost 0.7 of the kernel's 2.7 ms (ablation:
 // tools/micro/gram_prof.hip with / without the loads).  Rows beyond n in the last panel are never written: the tile loads clamp to row n - 1.
-template <int NL>
+// PLANAR (round 5, for the LDS-DMA kernel): [row / 64][k block][digit][row % 64][32 k] -- a digit plane of a tile's stage is one contiguous
+// 2 KB piece (two 1 KB DMA instructions), and a fragment read is 16 bytes of ONE row of ONE plane (32-byte row pitch).
+template <int NL, bool PLANAR>
 __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __restrict__ X, int n, int d, int nkb, int8_t* __restrict__ E,
                                                              long long* __restrict__ norms, int* __restrict__ flag) {
   const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -42,7 +44,8 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
   const int lane = lane_id();
   const float* x = X + (int64_t)row * d;
   // panel-major: [row / 64][k block][row % 64][digit][32 k] (see gram_i8_kernel: a tile's stage is one contiguous 64 x 32 NL byte block)
-  int8_t* e = E + ((int64_t)(row / GI_T) * nkb * GI_T + (row % GI_T)) * (32 * NL);
+  int8_t* e = PLANAR ? E + (int64_t)(row / GI_T) * nkb * (GI_T * 32 * NL) + (row % GI_T) * 32
+                     : E + ((int64_t)(row / GI_T) * nkb * GI_T + (row % GI_T)) * (32 * NL);
   long long acc = 0;
   bool bad = false;
   for (int k0 = 0; k0 < nkb * 32; k0 += 64) {
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256) void gram_i8_encode_kernel(const float* __rest
 #pragma unroll
     for (int L = 0; L < NL; L++) {
       const int dg = ((r + 128) & 255) - 128;               // balanced digit in [-128, 127]
-      p[32 * L] = (int8_t)dg;
+      p[PLANAR ? GI_T * 32 * L : 32 * L] = (int8_t)dg;
       r = (r - dg) >> 8;
     }
     if (r != 0) bad = true;                                 // |X| beyond NL digits
@@ -119,23 +122,10 @@ __device__ __forceinline__ unsigned halfwave_max(unsigned v) {
   return v;
 }
 
-// D[i,j] = half(half(sqrt(d2))^2) for rows [rowA0, rowA0+M) x all N columns, atomicMax rowmax.  EA = encoded rows of the
-// row block, EB = encoded rows of the whole set.  symmetric: only tiles on/above the diagonal are launched, mirrored on store.
-template <int NL, int KB2>
-__global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ EA, const int8_t* __restrict__ EB,
-                                                         const long long* __restrict__ nA, const long long* __restrict__ nB, int M, int N, int nkb,
-                                                         int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric,
-                                                         const int* __restrict__ flag, int sb) {
-  if (*flag) return;     // a feature did not fit NL digits: the caller falls back to the fp64 kernel
-  constexpr int BLK = 32 * NL;          // bytes of one k block of one row
-  constexpr int SB = KB2 * BLK;         // bytes of one stage row: KB2 consecutive k blocks (one barrier per KB2 * NL^2 MFMAs)
-  constexpr int PITCH = SB + 16;        // LDS row pitch: pitch/16 odd (7, 9, 13, 17) -> conflict-free b128
-  constexpr int CPR = SB / 16;          // 16-byte chunks per row and stage
-  constexpr int NCH = (2 * GI_T * CPR) / 256;   // chunks per thread: A tile + B tile
-  constexpr int NACC = 2 * NL - 1;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * PITCH];
+// tile (tm, tn) of this workgroup: row-major over the row block, or -- one GPU holding the whole matrix -- the upper triangle, in
+// super-blocks of sb x sb tiles per XCD.  false: the workgroup has no tile (padding of the super-block grid).
+__device__ __forceinline__ bool gi_pick_tile(int M, int N, int symmetric, int sb, int& tm, int& tn) {
   const int tiles_n = (N + GI_T - 1) / GI_T, tiles_m = (M + GI_T - 1) / GI_T;
-  int tm, tn;
   if ((symmetric & 1) && sb > 0) {
     // round 4: the upper triangle in SUPER-BLOCKS of sb x sb tiles, each XCD working through whole super-blocks.  In the row-major
     // order below, the ~96 tiles an XCD runs at a time are consecutive columns of ONE tile row: they share the A panel, but every tile
@@ -152,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     while ((r + 1) * nb - (r + 1) * r / 2 <= blk) r++;
     const int c = r + (blk - (r * nb - r * (r - 1) / 2));
     tm = r * sb + within / sb; tn = c * sb + within % sb;
-    if (tm >= T || tn >= T || tn < tm) return;            // outside the matrix / below the diagonal (diagonal super-blocks only)
+    if (tm >= T || tn >= T || tn < tm) return false;           // outside the matrix / below the diagonal (diagonal super-blocks only)
   } else if (symmetric & 1) {
     const int T = tiles_n;
     const int t = xcd_remap((int)blockIdx.x, T * (T + 1) / 2);
@@ -164,6 +154,112 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     const int tile = xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
     tm = tile / tiles_n; tn = tile % tiles_n;
   }
+  return true;
+}
+
+// sqrt -> half -> square -> half of the exact integer distance, D store (+ the mirrored half tile through an LDS patch), row maxima
+template <int NL>
+__device__ __forceinline__ void gi_epilogue(v16i (&acc)[2 * NL - 1], unsigned char* lds, const long long* __restrict__ nA, const long long* __restrict__ nB, int M, int N,
+                                            int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric, int tm, int tn, bool mirror) {
+  constexpr int NACC = 2 * NL - 1;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
+  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31 -> B row (j), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> A row (i).
+  const int gj = tn * GI_T + wn * 32 + l32;
+  const bool jok = gj < N;
+  const long long nj = jok ? nB[gj] : 0;
+  unsigned cmax = 0;
+  // Both the tile and (mirror) its transpose go through private LDS patches of the wave (the stage buffers are free after the last
+  // barrier) and leave as 32-byte row pieces, two 16-byte stores per lane.  (Rounds 1-4 stored the direct tile straight from the
+  // accumulators: 16 store instructions of 2 bytes per lane, and took every row maximum with a 5-step DPP reduction per accumulator
+  // register; the row pieces a lane pair stores now hold a whole row of the wave tile, so its maximum is 15 compares + one exchange.)
+  constexpr int MP = 34;                                   // patch pitch in halves (17 dwords: odd)
+  hbits* patch = reinterpret_cast<hbits*>(lds) + wave * (32 * MP);            // 2176 B per wave: first [row][col], then (mirror) [col][row]
+  unsigned dds[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const int il = (r & 3) + 8 * (r >> 2) + 4 * h;          // row of this accumulator element inside the wave tile
+    const int li = tm * GI_T + wm * 32 + il;
+    const bool ok = jok && li < M;
+    unsigned dd = 0;
+    if (ok) {
+      long long dot = 0;
+#pragma unroll
+      for (int w = NACC - 1; w >= 0; w--) dot = dot * 256 + (long long)acc[w][r];
+      long long d2i = nA[li] + nj - 2 * dot;           // exact squared distance in units of 2^-48
+      if (d2i < 0 || rowA0 + li == gj) d2i = 0;         // cannot be negative; cdist(x, x) diagonal is exactly 0
+      if (d2i < (1LL << 50) && !(symmetric & 2)) {
+        const hbits hh = sqrt_units48_to_half(d2i);      // == d2h(sqrt((double)d2i * 2^-48)) for d2 < 4: every L2-normalised pair
+        dd = h_mul(hh, hh);                              // np.power(half, 2) rerank.py:62
+      } else {
+        const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
+        const double sq = sqrt(s);
+        const hbits hh = d2h(sq);                         // cdist(...).astype(float16)   rerank.py:61
+        // np.power(half, 2) rerank.py:62; MemorySave branch (:49-59): np.power(cdist, 2).astype(float16), one rounding
+        dd = (symmetric & 2) ? d2h(sq * sq) : h_mul(hh, hh);
+      }
+      cmax = cmax > dd ? cmax : dd;
+    }
+    dds[r] = dd;
+    patch[il * MP + l32] = (hbits)dd;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the patch is written and read by this wave only
+  // lane pair (2j, 2j+1) stores the 32 halves of row j of the wave tile (then of mirrored row j = this tile's column j): 2 x 32 bytes
+  const int mj = lane >> 1, half16 = (lane & 1) * 16;
+  auto store_row = [&](const hbits* src, int grow, int gcol, int nrow_lim, int ncol_lim) {
+    if (grow < nrow_lim) {
+      hbits* dst = D + (int64_t)grow * N + gcol;
+      if (gcol + 16 <= ncol_lim && ((((int64_t)grow * N + gcol) & 7) == 0)) {
+        unsigned w[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) w[e] = (unsigned)src[2 * e] | ((unsigned)src[2 * e + 1] << 16);
+        reinterpret_cast<uint4*>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]); reinterpret_cast<uint4*>(dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+      } else {
+        for (int e = 0; e < 16; e++) if (gcol + e < ncol_lim) dst[e] = src[e];
+      }
+    }
+  };
+  {
+    const int li = tm * GI_T + wm * 32 + mj;               // row of the tile, columns gcol .. gcol + 15
+    const hbits* src = patch + mj * MP + half16;
+    store_row(src, li, tn * GI_T + wn * 32 + half16, M, N);
+    unsigned rmax = 0;                                      // (entries outside the matrix are 0 in the patch)
+#pragma unroll
+    for (int e = 0; e < 16; e++) { const unsigned v = src[e]; rmax = rmax > v ? rmax : v; }
+    const unsigned o = (unsigned)__shfl_xor((int)rmax, 1, 64);
+    rmax = rmax > o ? rmax : o;
+    if ((lane & 1) == 0 && li < M) atomicMax(&rowmax[li], rmax);
+  }
+  if (mirror) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // every lane is done reading the [row][col] patch
+#pragma unroll
+    for (int r = 0; r < 16; r++) patch[l32 * MP + (r & 3) + 8 * (r >> 2) + 4 * h] = (hbits)dds[r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    store_row(patch + mj * MP + half16, tn * GI_T + wn * 32 + mj, tm * GI_T + wm * 32 + half16, N, M);
+    // mirrored rows are this tile's columns: one lane per column and half-wave
+    const unsigned o = (unsigned)__shfl_xor((int)cmax, 32, 64);
+    cmax = cmax > o ? cmax : o;
+    if (h == 0 && jok) atomicMax(&rowmax[gj], cmax);
+  }
+}
+
+// D[i,j] = half(half(sqrt(d2))^2) for rows [rowA0, rowA0+M) x all N columns, atomicMax rowmax.  EA = encoded rows of the
+// row block, EB = encoded rows of the whole set.  symmetric: only tiles on/above the diagonal are launched, mirrored on store.
+template <int NL, int KB2>
+__global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restrict__ EA, const int8_t* __restrict__ EB,
+                                                         const long long* __restrict__ nA, const long long* __restrict__ nB, int M, int N, int nkb,
+                                                         int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric,
+                                                         const int* __restrict__ flag, int sb) {
+  if (*flag) return;     // a feature did not fit NL digits: the caller falls back to the fp64 kernel
+  constexpr int BLK = 32 * NL;          // bytes of one k block of one row
+  constexpr int SB = KB2 * BLK;         // bytes of one stage row: KB2 consecutive k blocks (one barrier per KB2 * NL^2 MFMAs)
+  constexpr int PITCH = SB + 16;        // LDS row pitch: pitch/16 odd (7, 9, 13, 17) -> conflict-free b128
+  constexpr int CPR = SB / 16;          // 16-byte chunks per row and stage
+  constexpr int NCH = (2 * GI_T * CPR) / 256;   // chunks per thread: A tile + B tile
+  constexpr int NACC = 2 * NL - 1;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * GI_T * PITCH];
+  int tm, tn;
+  if (!gi_pick_tile(M, N, symmetric, sb, tm, tn)) return;
   const bool mirror = (symmetric & 1) && tn > tm;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
@@ -244,75 +340,130 @@ __global__ __launch_bounds__(256, 2) void gram_i8_kernel(const int8_t* __restric
     if (sum_ == 0x7fffffff) D[0] = (hbits)sum_;
     return; }
 #endif
-  // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31 -> B row (j), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) -> A row (i).
-  const int gj = tn * GI_T + wn * 32 + l32;
-  const bool jok = gj < N;
-  const long long nj = jok ? nB[gj] : 0;
-  unsigned cmax = 0;
-  // mirror: the transposed 32x32 half tile goes through a private LDS patch (the stage buffers are free after the last
-  // barrier) so that it is stored as 64-byte row segments like the direct tile, not as scattered 8-byte pieces
-  constexpr int MP = 34;                                   // patch pitch in halves (17 dwords: odd)
-  hbits* patch = reinterpret_cast<hbits*>(lds) + wave * (32 * MP);
+  gi_epilogue<NL>(acc, lds, nA, nB, M, N, rowA0, D, rowmax, symmetric, tm, tn, mirror);
+}
+
+
+// ---- round 5: the same tile with LDS-DMA stages on digit PLANES -----------------------------------------------------------------------
+// The register-staged kernel above holds two stages' worth of global loads in 48 VGPRs (150 in all: three waves per SIMD) and pays the
+// VGPR -> LDS transfer of every byte (ds_write_b128: ~79 B/clk per CU, next to the fragment reads).  Here a stage goes global -> LDS
+// directly (buffer_load ... lds, 16 bytes per lane, 1 KB per wave instruction): no staging registers, no ds_write; NS stages of
+// [A: NL planes x 2 KB][B: NL planes x 2 KB] in separate __shared__ arrays, loads NS - 1 k blocks ahead.  The planar layout of the
+// encoder makes a plane of a stage ONE contiguous 2 KB piece (64 rows x 32 bytes) = two DMA instructions; rows land unpadded (the DMA is
+// lane-linear), and the two 16-byte halves of a row are swapped for rows with bit 3 set -- on the global side (a lane fetches the other
+// half) and again in the fragment reads -- so that the 16 lanes of a ds_read_b128 group (rows r .. r+3, r+12 .. r+15, r+20 .. r+27) hit
+// 64 distinct banks.  Same MFMA sequence, accumulators and epilogue as the kernel above: D is bit-identical.
+#define SSG_GI_LDSP(ptr_) ((__attribute__((address_space(3))) void*)(ptr_))
+__device__ __forceinline__ void gi_dma3(__amdgpu_buffer_rsrc_t rs, unsigned char* l0, unsigned char* l1, unsigned char* l2, unsigned g0, unsigned g1, unsigned g2) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, SSG_GI_LDSP(l0), 16, g0, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, SSG_GI_LDSP(l1), 16, g1, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, SSG_GI_LDSP(l2), 16, g2, 0, 0, 0);
+}
+template <int NL, int NS>
+__global__ __launch_bounds__(256, 4) void gram_i8_dma_kernel(const int8_t* __restrict__ E, unsigned e_bytes, const long long* __restrict__ nA, const long long* __restrict__ nB,
+                                                             int M, int N, int nkb, int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric,
+                                                             const int* __restrict__ flag, int sb) {
+  if (*flag) return;
+  constexpr int PLANE = GI_T * 32;                 // bytes of one digit plane of one operand and k block
+  constexpr int STAGE = 2 * NL * PLANE;            // [A planes][B planes]
+  constexpr int NACC = 2 * NL - 1;
+  constexpr int NDMA = 2 * NL * 2;                 // 1 KB DMA instructions per stage (two per plane)
+  static_assert(NDMA % 4 == 0, "the four waves share a stage's DMA instructions evenly");
+  constexpr int TDMA = NDMA / 4;                   // per wave and stage
+  static_assert(NS == 3 || NS == 4, "three or four stages");
+  __shared__ __attribute__((aligned(1024))) unsigned char st0[STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char st1[STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char st2[STAGE];
+  __shared__ __attribute__((aligned(1024))) unsigned char st3[NS == 4 ? STAGE : 1024];
+  int tm, tn;
+  if (!gi_pick_tile(M, N, symmetric, sb, tm, tn)) return;
+  const bool mirror = (symmetric & 1) && tn > tm;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
+  // ---- DMA addressing: instruction q = wave * TDMA + j of a stage fills operand q / (2 NL), plane (q % (2 NL)) / 2, rows 32 (q & 1) + lane / 2
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(E), 0, e_bytes, 0x00020000);
+  unsigned goff[TDMA]; int loff[TDMA];
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int il = (r & 3) + 8 * (r >> 2) + 4 * h;          // row of this accumulator element inside the wave tile
-    const int li = tm * GI_T + wm * 32 + il;
-    const bool ok = jok && li < M;
-    unsigned dd = 0;
-    if (ok) {
-      long long dot = 0;
+  for (int j = 0; j < TDMA; j++) {
+    const int q = wave * TDMA + j, op = q / (2 * NL), pl = (q % (2 * NL)) >> 1, row = 32 * (q & 1) + (lane >> 1), slot = lane & 1;
+    const int grow = op ? min(tn * GI_T + row, N - 1) : rowA0 + min(tm * GI_T + row, M - 1);
+    const int prow = grow % GI_T;
+    // planar layout: [panel][k block][digit][row % 64][32]; the lane fetches the half that belongs in its (swapped) slot
+    goff[j] = (unsigned)(((int64_t)(grow / GI_T) * nkb * NL + pl) * PLANE + prow * 32 + ((slot ^ ((prow >> 3) & 1)) * 16));
+    loff[j] = op * (NL * PLANE) + pl * PLANE + (q & 1) * 1024;           // (+ 16 * lane: implicit in the DMA)
+  }
+  // NOTE: rows of the tile are clamped PER LANE above (grow), so a lane's LDS slot (row = 32 (q & 1) + lane / 2) may hold another global
+  // row's bytes only for rows beyond the matrix, whose outputs are never stored; the swap bit must then follow the LDS row, not the global
+  // row: recompute it from the LDS row for those lanes
 #pragma unroll
-      for (int w = NACC - 1; w >= 0; w--) dot = dot * 256 + (long long)acc[w][r];
-      long long d2i = nA[li] + nj - 2 * dot;           // exact squared distance in units of 2^-48
-      if (d2i < 0 || rowA0 + li == gj) d2i = 0;         // cannot be negative; cdist(x, x) diagonal is exactly 0
-      if (d2i < (1LL << 50) && !(symmetric & 2)) {
-        const hbits hh = sqrt_units48_to_half(d2i);      // == d2h(sqrt((double)d2i * 2^-48)) for d2 < 4: every L2-normalised pair
-        dd = h_mul(hh, hh);                              // np.power(half, 2) rerank.py:62
-      } else {
-        const double s = (double)d2i * 3.5527136788005009e-15;   // 2^-48, exact (d2i < 2^53)
-        const double sq = sqrt(s);
-        const hbits hh = d2h(sq);                         // cdist(...).astype(float16)   rerank.py:61
-        // np.power(half, 2) rerank.py:62; MemorySave branch (:49-59): np.power(cdist, 2).astype(float16), one rounding
-        dd = (symmetric & 2) ? d2h(sq * sq) : h_mul(hh, hh);
-      }
-      D[(int64_t)li * N + gj] = (hbits)dd;
-      cmax = cmax > dd ? cmax : dd;
+  for (int j = 0; j < TDMA; j++) {
+    const int q = wave * TDMA + j, op = q / (2 * NL), pl = (q % (2 * NL)) >> 1, row = 32 * (q & 1) + (lane >> 1), slot = lane & 1;
+    const int grow = op ? min(tn * GI_T + row, N - 1) : rowA0 + min(tm * GI_T + row, M - 1);
+    goff[j] = (unsigned)(((int64_t)(grow / GI_T) * nkb * NL + pl) * PLANE + (grow % GI_T) * 32 + ((slot ^ ((row >> 3) & 1)) * 16));
+  }
+  const unsigned kstep = (unsigned)(NL * PLANE);                          // bytes from k block kb to kb + 1 inside a panel
+  int dn = 0;
+  static_assert(TDMA == 3, "gi_dma3 issues three instructions per wave and stage (three digits)");
+  // (the instructions live in a NON-template device function: with the builtin inside this kernel template hipcc's HOST pass silently
+  //  dropped the kernel's launch stub -- the library then failed to load with an undefined __device_stub__ symbol)
+#define SSG_GI_DMA(ST)                                                                                                \
+  { const unsigned kb_ = (unsigned)dn * kstep;                                                                        \
+    gi_dma3(rs, ST + loff[0], ST + loff[1], ST + loff[2], goff[0] + kb_, goff[1] + kb_, goff[2] + kb_);                \
+    dn += dn < nkb - 1 ? 1 : 0; }                 /* the tail re-fetches the last block (keeps the vmcnt accounting uniform) */
+  // ---- fragment addressing: lane (row l32 of its wave's 32-row block, k half h)
+  const int arow = wm * 32 + l32, brow = wn * 32 + l32;
+  const int aoff = arow * 32 + ((h ^ ((arow >> 3) & 1)) * 16), boff = NL * PLANE + brow * 32 + ((h ^ ((brow >> 3) & 1)) * 16);
+#define SSG_GI_MMA(ST)                                                                                                \
+  { v4i a_[NL], b_[NL];                                                                                               \
+    _Pragma("unroll") for (int L = 0; L < NL; L++) {                                                                 \
+      a_[L] = *reinterpret_cast<const v4i*>(ST + aoff + L * PLANE); b_[L] = *reinterpret_cast<const v4i*>(ST + boff + L * PLANE); } \
+    _Pragma("unroll") for (int La = 0; La < NL; La++) _Pragma("unroll") for (int Lb = 0; Lb < NL; Lb++)              \
+      acc[La + Lb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_[La], b_[Lb], acc[La + Lb], 0, 0, 0); }
+  v16i acc[NACC];
+#pragma unroll
+  for (int w = 0; w < NACC; w++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[w][r] = 0;
+  // publish = k block t has landed for every wave AND every wave is done reading the stage that is refilled next (lgkmcnt(0): hipcc sinks
+  // the fragment reads' waits below a bare barrier -- the race conv_dma_kernel had in rounds 1-2)
+#define SSG_GI_PUBLISH() asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TDMA * (NS - 2)) : "memory")
+  SSG_GI_DMA(st0)
+  SSG_GI_DMA(st1)
+  if constexpr (NS == 4) SSG_GI_DMA(st2)
+  const int nfull = nkb / NS * NS;
+  for (int kt = 0; kt < nfull; kt += NS) {
+    if constexpr (NS == 3) {
+      SSG_GI_PUBLISH(); SSG_GI_DMA(st2) __builtin_amdgcn_sched_barrier(0); SSG_GI_MMA(st0)
+      SSG_GI_PUBLISH(); SSG_GI_DMA(st0) __builtin_amdgcn_sched_barrier(0); SSG_GI_MMA(st1)
+      SSG_GI_PUBLISH(); SSG_GI_DMA(st1) __builtin_amdgcn_sched_barrier(0); SSG_GI_MMA(st2)
+    } else {
+      SSG_GI_PUBLISH(); SSG_GI_DMA(st3) __builtin_amdgcn_sched_barrier(0); SSG_GI_MMA(st0)
+      SSG_GI_PUBLISH(); SSG_GI_DMA(st0) __builtin_amdgcn_sched_barrier(0); SSG_GI_MMA(st1)
+      SSG_GI_PUBLISH(); SSG_GI_DMA(st1) __builtin_amdgcn_sched_barrier(0); SSG_GI_MMA(st2)
+      SSG_GI_PUBLISH(); SSG_GI_DMA(st2) __builtin_amdgcn_sched_barrier(0); SSG_GI_MMA(st3)
     }
-    if (mirror) patch[l32 * MP + il] = (hbits)dd;
-    const unsigned red = halfwave_max(dd);              // row maximum over the 32 columns of this half-wave
-    if (l32 == 0 && li < M) atomicMax(&rowmax[li], red);
   }
-  if (mirror) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // patch written and read by this wave only
-    // lane pair (2j, 2j+1) stores the 32 halves of mirrored row j = this tile's column j: 2 x 32 bytes
-    const int mj = lane >> 1, half16 = (lane & 1) * 16;
-    const int grow = tn * GI_T + wn * 32 + mj;            // mirrored row (a column of this tile)
-    const int gcol = tm * GI_T + wm * 32 + half16;        // first of 16 mirrored columns (rows of this tile)
-    if (grow < N) {
-      const hbits* src = patch + mj * MP + half16;
-      hbits* dst = D + (int64_t)grow * N + gcol;
-      if (gcol + 16 <= M && ((((int64_t)grow * N + gcol) & 7) == 0)) {
-        uint4 v0, v1;
-        unsigned w[8];
-#pragma unroll
-        for (int e = 0; e < 8; e++) w[e] = (unsigned)src[2 * e] | ((unsigned)src[2 * e + 1] << 16);
-        v0 = make_uint4(w[0], w[1], w[2], w[3]); v1 = make_uint4(w[4], w[5], w[6], w[7]);
-        reinterpret_cast<uint4*>(dst)[0] = v0; reinterpret_cast<uint4*>(dst)[1] = v1;
-      } else {
-        for (int e = 0; e < 16; e++) if (gcol + e < M) dst[e] = src[e];
-      }
-    }
-  }
-  if (mirror) {   // mirrored rows are this tile's columns: one lane per column and half-wave
-    const unsigned o = (unsigned)__shfl_xor((int)cmax, 32, 64);
-    cmax = cmax > o ? cmax : o;
-    if (h == 0 && jok) atomicMax(&rowmax[gj], cmax);
-  }
+  if (nkb - nfull >= 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_GI_MMA(st0) }
+  if (nkb - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_GI_MMA(st1) }
+  if constexpr (NS == 4) { if (nkb - nfull == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_GI_MMA(st2) } }
+  __syncthreads();                      // drains the (clamped, redundant) tail DMAs before stage 0 becomes the mirror patches
+#undef SSG_GI_DMA
+#undef SSG_GI_MMA
+#undef SSG_GI_PUBLISH
+  gi_epilogue<NL>(acc, st0, nA, nB, M, N, rowA0, D, rowmax, symmetric, tm, tn, mirror);
 }
 
 }  // namespace ssg
 
 using namespace ssg;
+
+// which kernel (and therefore which digit layout) a problem gets: the LDS-DMA kernel for 3 digits when the encoded table fits one buffer
+// resource; SSG_I8_DMA=0: the register-staged kernel of rounds 1-4.  Read per call: the encoder and the multiply must agree.
+static bool gi_use_dma(int n, int d, int ndigits) {
+  const char* e_ = getenv("SSG_I8_DMA");
+  const size_t bytes = (size_t)((n + GI_T - 1) / GI_T * GI_T) * (size_t)((d + 31) / 32) * 32 * (size_t)ndigits;
+  return (e_ ? atoi(e_) : 1) != 0 && ndigits == 3 && bytes < 0xfffffff0ull && (d + 31) / 32 >= 4;
+}
 
 extern "C" size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits) {       // whole 64-row panels
   return (size_t)((n + GI_T - 1) / GI_T * GI_T) * (size_t)((d + 31) / 32) * 32 * (size_t)ndigits;
@@ -323,8 +474,10 @@ extern "C" size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits) {       /
 extern "C" int ssg_gram_i8_encode(const float* x, int n, int d, int ndigits, void* E, int64_t* norms, int32_t* flag, hipStream_t stream) {
   if (n <= 0 || d <= 0 || d > 16384 || (ndigits != 3 && ndigits != 4)) { ssg_set_error("ssg_gram_i8_encode: need 0 < d <= 16384, ndigits 3 or 4 (n=%d d=%d ndigits=%d)", n, d, ndigits); return SSG_ERR_INVALID; }
   const int nkb = (d + 31) / 32;
-  if (ndigits == 3) hipLaunchKernelGGL(gram_i8_encode_kernel<3>, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, nkb, (int8_t*)E, (long long*)norms, flag);
-  else hipLaunchKernelGGL(gram_i8_encode_kernel<4>, dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, nkb, (int8_t*)E, (long long*)norms, flag);
+  if (ndigits == 3 && gi_use_dma(n, d, ndigits))
+    hipLaunchKernelGGL((gram_i8_encode_kernel<3, true>), dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, nkb, (int8_t*)E, (long long*)norms, flag);
+  else if (ndigits == 3) hipLaunchKernelGGL((gram_i8_encode_kernel<3, false>), dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, nkb, (int8_t*)E, (long long*)norms, flag);
+  else hipLaunchKernelGGL((gram_i8_encode_kernel<4, false>), dim3((n + 3) / 4), dim3(256), 0, stream, x, n, d, nkb, (int8_t*)E, (long long*)norms, flag);
   SSG_LAUNCH_CHECK("gram_i8_encode_kernel");
   return SSG_OK;
 }
@@ -350,6 +503,15 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
   const int8_t* e = (const int8_t*)E;
 #define SSG_GI_LAUNCH(NL_, KB_) hipLaunchKernelGGL((gram_i8_kernel<NL_, KB_>), dim3((unsigned)tiles), dim3(256), 0, stream, e, e, \
     (const long long*)norms + row0, (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric | (memory_save ? 2 : 0), flag, sb)
+  if (gi_use_dma(N, d, ndigits)) {
+    const unsigned e_bytes = (unsigned)ssg_gram_i8_encoded_bytes(N, d, ndigits);
+#define SSG_GI_DMA_LAUNCH(NS_) hipLaunchKernelGGL((gram_i8_dma_kernel<3, NS_>), dim3((unsigned)tiles), dim3(256), 0, stream, e, e_bytes, (const long long*)norms + row0, \
+      (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric | (memory_save ? 2 : 0), flag, sb)
+    SSG_GI_DMA_LAUNCH(3);          // (three stages of 12 KB: four workgroups per CU; the four-stage instantiation loses a workgroup per CU to LDS)
+#undef SSG_GI_DMA_LAUNCH
+    SSG_LAUNCH_CHECK("gram_i8_dma_kernel");
+    return SSG_OK;
+  }
   static int kb2 = -1;
   if (kb2 < 0) { const char* e_ = getenv("SSG_I8_KB2"); kb2 = e_ ? atoi(e_) : 1; }   // measured: 1 block per stage (3 waves/SIMD) 2.64 ms, 2 blocks (2 waves/SIMD) 2.9 ms at N=16000
   const bool two = kb2 == 2 && (nkb % 2) == 0;     // two k blocks per LDS stage: half the barriers, but 190 VGPRs
