@@ -507,7 +507,8 @@ extern "C" int ssg_sqdist_self_i8(const void* E, const int64_t* norms, int N, in
     const unsigned e_bytes = (unsigned)ssg_gram_i8_encoded_bytes(N, d, ndigits);
 #define SSG_GI_DMA_LAUNCH(NS_) hipLaunchKernelGGL((gram_i8_dma_kernel<3, NS_>), dim3((unsigned)tiles), dim3(256), 0, stream, e, e_bytes, (const long long*)norms + row0, \
       (const long long*)norms, nrows, N, nkb, row0, D, rowmax, symmetric | (memory_save ? 2 : 0), flag, sb)
-    SSG_GI_DMA_LAUNCH(3);          // (three stages of 12 KB: four workgroups per CU; the four-stage instantiation loses a workgroup per CU to LDS)
+    const char* s_ = getenv("SSG_I8_DMA_STAGES");      // 3 (default): 36 KB, four workgroups per CU; 4: 48 KB, three
+    if (s_ && atoi(s_) == 4) SSG_GI_DMA_LAUNCH(4); else SSG_GI_DMA_LAUNCH(3);
 #undef SSG_GI_DMA_LAUNCH
     SSG_LAUNCH_CHECK("gram_i8_dma_kernel");
     return SSG_OK;

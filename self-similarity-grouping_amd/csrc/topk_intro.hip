@@ -581,26 +581,24 @@ __global__ __launch_bounds__(NT) void topk_introsort_kernel(const hbits* __restr
     const int first = (int)(base - al);
     const int nch = (first + N + 7) >> 3;
     uint32_t* dst = LDS ? ent : arena + (size_t)blockIdx.x * arena_stride;
-    for (int c0 = 0; c0 < nch; c0 += 2 * NT) {      // two 16-byte loads in flight per thread
-      uint4 x[2];
+    // (round 5: the row goes through a bounds-checked buffer resource that starts at its 16-byte-aligned base and ends with the matrix:
+    //  reads past the end return 0, so the loads are unconditional straight-line code.  With `if (c < nch) { if (off + 8 <= total) load
+    //  else tail }` around them hipcc waited for each load where its branch joined -- the "loads in flight" were one at a time.)
+    // (whole dwords: the range check is per dword, and the last half of an odd-sized matrix shares its dword with 2 bytes behind the end)
+    const int64_t row_bytes_ = ((total - al) * 2 + 3) & ~(int64_t)3;
+    const __amdgpu_buffer_rsrc_t rrow_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<hbits*>(D + al), 0,
+                                                                        (int)(row_bytes_ > 0x7ffffff0ll ? 0x7ffffff0ll : row_bytes_), 0x00020000);
+    constexpr int LU = 4;                              // 16-byte loads in flight per thread
+    for (int c0 = 0; c0 < nch; c0 += LU * NT) {
+      uint4 x[LU];
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
-        const int c = c0 + u * NT + tid;
-        const int64_t off = al + (int64_t)c * 8;
-        x[u] = make_uint4(0, 0, 0, 0);
-        if (c < nch) {
-          if (off + 8 <= total) x[u] = *reinterpret_cast<const uint4*>(D + off);
-          else {
-            unsigned w[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int e = 0; e < 8; e++)
-              if (off + e < total) w[e >> 1] |= (unsigned)D[off + e] << ((e & 1) * 16);
-            x[u] = make_uint4(w[0], w[1], w[2], w[3]);
-          }
-        }
+      for (int u = 0; u < LU; u++) {
+        typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+        const v4u_ t_ = __builtin_amdgcn_raw_buffer_load_b128(rrow_, min(c0 + u * NT + tid, nch - 1) * 16, 0, 0);
+        x[u] = make_uint4(t_[0], t_[1], t_[2], t_[3]);
       }
 #pragma unroll
-      for (int u = 0; u < 2; u++) {
+      for (int u = 0; u < LU; u++) {
         const int c = c0 + u * NT + tid;
         if (c < nch) {
           const unsigned w[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
@@ -1055,7 +1053,8 @@ __global__ __launch_bounds__(NT) void topk_introsort_stream_kernel(const hbits* 
     const int64_t al = base & ~(int64_t)7;
     const int first = (int)(base - al);
     // level 1 reads the row of D through a buffer resource (from the row's aligned base to the end of the matrix, at most 4 GB)
-    const int64_t rs_bytes = (total - al) * 2;
+    // (whole dwords: the range check is per dword, and the last half of an odd-sized matrix shares its dword with 2 bytes behind the end)
+    const int64_t rs_bytes = ((total - al) * 2 + 3) & ~(int64_t)3;
     Src<true> drow{nullptr, __builtin_amdgcn_make_buffer_rsrc(const_cast<hbits*>(D + al), 0, (int)(rs_bytes > 0x7ffffff0ll ? 0x7ffffff0ll : rs_bytes), 0x00020000), first};
     int n = N, cd = 2 * (31 - __clz(N)), which = 0, level = 0;
     bool in_lds = false, bad = false;

@@ -382,6 +382,14 @@ def test_introsort_streamed_levels_vs_numpy_argsort(N, cap, dev, monkeypatch):
     old = _rank_rows(keys, 21, dev, force_arena=force)
     monkeypatch.delenv("SSG_INTRO_STREAM")
     assert np.array_equal(old, _rank_rows(keys, 21, dev, force_arena=force))
+    # the LAST row of a matrix with an odd number of halves: its last element shares a dword with the 2 bytes behind the buffer (the row is
+    # read through a bounds-checked buffer resource whose range check is per dword) -- a small key there must still rank first
+    last = keys[:3].copy(); last[2, :] = 9000; last[2, N - 1] = 1; last[2, N - 2] = 2
+    for K in (1, 21):
+        got = _rank_rows(last, K, dev, force_arena=force)
+        assert np.array_equal(got[2], np.argsort(last[2].view(np.float16))[:K]), (N, cap, K, "last row")
+        if N <= 36000:
+            assert np.array_equal(_rank_rows(last, K, dev)[2], got[2])
 
 
 @pytest.mark.parametrize("N,d", [(6000, 64), (20000, 128)])
