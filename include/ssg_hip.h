@@ -200,7 +200,12 @@ int ssg_sort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, ssg_s
  * cursor[1])) == top_guess (the tree ssg_eps_mean_run summed), cursor[0] <= n_cap keys collected, >= top of them, the top-th sorted key below
  * the float32 threshold thr3[0] by its margin.  status6 = {ok, got, zeros, top, top-th key bits, threshold bits}; on failure eps2[0] := NaN */
 int ssg_eps_check(const uint64_t* sorted_keys, const uint64_t* cursor, const uint64_t* thr3, double rho, uint64_t upper_total, int64_t top_guess,
-                  uint64_t n_cap, double* eps2, uint64_t* status6, ssg_stream_t stream);
+                  uint64_t n_cap, double* eps2, uint64_t* status6, const uint64_t* sort_fail, ssg_stream_t stream);   /* sort_fail: nullable, ssg_samplesort_u64_dev's word */
+/* round 5: the same device-sized ascending sort in 5 launches instead of 25 (sample sort: 1023 splitters out of a sorted sample of 4096 keys,
+ * buckets ranked in LDS; keys equal to a splitter get their own bucket, so duplicates cost nothing).  In place through ws (any n_cap >= 1);
+ * *fail = 1 when a bucket between two splitters holds more than 16384 keys (buf is then a permutation of the keys, not sorted) */
+size_t ssg_samplesort_u64_workspace_bytes(uint64_t n_cap);
+int ssg_samplesort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, void* ws, size_t ws_bytes, uint64_t* fail, ssg_stream_t stream);
 size_t ssg_eps_mean_workspace_bytes(int64_t top);
 /* out2[0] = mean of the first `top` sorted keys with numpy's pairwise summation (mode 0: f64;
  * mode 1: float32 sum of half values -> half, out2[1] = its bits) */

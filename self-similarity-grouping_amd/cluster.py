@@ -253,7 +253,7 @@ def eps_rule_dbscan(X, rho, min_samples=4):
     # ---- the sampled threshold and the one full pass, exactly as _eps_rule_sampled queues them
     stride = max(1, h.nrows // 192)
     # every small zero-initialised table of the chain out of ONE allocation (one fill kernel instead of six)
-    z = torch.zeros(2 * 4097 + 5 + 3 + 6 + 2 + 2, dtype=torch.int64, device=dev)
+    z = torch.zeros(2 * 4097 + 5 + 3 + 6 + 2 + 2 + 1, dtype=torch.int64, device=dev)
     hist1, hist2 = z[:4097], z[4097:8194]
     thr3, cursor, status6, ecur, eps2 = z[8194:8199], z[8199:8202], z[8202:8208], z[8208:8210], z[8210:8212].view(torch.float64)
     check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist1), st), "ssg_eps_sample_hist")
@@ -275,9 +275,20 @@ def eps_rule_dbscan(X, rho, min_samples=4):
         check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
     # ---- sort (device-sized), numpy's pairwise mean of the first top_guess keys, the checks -- no read-back
     tree = _eps_tree(L, top_guess, dev, st)
-    check(L.ssg_sort_u64_dev(ptr(buf), n_cap, ptr(cursor), st), "ssg_sort_u64_dev")
+    # sample sort (5 launches) while its 1024 sorting buckets stay LDS-sized: ~1.3 * top candidates expected, a bucket may run to 4x the
+    # mean, 2048 keys fit -> up to 4e5 candidates (N = 16 000: 2.7e5); above that the bitonic network (25+ launches) as in round 4
+    if os.environ.get("SSG_EPS_SORT", "sample") == "bitonic" or 1.3 * top_guess * h.nrows / N > 4.0e5:
+        check(L.ssg_sort_u64_dev(ptr(buf), n_cap, ptr(cursor), st), "ssg_sort_u64_dev")
+        sort_fail = None
+    else:
+        # sample sort: 5 launches whatever the count; its fail word (a bucket the sample missed) is one more condition of the check below
+        sws_bytes = int(L.ssg_samplesort_u64_workspace_bytes(n_cap))
+        sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
+        sort_fail = z[8212:8213]
+        check(L.ssg_samplesort_u64_dev(ptr(buf), n_cap, ptr(cursor), ptr(sws), sws_bytes, ptr(sort_fail), st), "ssg_samplesort_u64_dev")
     check(L.ssg_eps_mean_run(ptr(buf), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), st), "ssg_eps_mean_run")
-    check(L.ssg_eps_check(ptr(buf), ptr(cursor), ptr(thr3), rho, upper_total, top_guess, n_cap, ptr(eps2), ptr(status6), st), "ssg_eps_check")
+    check(L.ssg_eps_check(ptr(buf), ptr(cursor), ptr(thr3), rho, upper_total, top_guess, n_cap, ptr(eps2), ptr(status6),
+                          ptr(sort_fail), st), "ssg_eps_check")
     # ---- region query with eps read from the device, components, labels
     cnt = torch.empty(h.nrows, dtype=torch.int32, device=dev)
     ecap = max(64 * h.nrows, 1 << 16)

@@ -984,13 +984,60 @@ __global__ void cc_init_kernel(const int32_t* __restrict__ cnt, int N, int min_s
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < N) { parent[i] = i; lab[i] = 0x7fffffff; (void)cnt; (void)min_samples; }
 }
+// The region query emits a row's edges (i, k1), (i, k2), ... next to each other, so a wave holds runs of lanes with the same i.  The lanes
+// of a run agree on m = min(k1, k2, ...) over the run's core-core edges (a segmented min: 12 shuffles); `first` marks the run's first lane.
+__device__ __forceinline__ void cc_run_min(const int32_t* __restrict__ edges, unsigned long long e, unsigned long long ne, const int32_t* __restrict__ cnt,
+                                           int min_samples, int lane, int& i, int& k, bool& valid, int& m, bool& first) {
+  i = -1 - lane; k = 0x7fffffff; valid = false;                                   // (idle lanes: a run of their own)
+  if (e < ne) {
+    i = edges[2 * e]; const int kk = edges[2 * e + 1];
+    valid = i != kk && cnt[i] >= min_samples && cnt[kk] >= min_samples;
+    if (valid) k = kk;
+  }
+  m = k;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int oi = __shfl_up(i, d, 64), om = __shfl_up(m, d, 64);
+    if (lane >= d && oi == i) m = om < m ? om : m;
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int oi = __shfl_down(i, d, 64), om = __shfl_down(m, d, 64);
+    if (lane + d < 64 && oi == i) m = om < m ? om : m;
+  }
+  const int pi = __shfl_up(i, 1, 64);
+  first = lane == 0 || pi != i;
+}
+// Pass 1 (round 5): every core point is hooked under its smallest core neighbour with ONE fire-and-forget atomicMin per run -- no find,
+// no compare-and-swap, no dependent chain of device-scope accesses (each is ~1.5 us on this part: the L2s of the 8 XCDs are not coherent
+// with each other, a device-scope access goes out to the fabric).  parent[i] <= i stays a valid forest inside i's component; a clique --
+// what a DBSCAN cluster mostly is -- ends with every member pointing at its smallest one.
+__global__ void cc_hook_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const unsigned long long* __restrict__ ne_dev,
+                               const int32_t* __restrict__ cnt, int min_samples, int* __restrict__ parent) {
+  if (ne_dev) { const unsigned long long d = *ne_dev; ne = d < ne ? d : ne; }     // device-side count (region query cursor), capped by the capacity
+  const int lane = (int)(threadIdx.x & 63);
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long eb = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x - lane; eb < ne; eb += stride) {     // (wave-uniform trip count)
+    int i, k, m; bool valid, first;
+    cc_run_min(edges, eb + lane, ne, cnt, min_samples, lane, i, k, valid, m, first);
+    if (first && m < i) atomicMin(&parent[i], m);                                  // (m < i implies the run holds a core-core edge, so i is core)
+  }
+}
+// Pass 2: the union-find proper, for the edges pass 1 left open.  Two rounds of plain loads (an ancestor read a moment too early is still
+// an ancestor in the same component) show for nearly every edge that both ends already hang under the same point; the rest is united
+// with the lock-free find / compare-and-swap above.  (Before pass 1 existed every edge paid two finds and a compare-and-swap, the lanes
+// of a run with k < i one winner at a time: 77 us at N = 16 000; hooking the run's k to the run's minimum instead: 60 us.)
 __global__ void cc_union_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const unsigned long long* __restrict__ ne_dev,
                                 const int32_t* __restrict__ cnt, int min_samples,
                                 int* __restrict__ parent) {
-  if (ne_dev) { const unsigned long long d = *ne_dev; ne = d < ne ? d : ne; }     // device-side count (region query cursor), capped by the capacity
+  if (ne_dev) { const unsigned long long d = *ne_dev; ne = d < ne ? d : ne; }
   for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (unsigned long long)gridDim.x * blockDim.x) {
     const int i = edges[2 * e], k = edges[2 * e + 1];
-    if (i != k && cnt[i] >= min_samples && cnt[k] >= min_samples) uf_union(parent, i, k);
+    if (i == k || cnt[i] < min_samples || cnt[k] < min_samples) continue;
+    const int hi = parent[i], hk = parent[k];
+    if (hi == hk) continue;
+    const int gi = parent[hi], gk = parent[hk];
+    if (gi != gk) uf_union(parent, gi, gk);
   }
 }
 // rootflag[i] = 1 iff i is a core point that is the root (= smallest index) of its component
@@ -1006,11 +1053,15 @@ __global__ void cc_label_core_kernel(const int32_t* __restrict__ cnt, int N, int
   const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (i < N && cnt[i] >= min_samples) lab[i] = (int)rootid[parent[i]];
 }
+// border points take the smallest label among their core neighbours; the same launch labels the core points (disjoint entries of lab)
 __global__ void cc_border_kernel(const int32_t* __restrict__ edges, unsigned long long ne, const unsigned long long* __restrict__ ne_dev,
                                  const int32_t* __restrict__ cnt, int min_samples,
-                                 const int* __restrict__ parent, const int64_t* __restrict__ rootid, int* __restrict__ lab) {
+                                 const int* __restrict__ parent, const int64_t* __restrict__ rootid, int* __restrict__ lab, int N) {
   if (ne_dev) { const unsigned long long d = *ne_dev; ne = d < ne ? d : ne; }
-  for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (unsigned long long)gridDim.x * blockDim.x) {
+  const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = gid; i < (unsigned long long)N; i += stride)
+    if (cnt[i] >= min_samples) lab[i] = (int)rootid[parent[i]];
+  for (unsigned long long e = gid; e < ne; e += stride) {
     const int i = edges[2 * e], k = edges[2 * e + 1];
     if (cnt[i] >= min_samples && cnt[k] < min_samples) atomicMin(&lab[k], (int)rootid[parent[i]]);
   }
@@ -1270,21 +1321,239 @@ extern "C" int ssg_sort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n
   return SSG_OK;
 }
 
+// ---- round 5: sample sort of the device-sized key list -------------------------------------------------------------------------------
+// The bitonic network above costs 25 launches (0.15 ms of 4..9 us kernels + their dispatch gaps) for the ~2.7e5 candidates of the eps rule
+// at N = 16 000 -- a third of the whole eps rule + DBSCAN chain.  Five launches instead:
+//   1. one workgroup sorts a strided sample of 4096 keys in LDS and keeps every 4th as a splitter (1023 of them);
+//   2. every workgroup of 4096 keys finds each key's bucket by a 10-step lower bound over the splitters in LDS and counts per bucket:
+//      bucket = 2 * #(splitters < key) + (key == that splitter) -- keys EQUAL to a splitter get a bucket of their own (odd numbers), so
+//      any number of duplicates (half-valued distances: a few hundred distinct keys) stays out of the buckets that need sorting; the
+//      workgroup reserves its share of every bucket with one returning atomic per non-empty bucket (the order inside a bucket is free);
+//   3. one workgroup scans the 2048 bucket totals into offsets;
+//   4. the keys are scattered to their bucket's range (LDS cursors on top of the reserved bases);
+//   5. one workgroup per bucket sorts its keys in LDS (bitonic on the next power of two: ~260 keys at 4x oversampling) and writes them
+//      back.  Buckets over 2048 keys are ranked out of global memory (slow, exact); over 16384: *fail = 1.
+// (First version, measured: ranking every key against the whole bucket in LDS = 73 us of dependent LDS reads, the sample's bitonic
+//  network with integer divisions in its index arithmetic = 51 us, a (workgroup x bucket) count matrix scanned by one workgroup = 17 us:
+//  171 us, slower than the network it was to replace.)
+constexpr int SS_SAMPLE = 4096, SS_NSPLIT = 1023, SS_NBK = 2 * (SS_NSPLIT + 1), SS_CHUNK = 4096, SS_CAP = 2048, SS_CAP_GLOBAL = 16384;
+struct SsWs { unsigned long long* tmp; unsigned long long* split; unsigned int* cmat; unsigned int* gcount; unsigned int* off; unsigned short* bid; };
+static size_t ss_layout(uint64_t n_cap, char* base, SsWs* w) {
+  size_t o = 0;
+  const size_t G = (size_t)((n_cap + SS_CHUNK - 1) / SS_CHUNK);
+  auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t a_tmp = take((size_t)n_cap * 8), a_split = take(1024 * 8), a_cmat = take(G * SS_NBK * 4), a_gc = take(SS_NBK * 4), a_off = take((SS_NBK + 1) * 4),
+               a_bid = take((size_t)n_cap * 2);
+  if (w) {
+    w->tmp = (unsigned long long*)(base + a_tmp); w->split = (unsigned long long*)(base + a_split); w->cmat = (unsigned int*)(base + a_cmat);
+    w->gcount = (unsigned int*)(base + a_gc); w->off = (unsigned int*)(base + a_off); w->bid = (unsigned short*)(base + a_bid);
+  }
+  return o;
+}
+__device__ __forceinline__ unsigned long long ss_count_of(const unsigned long long* n_dev, unsigned long long n_cap) {
+  const unsigned long long n = *n_dev;
+  return n > n_cap ? n_cap : n;
+}
+// One bitonic network over M = E * NT keys, E consecutive keys per thread IN REGISTERS (key index e = t * E + r).  A compare-exchange
+// partner at distance j sits in the same thread (j < E), in the same wave (j < 64 E: one 64-bit shuffle) or in another wave (LDS, two
+// barriers) -- 10 of the 78 steps of a 4096-key network go through LDS instead of all of them (the all-LDS version was bound by LDS
+// traffic: 40 us for the sample, 21 us for the buckets).  After the call key e of the sorted order is v[e - t * E] of thread e / E.
+template <int E, int NT>
+__device__ __forceinline__ void ss_bitonic_reg(unsigned long long (&v)[E], unsigned long long* s, int t) {
+  constexpr int M = E * NT, WSPAN = 64 * E;
+  const int e0 = t * E;
+  for (int k = 2; k <= M; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < E) {
+#pragma unroll
+        for (int jj = 1; jj < E; jj <<= 1)
+          if (j == jj) {
+#pragma unroll
+            for (int r = 0; r < E; r++)
+              if (!(r & jj)) cswap(v[r], v[r | jj], ((e0 + r) & k) == 0);
+          }
+      } else {
+        unsigned long long pv[E];
+        if (j < WSPAN) {
+          const int lx = j / E;
+#pragma unroll
+          for (int r = 0; r < E; r++) pv[r] = __shfl_xor(v[r], lx, 64);
+        } else {
+#pragma unroll
+          for (int r = 0; r < E; r++) s[e0 + r] = v[r];
+          __syncthreads();
+#pragma unroll
+          for (int r = 0; r < E; r++) pv[r] = s[(e0 + r) ^ j];
+          __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < E; r++) {
+          const int e = e0 + r;
+          const bool take_min = (((e & j) == 0) == ((e & k) == 0));      // the lower key of an ascending pair, the upper one of a descending pair
+          const unsigned long long a = v[r], b = pv[r];
+          v[r] = take_min ? (a < b ? a : b) : (a < b ? b : a);
+        }
+      }
+    }
+}
+__global__ __launch_bounds__(1024) void ss_splitters_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap,
+                                                            unsigned long long* __restrict__ split, unsigned int* __restrict__ gcount,
+                                                            unsigned long long* __restrict__ fail) {
+  __shared__ unsigned long long s[SS_SAMPLE];
+  const unsigned long long n = ss_count_of(n_dev, n_cap);
+  const int t = (int)threadIdx.x;
+  if (t == 0) *fail = 0ull;
+  gcount[t] = 0u; gcount[t + 1024] = 0u;
+  if (n == 0) return;
+  unsigned long long v[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) v[r] = a[((unsigned long long)(4 * t + r) * n) >> 12];
+  ss_bitonic_reg<4, 1024>(v, s, t);
+  if (t < SS_NSPLIT) split[t] = v[3];                               // sorted sample keys 3, 7, .., 4091
+}
+// sp: 1024 entries in LDS, the 1023 splitters ascending + ~0
+__device__ __forceinline__ int ss_bucket(const unsigned long long* sp, unsigned long long key) {
+  int lo = 0;
+#pragma unroll
+  for (int step = 512; step > 0; step >>= 1) lo += (sp[lo + step - 1] < key) ? step : 0;
+  return 2 * lo + (sp[lo] == key ? 1 : 0);
+}
+__global__ __launch_bounds__(256) void ss_count_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap,
+                                                       const unsigned long long* __restrict__ split, unsigned int* __restrict__ gcount,
+                                                       unsigned int* __restrict__ cmat, unsigned short* __restrict__ bid) {
+  __shared__ unsigned long long sp[1024];
+  __shared__ unsigned int cn[SS_NBK];
+  const unsigned long long n = ss_count_of(n_dev, n_cap);
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * SS_CHUNK;
+  if (g0 >= n) return;
+  const int t = (int)threadIdx.x;
+  for (int q = t; q < 1024; q += 256) sp[q] = q < SS_NSPLIT ? split[q] : ~0ull;
+  for (int q = t; q < SS_NBK; q += 256) cn[q] = 0u;
+  __syncthreads();
+  for (int u = 0; u < SS_CHUNK / 256; u += 4) {
+    unsigned long long key[4]; int b[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { const unsigned long long idx = g0 + (unsigned long long)(u + v) * 256 + t; key[v] = a[idx < n ? idx : n - 1]; }
+#pragma unroll
+    for (int v = 0; v < 4; v++) b[v] = ss_bucket(sp, key[v]);
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const unsigned long long idx = g0 + (unsigned long long)(u + v) * 256 + t;
+      if (idx < n) { atomicAdd(&cn[b[v]], 1u); bid[idx] = (unsigned short)b[v]; }
+    }
+  }
+  __syncthreads();
+  for (int q = t; q < SS_NBK; q += 256) {
+    const unsigned int c = cn[q];
+    cmat[(size_t)blockIdx.x * SS_NBK + q] = c ? atomicAdd(&gcount[q], c) : 0u;       // this workgroup's base inside bucket q
+  }
+}
+__global__ __launch_bounds__(1024) void ss_scan_kernel(const unsigned int* __restrict__ gcount, unsigned int* __restrict__ off) {
+  __shared__ unsigned int wsum[16];
+  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
+  const unsigned int v0 = gcount[2 * t], v1 = gcount[2 * t + 1];
+  unsigned int sc = v0 + v1;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(sc, d, 64); if (lane >= d) sc += o; }
+  if (lane == 63) wsum[wave] = sc;
+  __syncthreads();
+  unsigned int woff = 0;
+  for (int w = 0; w < wave; w++) woff += wsum[w];
+  const unsigned int excl = woff + sc - (v0 + v1);
+  off[2 * t] = excl; off[2 * t + 1] = excl + v0;
+  if (t == 1023) off[SS_NBK] = excl + v0 + v1;
+}
+__global__ __launch_bounds__(256) void ss_scatter_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap,
+                                                         const unsigned int* __restrict__ cmat, const unsigned int* __restrict__ off,
+                                                         const unsigned short* __restrict__ bid, unsigned long long* __restrict__ tmp) {
+  __shared__ unsigned int cur[SS_NBK];
+  const unsigned long long n = ss_count_of(n_dev, n_cap);
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * SS_CHUNK;
+  if (g0 >= n) return;
+  const int t = (int)threadIdx.x;
+  for (int q = t; q < SS_NBK; q += 256) cur[q] = off[q] + cmat[(size_t)blockIdx.x * SS_NBK + q];
+  __syncthreads();
+  for (int u = 0; u < SS_CHUNK / 256; u += 4) {
+    unsigned long long key[4]; int b[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const unsigned long long idx = g0 + (unsigned long long)(u + v) * 256 + t, ic = idx < n ? idx : n - 1;
+      key[v] = a[ic]; b[v] = (int)bid[ic];
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+      const unsigned long long idx = g0 + (unsigned long long)(u + v) * 256 + t;
+      if (idx < n) tmp[atomicAdd(&cur[b[v]], 1u)] = key[v];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void ss_bucket_sort_kernel(const unsigned long long* __restrict__ tmp, const unsigned int* __restrict__ off,
+                                                             unsigned long long* __restrict__ out, unsigned long long* __restrict__ fail) {
+  __shared__ unsigned long long s[SS_CAP];
+  const int b = (int)blockIdx.x, t = (int)threadIdx.x;
+  const unsigned int s0 = off[b];
+  const int len = (int)(off[b + 1] - s0);
+  if (len <= 0) return;
+  if ((b & 1) || len == 1 || len > SS_CAP_GLOBAL) {                 // all keys equal (a splitter's own bucket) / one key / hopeless: copy
+    for (int q = t; q < len; q += 256) out[s0 + q] = tmp[s0 + q];
+    if (!(b & 1) && len > SS_CAP_GLOBAL && t == 0) atomicOr(fail, 1ull);
+    return;
+  }
+  if (len <= SS_CAP) {
+    // 256 * E keys (E = 1, 2, 4, 8: the power of two that holds the bucket), padded with ~0
+#define SS_BUCKET(E_)                                                                                          \
+    {                                                                                                          \
+      unsigned long long v[E_];                                                                                \
+      _Pragma("unroll") for (int r = 0; r < E_; r++) { const int e = t * E_ + r; v[r] = e < len ? tmp[s0 + e] : ~0ull; } \
+      ss_bitonic_reg<E_, 256>(v, s, t);                                                                        \
+      _Pragma("unroll") for (int r = 0; r < E_; r++) { const int e = t * E_ + r; if (e < len) out[s0 + e] = v[r]; }      \
+    }
+    if (len <= 256) SS_BUCKET(1) else if (len <= 512) SS_BUCKET(2) else if (len <= 1024) SS_BUCKET(4) else SS_BUCKET(8)
+#undef SS_BUCKET
+    return;
+  }
+  for (int q = t; q < len; q += 256) {                                // an oversized bucket: every key ranked against the bucket out of global memory
+    const unsigned long long key = tmp[s0 + q];
+    int rank = 0;
+    for (int j = 0; j < len; j++) { const unsigned long long kj = tmp[s0 + j]; rank += (kj < key || (kj == key && j < q)) ? 1 : 0; }
+    out[s0 + rank] = key;
+  }
+}
+extern "C" size_t ssg_samplesort_u64_workspace_bytes(uint64_t n_cap) { return ss_layout(n_cap, nullptr, nullptr); }
+// ascending sort of buf[0 .. min(*n_dev, n_cap)) in place (through ws); *fail = 1 when a bucket could not be sorted (more than 16384 keys
+// strictly between two neighbouring splitters: the sample missed the distribution) -- buf then holds a permutation of the keys, not sorted.
+extern "C" int ssg_samplesort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, void* ws, size_t ws_bytes, uint64_t* fail, hipStream_t stream) {
+  if (!buf || !n_dev || !ws || !fail || n_cap == 0 || n_cap > (1ull << 31)) { ssg_set_error("ssg_samplesort_u64_dev: bad arguments"); return SSG_ERR_INVALID; }
+  SsWs w;
+  if (ss_layout(n_cap, (char*)ws, &w) > ws_bytes) { ssg_set_error("ssg_samplesort_u64_dev: workspace too small"); return SSG_ERR_INVALID; }
+  unsigned long long* a = (unsigned long long*)buf;
+  const unsigned long long* nd = (const unsigned long long*)n_dev;
+  const unsigned G = (unsigned)((n_cap + SS_CHUNK - 1) / SS_CHUNK);
+  hipLaunchKernelGGL(ss_splitters_kernel, dim3(1), dim3(1024), 0, stream, a, nd, (unsigned long long)n_cap, w.split, w.gcount, (unsigned long long*)fail);
+  hipLaunchKernelGGL(ss_count_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.split, w.gcount, w.cmat, w.bid);
+  hipLaunchKernelGGL(ss_scan_kernel, dim3(1), dim3(1024), 0, stream, w.gcount, w.off);
+  hipLaunchKernelGGL(ss_scatter_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.cmat, w.off, w.bid, w.tmp);
+  hipLaunchKernelGGL(ss_bucket_sort_kernel, dim3(SS_NBK), dim3(256), 0, stream, w.tmp, w.off, a, (unsigned long long*)fail);
+  SSG_LAUNCH_CHECK("sample sort (device-sized)");
+  return SSG_OK;
+}
+
 // The a-posteriori checks of the sampled eps rule (ssg_amd/cluster.py _eps_rule_sampled) on the device, one thread:
 //   count = upper_total - zeros;  top = rint(rho * count) (np.round: half to even, selftraining.py:292) must equal the top_guess the
 //   summation tree was built for;  every collected key fits (got <= n_cap), at least `top` were collected, the threshold is finite and
-//   the top-th sorted key lies below it by the float32 surrogate's margin (=> the `top` smallest are all among the collected keys).
+//   the top-th sorted key lies below it by the float32 surrogate's margin (=> the `top` smallest are all among the collected keys);
+//   *sort_fail (the sample sort's word; may be null) is zero.
 // status6 = {ok, got, zeros, top, bits of the top-th key, threshold bits};  eps2[0] (the mean ssg_eps_mean_run left there) is replaced
 // by NaN when a check fails, so that a region query queued behind finds nothing and the caller falls back.
 __global__ void eps_check_kernel(const unsigned long long* __restrict__ sorted, const unsigned long long* __restrict__ cursor, const unsigned long long* __restrict__ thr3,
                                  double rho, unsigned long long upper_total, long long top_guess, unsigned long long n_cap, double* __restrict__ eps2,
-                                 unsigned long long* __restrict__ status6) {
+                                 unsigned long long* __restrict__ status6, const unsigned long long* __restrict__ sort_fail) {
   if (blockIdx.x || threadIdx.x) return;
   const unsigned long long got = cursor[0], zeros = cursor[1];
   const long long count = (long long)(upper_total - zeros);
   const long long top = (long long)rint(rho * (double)count);
   const double thr = (double)__uint_as_float((unsigned)(thr3[0] & 0xffffffffull));
-  bool ok = top == top_guess && top > 0 && got <= n_cap && got >= (unsigned long long)top && isfinite(thr);
+  bool ok = top == top_guess && top > 0 && got <= n_cap && got >= (unsigned long long)top && isfinite(thr) && !(sort_fail && *sort_fail);
   unsigned long long kb = 0;
   if (ok) {
     kb = sorted[top - 1];
@@ -1295,11 +1564,11 @@ __global__ void eps_check_kernel(const unsigned long long* __restrict__ sorted, 
   if (!ok) eps2[0] = __longlong_as_double(0x7ff8000000000000ll);
 }
 extern "C" int ssg_eps_check(const uint64_t* sorted_keys, const uint64_t* cursor, const uint64_t* thr3, double rho, uint64_t upper_total, int64_t top_guess,
-                             uint64_t n_cap, double* eps2, uint64_t* status6, hipStream_t stream) {
+                             uint64_t n_cap, double* eps2, uint64_t* status6, const uint64_t* sort_fail, hipStream_t stream) {
   if (!sorted_keys || !cursor || !thr3 || !eps2 || !status6) { ssg_set_error("ssg_eps_check: null argument"); return SSG_ERR_INVALID; }
   hipLaunchKernelGGL(eps_check_kernel, dim3(1), dim3(64), 0, stream, (const unsigned long long*)sorted_keys, (const unsigned long long*)cursor,
                      (const unsigned long long*)thr3, rho, (unsigned long long)upper_total, (long long)top_guess, (unsigned long long)n_cap, eps2,
-                     (unsigned long long*)status6);
+                     (unsigned long long*)status6, (const unsigned long long*)sort_fail);
   SSG_LAUNCH_CHECK("eps_check_kernel");
   return SSG_OK;
 }
@@ -1458,11 +1727,14 @@ static int dbscan_cc_impl(const int32_t* cnt, const int32_t* edges, uint64_t ned
   const int nb = (N + 255) / 256;
   const int eb = nedges ? (int)((nedges + 255) / 256 < 8192 ? (nedges + 255) / 256 : 8192) : 1;
   hipLaunchKernelGGL(cc_init_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, lab);
-  if (nedges) hipLaunchKernelGGL(cc_union_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent);
+  if (nedges) {
+    hipLaunchKernelGGL(cc_hook_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent);
+    hipLaunchKernelGGL(cc_union_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent);
+  }
   hipLaunchKernelGGL(cc_flatten_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootflag);
   hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, stream, rootflag, N, rootid);
-  hipLaunchKernelGGL(cc_label_core_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootid, lab);
-  if (nedges) hipLaunchKernelGGL(cc_border_kernel, dim3(eb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent, rootid, lab);
+  if (nedges) hipLaunchKernelGGL(cc_border_kernel, dim3(eb > nb ? eb : nb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent, rootid, lab, N);
+  else hipLaunchKernelGGL(cc_label_core_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootid, lab);
   hipLaunchKernelGGL(cc_finalize_kernel, dim3(nb), dim3(256), 0, stream, lab, N, labels);
   SSG_LAUNCH_CHECK("dbscan_cc");
   return SSG_OK;

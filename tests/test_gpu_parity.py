@@ -287,6 +287,70 @@ def test_sort_u64_dev_sorts_the_device_count(dev):
         assert torch.equal(buf[:n].cpu(), torch.sort(keys[:n]).values), n
 
 
+def test_samplesort_u64_dev_sorts_the_device_count(dev):
+    """ssg_samplesort_u64_dev (5 launches, any capacity): buf[0 .. *n_dev) sorted for counts around the chunk / sample sizes, on uniform
+    keys, on double bit patterns crowded against one end, on a few hundred distinct values (half-valued distances: every key a duplicate),
+    on all-equal keys and on an already sorted list; the fail word stays 0; the tail past the count is untouched"""
+    from ssg_amd import _lib
+    from ssg_amd._lib import check, ptr, stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    for n_cap in (1, 777, 1 << 15, 300001):
+        wsb = int(L.ssg_samplesort_u64_workspace_bytes(n_cap))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        fail = torch.full((1,), 5, dtype=torch.int64, device=dev)
+        makers = {
+            "uniform": lambda: torch.randint(0, 1 << 62, (n_cap,), generator=g, dtype=torch.int64),
+            "crowded doubles": lambda: (0.9 - 0.9 * torch.rand(n_cap, generator=g, dtype=torch.float64) ** 8).view(torch.int64),
+            "few distinct": lambda: torch.randint(0, 300, (n_cap,), generator=g, dtype=torch.int64) * 1000003,
+            "all equal": lambda: torch.full((n_cap,), 424242, dtype=torch.int64),
+            "sorted": lambda: torch.arange(n_cap, dtype=torch.int64) * 3,
+        }
+        for name, mk in makers.items():
+            for n in sorted({0, 1, 2, 5, 4095, 4096, 4097, 8191, 8192, 8193, 20000, n_cap - 1, n_cap}):
+                if n < 0 or n > n_cap:
+                    continue
+                keys = mk()
+                buf = keys.to(dev)
+                nd = torch.tensor([n, 7, 9], dtype=torch.int64, device=dev)
+                check(L.ssg_samplesort_u64_dev(ptr(buf), n_cap, ptr(nd), ptr(ws), wsb, ptr(fail), stream()), "ssg_samplesort_u64_dev")
+                out = buf.cpu()
+                assert int(fail.item()) == 0, (name, n_cap, n)
+                assert torch.equal(out[:n], torch.sort(keys[:n]).values), (name, n_cap, n)
+                assert torch.equal(out[n:], keys[n:]), (name, n_cap, n)
+    # a count above the capacity is clamped (the eps check reports it)
+    n_cap = 5000
+    wsb = int(L.ssg_samplesort_u64_workspace_bytes(n_cap)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    keys = torch.randint(0, 1 << 40, (n_cap,), generator=g, dtype=torch.int64); buf = keys.to(dev)
+    nd = torch.tensor([n_cap + 99], dtype=torch.int64, device=dev); fail = torch.zeros(1, dtype=torch.int64, device=dev)
+    check(L.ssg_samplesort_u64_dev(ptr(buf), n_cap, ptr(nd), ptr(ws), wsb, ptr(fail), stream()), "ssg_samplesort_u64_dev")
+    assert torch.equal(buf.cpu(), torch.sort(keys).values)
+
+
+def test_samplesort_oversized_bucket_paths(dev):
+    """a distribution the strided sample cannot see: 30 000 distinct keys hidden in ONE stretch between two sampled positions' values
+    (every sampled key is one of two values) -> buckets over the LDS size are ranked out of global memory, over 16384 keys raise the
+    fail word (and `ssg_eps_check` turns that into ok = 0)"""
+    from ssg_amd import _lib
+    from ssg_amd._lib import check, ptr, stream
+    L = _lib.lib()
+    n = 1 << 16                                       # sample stride 16: positions 0, 16, 32, ...
+    for hidden, want_fail in ((5000, 0), (30000, 1)):
+        keys = torch.full((n,), 10, dtype=torch.int64)
+        keys[n // 2:] = 1 << 40
+        pos = torch.arange(hidden) * 2 + 1            # odd positions: never sampled
+        keys[pos] = 1000 + torch.randperm(hidden, generator=torch.Generator().manual_seed(1)).to(torch.int64)
+        buf = keys.to(dev)
+        wsb = int(L.ssg_samplesort_u64_workspace_bytes(n)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        nd = torch.tensor([n], dtype=torch.int64, device=dev); fail = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(L.ssg_samplesort_u64_dev(ptr(buf), n, ptr(nd), ptr(ws), wsb, ptr(fail), stream()), "ssg_samplesort_u64_dev")
+        assert int(fail.item()) == want_fail
+        if not want_fail:
+            assert torch.equal(buf.cpu(), torch.sort(keys).values)
+        else:
+            assert torch.equal(torch.sort(buf.cpu()).values, torch.sort(keys).values)      # still a permutation of the keys
+
+
 def test_range_stats_kernel(dev):
     """ssg_range_stats_f32 (one launch for the four value ranges the host decides on) against torch: maxima exact, norms upper bounds
     within 2e-5 relative; NaN propagates."""

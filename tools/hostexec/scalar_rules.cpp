@@ -43,6 +43,10 @@ static inline int hx_atomicMin(int* p, int v) { const int o = *p; if (v < o) *p 
 static inline int hx_atomicCAS(int* p, int cmp, int v) { const int o = *p; if (o == cmp) *p = v; return o; }
 #define atomicMin hx_atomicMin
 #define atomicCAS hx_atomicCAS
+// ... and a wave is that one thread (lane 0): a shuffle returns the lane's own value, so cc_hook_kernel's segmented min over the lanes of a
+// run degenerates to m = k and every edge hooks by itself
+#define __shfl_up(v, d, w) (v)
+#define __shfl_down(v, d, w) (v)
 #include <algorithm>
 #include <vector>
 using std::max;
@@ -94,13 +98,13 @@ void hx_dbscan_cc(const int32_t* cnt, const int32_t* edges, unsigned long long n
   hx_blockDim.x = 1; hx_gridDim.x = 1; hx_threadIdx.x = 0;
   for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_init_kernel(cnt, N, min_samples, parent.data(), lab.data()); }
   hx_blockIdx.x = 0;
-  if (ne) cc_union_kernel(edges, ne, nullptr, cnt, min_samples, parent.data());
+  if (ne) { cc_hook_kernel(edges, ne, nullptr, cnt, min_samples, parent.data()); cc_union_kernel(edges, ne, nullptr, cnt, min_samples, parent.data()); }
   for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_flatten_kernel(cnt, N, min_samples, parent.data(), rootflag.data()); }
   int64_t run = 0;
   for (int i = 0; i < N; i++) { rootid[i] = run; run += rootflag[i]; }
-  for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_label_core_kernel(cnt, N, min_samples, parent.data(), rootid.data(), lab.data()); }
   hx_blockIdx.x = 0;
-  if (ne) cc_border_kernel(edges, ne, nullptr, cnt, min_samples, parent.data(), rootid.data(), lab.data());
+  if (ne) cc_border_kernel(edges, ne, nullptr, cnt, min_samples, parent.data(), rootid.data(), lab.data(), N);      // (labels the core points too)
+  else for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_label_core_kernel(cnt, N, min_samples, parent.data(), rootid.data(), lab.data()); }
   for (int i = 0; i < N; i++) { hx_blockIdx.x = (unsigned)i; cc_finalize_kernel(lab.data(), N, labels); }
   hx_blockIdx.x = 0;
 }

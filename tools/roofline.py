@@ -12,7 +12,7 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec
 
 K5_K12 = ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_jaccard_rows2", "ssg_half_min",
           "ssg_eps_hist", "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_refine_threshold", "ssg_eps_compact_below",
-          "ssg_eps_compact_below_s", "ssg_fill_u64", "ssg_sort_u64", "ssg_sort_u64_dev", "ssg_eps_check", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_region_query_s",
+          "ssg_eps_compact_below_s", "ssg_fill_u64", "ssg_sort_u64", "ssg_sort_u64_dev", "ssg_samplesort_u64_dev", "ssg_eps_check", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_region_query_s",
           "ssg_region_query_dev", "ssg_region_query_s_dev", "ssg_dbscan_cc",
           "ssg_dbscan_cc_dev")
 
