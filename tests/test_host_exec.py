@@ -46,7 +46,8 @@ def hx(tmp_path_factory):
             cut("cluster.hip", "__device__ __forceinline__ int sur_bin(float x)"),
             cut("cluster.hip", "__device__ __forceinline__ float sur_bin_upper"),
             cut("topk_intro.hip", "constexpr uint32_t KEY_NAN"),
-            cut("topk_intro.hip", "__device__ __forceinline__ uint32_t norm_key")]
+            cut("topk_intro.hip", "__device__ __forceinline__ uint32_t norm_key"),
+            cut("cluster.hip", "__device__ __forceinline__ int ss_bucket")]
     assert "sqrt_units48_to_half" in text[0]
     (d / "rules_cut.inc").write_text("\n".join(text))
     (d / "preprocess_cut.inc").write_text(cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_h_u8_kernel") + "\n" +
@@ -216,6 +217,28 @@ def test_rank_key_and_surrogate_bins(hx):
     assert np.all(x[inside] < up[b[inside]]) and np.all(np.diff(up) > 0)
     lo = b > 0
     assert np.all(x[lo] >= up[b[lo] - 1])
+
+
+def test_sample_sort_bucket_rule(hx):
+    """`ss_bucket` of the device-sized sample sort (cluster.hip, round 5), its own text on the host: bucket = 2 * #(splitters < key) + (key equals
+    that splitter) against numpy's searchsorted, on splitter tables with duplicates -- and the property the sort rests on: the bucket
+    number never decreases with the key, and an odd bucket holds copies of ONE key only"""
+    rng = np.random.default_rng(21)
+    for trial in range(6):
+        hi = [1 << 62, 5000, 300, 3, 1 << 40, 1][trial]
+        sp = np.sort(rng.integers(0, hi, 1023, dtype=np.uint64))
+        table = np.concatenate([sp, np.array([0xFFFFFFFFFFFFFFFF], dtype=np.uint64)])
+        keys = np.concatenate([rng.integers(0, max(hi, 2) * 2, 200000, dtype=np.uint64), sp, sp + np.uint64(1), np.array([0, 0xFFFFFFFFFFFFFFFF], dtype=np.uint64)])
+        out = np.empty(keys.size, dtype=np.int32)
+        hx.hx_ss_bucket(table.ctypes.data_as(ctypes.c_void_p), keys.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(keys.size), out.ctypes.data_as(ctypes.c_void_p))
+        lo = np.searchsorted(sp, keys, side="left")
+        eq = table[lo] == keys
+        assert np.array_equal(out, (2 * lo + eq).astype(np.int32)), trial
+        order = np.argsort(keys, kind="stable")
+        assert (np.diff(out[order]) >= 0).all(), trial
+        odd = out % 2 == 1
+        for b in np.unique(out[odd])[:50]:
+            assert np.unique(keys[out == b]).size == 1, (trial, b)
 
 
 def test_resize_kernels_on_host_match_pillow(hx):
