@@ -306,6 +306,18 @@ def initial_rank(D, rowmax, N, nrows, K, rank_mode=None, force_arena=False):
     return rank_blk
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    """the second HIP stream of a device (created once): the source term of `re_ranking_device` runs on it beside the k-reciprocal kernels"""
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, keep_euclid=True, row0=0, nrows=None,
                       group=None, stages=None, rank_mode=None, memory_save=False, validate=True):
     """Fused device pipeline K3..K9 for one feature split.
@@ -340,10 +352,28 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     # ---- source-domain term (rerank.py:35-40): v half [N]; initial ranking (rerank.py:68-70): the columns that are ever read are
     # [0, max(k1+1, k2)) (:76, :83, :97).  Sharded rows: the two row-block tables (source minima, rank lists) travel in ONE collective
     K = min(max(k1 + 1, k2), N)
-    rowmin, rank = _gather_rows_packed([source_vector(src, tgt, row0, nrows, stats=stats), initial_rank(D, rowmax, N, nrows, K, rank_mode)], group, N)
     v = torch.empty(N, dtype=torch.float16, device=dev)
     vmax = status[0:1]
-    check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
+    # One GPU: the source term (two matrix-core passes, ~1.3 ms at the bench's shape) is needed by nothing before the eps rule, and
+    # the kernels between the initial ranking and the Jaccard rows (k-reciprocal sets, query expansion, inverted index: latency-bound,
+    # little LDS) leave the matrix pipes idle -- it runs on a second stream behind the initial ranking and is joined after the Jaccard
+    # rows (`join_source`).  Sharded rows keep the one-stream order: the source minima travel with the rank lists in one collective.
+    overlap = group is None and os.environ.get("SSG_RERANK_OVERLAP", "1") != "0"
+    join_source = None
+    if overlap:
+        rank = initial_rank(D, rowmax, N, nrows, K, rank_mode)
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            rowmin = source_vector(src, tgt, row0, nrows, stats=stats)
+
+        def join_source():
+            main.wait_stream(side)
+            rowmin.record_stream(main)
+            check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
+    else:
+        rowmin, rank = _gather_rows_packed([source_vector(src, tgt, row0, nrows, stats=stats), initial_rank(D, rowmax, N, nrows, K, rank_mode)], group, N)
+        check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
 
     # ---- k-reciprocal encoding (rerank.py:74-92)
     capV = int(L.ssg_krecip_row_capacity(k1))
@@ -363,7 +393,8 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
         nseg = int(L.ssg_jaccard_segments(N))
         s_cap = int(nrows) * int(min(N, int(os.environ.get("SSG_SPARSE_ROW_ENTRIES", "1024"))))
         vmin = torch.empty(1, dtype=torch.int32, device=dev)
-        check(L.ssg_half_min(ptr(v), N, ptr(vmin), st), "ssg_half_min")      # the row floors J'(0) + lambda * half(v_i + min v) of the sparse passes
+        if join_source is None:
+            check(L.ssg_half_min(ptr(v), N, ptr(vmin), st), "ssg_half_min")      # the row floors J'(0) + lambda * half(v_i + min v) of the sparse passes
         sparse = dict(pool=torch.empty(max(s_cap, 1), dtype=torch.int32, device=dev), cap=s_cap, cursor=torch.zeros(2, dtype=torch.int64, device=dev),
                       seg_off=torch.empty(nrows * nseg, dtype=torch.int64, device=dev), seg_len=torch.empty(nrows * nseg, dtype=torch.int32, device=dev),
                       nseg=nseg, jp0=int(om), vmin=vmin, rowmask=torch.empty(nrows, dtype=torch.uint8, device=dev))
@@ -423,6 +454,10 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     else:
         tail(max(int(v_nnz.max().item()), 1), None)  # exact bound: one blocking read (v_nnz is the gathered table: the same on every rank)
 
+    if join_source is not None:
+        join_source()
+        if sparse is not None:
+            check(L.ssg_half_min(ptr(v), N, ptr(sparse["vmin"]), st), "ssg_half_min")
     h = DistHandle(N, 0, Jp, v=v, lambda_value=lambda_value, euclid=D if keep_euclid else None, row0=row0, nrows=nrows, group=group)
     # the device-side status words (zero source vector -> the reference's NaN path; int8 digit overflow; a V row longer than the guess)
     # are read with the consumer's first host round trip (`validate`: eps_rule / DBSCAN / final_dist), not with one of their own
