@@ -17,8 +17,8 @@ if has prof2; then
   (cd $R; python tools/prof_summary.py $(find gpurun_out/r05z/prof2 -name "*results.db" | head -1) gpurun_out/r05z/kernel_stats_two_streams.md "rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras" "PRODUCT DEFAULT: the two forwards of a batch (original + flipped) run on two HIP streams, so the durations below OVERLAP -- their sum is about twice the wall time of the step and every convolution average is dilated by the kernel running beside it (about 1.6x).  Per-kernel fractions must be taken from the single-stream file next to this one (r05_bench_kernel_stats_single_stream.md) or from r05_layer_table.md.")
 fi
 if has prof1; then
-  SSG_FLIP_STREAMS=0 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof1 -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof_single_stream.json 2> $O/prof1_err.log
-  (cd $R; python tools/prof_summary.py $(find gpurun_out/r05z/prof1 -name "*results.db" | head -1) gpurun_out/r05z/kernel_stats_single_stream.md "SSG_FLIP_STREAMS=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras" "SINGLE STREAM (SSG_FLIP_STREAMS=0): every launch runs alone, durations do not overlap and sum to the step's GPU time; this is the file per-kernel averages and fractions are quoted from.  The product default (two streams, +2-3 % throughput) is profiled in r05_bench_kernel_stats_two_streams.md.")
+  SSG_RERANK_OVERLAP=0 SSG_FLIP_STREAMS=0 timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof1 -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_under_rocprof_single_stream.json 2> $O/prof1_err.log
+  (cd $R; python tools/prof_summary.py $(find gpurun_out/r05z/prof1 -name "*results.db" | head -1) gpurun_out/r05z/kernel_stats_single_stream.md "SSG_RERANK_OVERLAP=0 SSG_FLIP_STREAMS=0 rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras" "SINGLE STREAM (SSG_FLIP_STREAMS=0): every launch runs alone, durations do not overlap and sum to the step's GPU time; this is the file per-kernel averages and fractions are quoted from.  The product default (two streams, +2-3 % throughput) is profiled in r05_bench_kernel_stats_two_streams.md.")
 fi
 cd $R
 if has layer; then timeout 600 python tools/layer_table.py --reps 5 > $O/layer_table.md 2>&1; tail -2 $O/layer_table.md; fi
