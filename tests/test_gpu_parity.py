@@ -213,6 +213,31 @@ def test_query_expansion_guess_miss_is_redone(golden, dev, ora):
     assert np.array_equal(h4.final_dist().cpu().numpy(), g["final"])
 
 
+def test_rerank_second_stream_gives_the_one_stream_result(dev, monkeypatch):
+    """round 5: on one GPU the source term runs on a second HIP stream beside the k-reciprocal kernels and is joined after the Jaccard rows
+    (SSG_RERANK_OVERLAP, default on): J', the source vector, the sparse copy's floor word and the status words equal the one-stream
+    call's bit for bit, repeatedly (a missing join would show as a stale or racing source vector), also when the handle is consumed
+    right away by the fused eps rule + DBSCAN chain"""
+    from ssg_amd import rerank, cluster
+    tgt = hard_clustered(2500, 128, 41); src = hard_clustered(1100, 128, 42, intra=0.7)
+    s_d, t_d = torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev)
+    monkeypatch.setenv("SSG_RERANK_OVERLAP", "0")
+    h0 = rerank.re_ranking_device(s_d, t_d, lambda_value=0.3)
+    ref = (h0.M.cpu().numpy().copy(), h0.v.cpu().numpy().copy(), int(h0.sparse["vmin"].item()))
+    lab0 = cluster.eps_rule_dbscan(h0, 1.6e-3, min_samples=4)
+    monkeypatch.setenv("SSG_RERANK_OVERLAP", "1")
+    for _ in range(4):
+        junk = torch.randn(1 << 22, device=dev)           # (main-stream work in front: the second stream has to wait for it)
+        h1 = rerank.re_ranking_device(s_d, t_d, lambda_value=0.3, validate=False)      # (no read-back between the join and the chain)
+        floor1 = h1.sparse["vmin"]
+        lab1 = cluster.eps_rule_dbscan(h1, 1.6e-3, min_samples=4)
+        assert np.array_equal(bits(h1.v.cpu().numpy()), bits(ref[1]))
+        assert np.array_equal(bits(h1.M.cpu().numpy()), bits(ref[0]))
+        assert int(floor1.item()) == ref[2]
+        assert lab1[:3] == lab0[:3] and np.array_equal(lab1[3], lab0[3])
+        del junk
+
+
 def test_eps_rule_dbscan_chain_equals_the_two_calls(dev, monkeypatch):
     """round 5: cluster.eps_rule_dbscan (eps rule -> region query -> components on the device, ONE read-back) against eps_rule followed
     by DBSCAN.fit on the same handle: eps, count, top, labels, core samples -- re-rank handles with and without the sparse copy, the half
