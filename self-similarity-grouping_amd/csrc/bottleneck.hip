@@ -559,7 +559,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
       {   // even lane holds hi0..7 of the 8-channel group, odd lane lo0..7; each needs hi and lo of ITS four channels
         // (component-wise selects: a select between uint2 / float4 aggregates goes through scratch memory)
         const unsigned a0 = __float_as_uint(rw.x), a1 = __float_as_uint(rw.y), a2 = __float_as_uint(rw.z), a3 = __float_as_uint(rw.w);
-        const unsigned g0 = (unsigned)__shfl_xor((int)(odd ? a0 : a2), 1, 64), g1 = (unsigned)__shfl_xor((int)(odd ? a1 : a3), 1, 64);
+        const unsigned g0 = lane_xor1((odd ? a0 : a2)), g1 = lane_xor1((odd ? a1 : a3));
         const unsigned h0 = odd ? g0 : a0, h1 = odd ? g1 : a1, l0 = odd ? a2 : g0, l1 = odd ? a3 : g1;
         r4 = decode4(make_uint2(h0, h1), make_uint2(l0, l1));
       }
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
       uint2 hp, lp;
       encode4(v, hp, lp);
       ovf |= hi_nonfinite_bits(hp);
-      const unsigned rx = (unsigned)__shfl_xor((int)(odd ? hp.x : lp.x), 1, 64), ry = (unsigned)__shfl_xor((int)(odd ? hp.y : lp.y), 1, 64);
+      const unsigned rx = lane_xor1((odd ? hp.x : lp.x)), ry = lane_xor1((odd ? hp.y : lp.y));
       const uint4 stv = make_uint4(odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry);
 #ifdef SSG_BN_NT_STORE
       { const v4u sv_ = {stv.x, stv.y, stv.z, stv.w}; __builtin_nontemporal_store(sv_, reinterpret_cast<v4u*>(outp + (int64_t)pr * C + col)); }

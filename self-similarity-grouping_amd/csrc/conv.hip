@@ -445,7 +445,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
           if (p.res_split) {
             // even lane holds hi0..7 of the 8-channel group, odd lane lo0..7; each needs hi and lo of ITS four channels
             const unsigned s0 = odd ? __float_as_uint(r4.x) : __float_as_uint(r4.z), s1 = odd ? __float_as_uint(r4.y) : __float_as_uint(r4.w);
-            const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+            const unsigned g0 = lane_xor1(s0), g1 = lane_xor1(s1);
             r4 = odd ? split_decode4(make_uint2(g0, g1), make_uint2(__float_as_uint(r4.z), __float_as_uint(r4.w)))
                      : split_decode4(make_uint2(__float_as_uint(r4.x), __float_as_uint(r4.y)), make_uint2(g0, g1));
           }
@@ -457,7 +457,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
           split_encode4(v, hp, lp);
           if (p.overflow && split_hi_nonfinite(hp)) *p.overflow = 1;
           const uint2 send = odd ? hp : lp;
-          const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 1, 64), (unsigned)__shfl_xor((int)send.y, 1, 64));
+          const uint2 recv = make_uint2(lane_xor1(send.x), lane_xor1(send.y));
           const uint4 st = odd ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
           if (m < p.M) *reinterpret_cast<uint4*>(outp + (int64_t)m * p.Cout + col) = st;
         } else if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
@@ -545,10 +545,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
 // NS: LDS stages (NS - 1 k-tiles in flight).  The 1x1 convolutions that stream their pixel operand from HBM (K = 512 ... 2048) sat at
 // 0.4 of the matrix peak AND 0.4 of the HBM rate with two 32 KB tiles in flight per CU: bytes in flight / memory latency was the
 // bound (64 KB / ~3 us = 21 GB/s per CU).  The 256 x 256 kernel (one workgroup per CU, 96 of 160 KB of LDS) takes a fourth stage.
-template <int BN, bool ONEPROD = false, int BM = 128, bool DUAL = false, int NS = 3>
-__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 256 ? 4 : 3)) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
+// WM_ = 128 (256 x 256 tile only): 8 waves of 128 x 64 instead of 16 of 64 x 64 -- 12 fragment reads per 24 MFMAs instead of 8 per 12 (a
+// quarter fewer LDS bytes per MFMA), half the waves at every barrier, 2 waves per SIMD with up to 256 VGPRs each.  TWOSET: the fragments
+// of k-tile t + 1 are read into a second register set right after the barrier that publishes them, under the last MFMA group of tile t
+// (source_bound_dma_kernel's schedule).
+template <int BN, bool ONEPROD = false, int BM = 128, bool DUAL = false, int NS = 3, int WM_ = 64, bool TWOSET = false>
+__global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 256 ? 4 : 3)) void conv_dma_kernel(ConvParams p) {   // 4 (3) waves per SIMD: at most 128 (168) VGPRs
   static_assert(NS == 3 || NS == 4, "three or four stages");
-  constexpr int WM = 64, WN = 64, MT = 2, NT = 2, CBK = 16;
+  static_assert(WM_ == 64 || (WM_ == 128 && BM == 256 && BN == 256 && !ONEPROD && NS == 4), "128-row wave tiles: the 256 x 256 three-product kernel");
+  static_assert(!TWOSET || WM_ == 128, "second fragment set: 8-wave kernel only");
+  constexpr int WM = WM_, WN = 64, MT = WM / 32, NT = 2, CBK = 16;
   constexpr int WCOLS = BN / WN, NW = (BM / WM) * WCOLS;             // 8 waves (2 x 4) for 128 x 256, 4 waves (2 x 2) for 128 x 128, 16 (4 x 4) for 256 x 256
   constexpr int ABLK = BM / 16 / NW, WBLK = BN / 16 / NW;            // 16-row A / W blocks per wave and stage: 1 or 2
   constexpr int STAGE_BYTES = (BM + BN) * 64;                       // [A: BM rows x 64 B][W: BN rows x 64 B]
@@ -723,6 +729,51 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
   if (nk - nfull >= 1) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st0) }
   if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st1) }
   if constexpr (NS == 4) { if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_MMA(st2) } }
+  } else if constexpr (TWOSET) {
+    v8h fah[2][MT], fal[2][MT], fbh[2][NT], fbl[2][NT];     // [register set][tile]
+#define SSG_READS2(ST, S)                                                                                            \
+    { _Pragma("unroll") for (int i = 0; i < MT; i++) {                                                               \
+        fah[S][i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offh); fal[S][i] = *reinterpret_cast<const v8h*>(ST + arow + i * 2048 + offl); } \
+      _Pragma("unroll") for (int j = 0; j < NT; j++) {                                                               \
+        fbh[S][j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offh); fbl[S][j] = *reinterpret_cast<const v8h*>(ST + brow + j * 2048 + offl); } }
+#define SSG_GA(S) { _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[S][j], fal[S][i], acc[i][j], 0, 0, 0); }
+#define SSG_GB(S) { _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbl[S][j], fah[S][i], acc[i][j], 0, 0, 0); }
+#define SSG_GC(S) { _Pragma("unroll") for (int i = 0; i < MT; i++) _Pragma("unroll") for (int j = 0; j < NT; j++)   \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[S][j], fah[S][i], acc[i][j], 0, 0, 0); }
+    // k-tile t (fragments in set S): the first two MFMA groups, publish tile t + 1 (and: everybody is done reading this stage -- its
+    // fragment reads were waited for one step ago), refill this stage with tile t + NS, read tile t + 1's fragments into the other set,
+    // the third group
+#define SSG_STEP2(ST, STN, S)                                                                                        \
+    { SSG_GA(S) SSG_GB(S)                                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TDMA * (NS - 2)) : "memory");                  \
+      SSG_DMA_NEXT(ST)                                                                                               \
+      SSG_READS2(STN, 1 - (S))                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                             \
+      SSG_GC(S) }
+    SSG_DMA_NEXT(st0)
+    SSG_DMA_NEXT(st1)
+    SSG_DMA_NEXT(st2)
+    SSG_DMA_NEXT(st3)
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TDMA * (NS - 1)) : "memory");     // tile 0 landed for everybody
+    SSG_READS2(st0, 0)
+    for (int kt = 0; kt < nfull; kt += NS) {
+      SSG_STEP2(st0, st1, 0)
+      SSG_STEP2(st1, st2, 1)
+      SSG_STEP2(st2, st3, 0)
+      SSG_STEP2(st3, st0, 1)
+    }
+    // left-over tiles (nk % NS): set 0 holds the fragments of tile nfull (published by the last barrier of the loop, or by the one above)
+    if (nk - nfull >= 1) { SSG_GA(0) SSG_GB(0) SSG_GC(0) }
+    if (nk - nfull >= 2) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_READS2(st1, 0) SSG_GA(0) SSG_GB(0) SSG_GC(0) }
+    if (nk - nfull == 3) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); SSG_READS2(st2, 0) SSG_GA(0) SSG_GB(0) SSG_GC(0) }
+#undef SSG_STEP2
+#undef SSG_GA
+#undef SSG_GB
+#undef SSG_GC
+#undef SSG_READS2
   } else {
     v8h fah[MT], fal[MT], fbh[NT], fbl[NT];
 #define SSG_READS(ST)                                                                                                \
@@ -844,7 +895,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
           float4 r4 = rr[it];
           if (p.res_split) {
             const unsigned s0 = odd ? __float_as_uint(r4.x) : __float_as_uint(r4.z), s1 = odd ? __float_as_uint(r4.y) : __float_as_uint(r4.w);
-            const unsigned g0 = (unsigned)__shfl_xor((int)s0, 1, 64), g1 = (unsigned)__shfl_xor((int)s1, 1, 64);
+            const unsigned g0 = lane_xor1(s0), g1 = lane_xor1(s1);
             r4 = odd ? split_decode4(make_uint2(g0, g1), make_uint2(__float_as_uint(r4.z), __float_as_uint(r4.w)))
                      : split_decode4(make_uint2(__float_as_uint(r4.x), __float_as_uint(r4.y)), make_uint2(g0, g1));
           }
@@ -856,7 +907,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64, BM == 256 ? 1 : (BN == 
           split_encode4(v, hp, lp);
           if (p.overflow && split_hi_nonfinite(hp)) *p.overflow = 1;
           const uint2 send = odd ? hp : lp;
-          const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 1, 64), (unsigned)__shfl_xor((int)send.y, 1, 64));
+          const uint2 recv = make_uint2(lane_xor1(send.x), lane_xor1(send.y));
           const uint4 stv = odd ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
           if (m < p.M) *reinterpret_cast<uint4*>(outp + (int64_t)m * p.Cout + col) = stv;
         } else if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
@@ -1091,7 +1142,11 @@ static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
     if (tall > 0 && p.products == 3 && p.epi == 0 && (!p.res || tall_res) && !p.in2 && tiles_tall >= tall) {   // measured: -2.5 % (3x3) / -6 % (1x1) on layer3 shapes; with a residual epilogue +3 %
       static int tall_ns = -1;               // SSG_CONV_TALL_STAGES=3: the three-stage pipeline of round 2 (tuning knob)
       if (tall_ns < 0) { const char* e = getenv("SSG_CONV_TALL_STAGES"); tall_ns = e ? atoi(e) : 4; }
-      if (tall_ns == 4) hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false, 4>), dim3(tiles_tall), dim3(1024), 0, stream, p);
+      static int tall_wm = -1;               // SSG_CONV_TALL_WM=128: 8 waves of 128 x 64; =129: the same with a second fragment register set
+      if (tall_wm < 0) { const char* e = getenv("SSG_CONV_TALL_WM"); tall_wm = e ? atoi(e) : 64; }
+      if (tall_wm == 128) hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false, 4, 128, false>), dim3(tiles_tall), dim3(512), 0, stream, p);
+      else if (tall_wm == 129) hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false, 4, 128, true>), dim3(tiles_tall), dim3(512), 0, stream, p);
+      else if (tall_ns == 4) hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false, 4>), dim3(tiles_tall), dim3(1024), 0, stream, p);
       else hipLaunchKernelGGL((conv_dma_kernel<256, false, 256, false>), dim3(tiles_tall), dim3(1024), 0, stream, p);
       return ssg_check_hip(hipGetLastError(), "conv_dma_kernel<256x256>");
     }

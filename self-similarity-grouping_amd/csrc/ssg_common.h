@@ -66,6 +66,9 @@ __device__ __forceinline__ double final_dist_value(hbits jp, hbits vi, hbits vk,
 }
 
 // wave64 helpers
+// value of lane (l ^ 1): a DPP quad permutation [1,0,3,2] on the way into the VALU -- __shfl_xor(v, 1) compiles to ds_bpermute_b32,
+// an LDS-pipe round trip per dword (the split-half epilogues exchange four dwords per 16-byte store).  Every lane must be active.
+__device__ __forceinline__ unsigned lane_xor1(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ULL << lane_id()) - 1ULL; }
 
