@@ -232,6 +232,13 @@ def main():
                     help="embeddings of the timed grouping leg: 'hard' (tools/synth.hard_clustered: noise, border points, unequal identity "
                          "sizes) or 'separable' (SURVEY 8d: 16 per identity, trivially separable); the other one is timed once, untimed-region")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra measurements (f32 embed, stable rank mode, other track)")
+    ap.add_argument("--grouping", choices=("auto", "shard", "replicate"), default="auto",
+                    help="N > 1: form of the grouping leg -- 'shard' (row blocks + all-gathers), 'replicate' (every rank runs the whole leg, no "
+                         "collective) or 'auto' (ssg_amd.dist.choose_grouping: the form its time model predicts to be faster for this N and world size)")
+    ap.add_argument("--uniform", action="store_true",
+                    help="time the PRODUCT DEFAULT only: no per-launch HIP events anywhere in the timed region (every embedding batch on two streams, "
+                         "the re-rank's source term on its second stream on every step); the roofline objects of the line are then null -- a cross-check "
+                         "of `value` against the default run, whose timed steps alternate two instrumentation modes")
     args = ap.parse_args()
 
     import ssg_amd
@@ -263,7 +270,10 @@ def main():
     emb_np = {k: (g(args.Ns, 2048, 2, intra=0.7), g(args.N, 2048, 1)) for k, g in gens.items() if k == args.track_g or not args.no_extras}
     src_emb = torch.from_numpy(emb_np[args.track_g][0]).to(dev)
     tgt_emb = torch.from_numpy(emb_np[args.track_g][1]).to(dev)
-    row0, row1 = sdist.shard_bounds(args.N, rank, world)      # ragged row blocks (N need not divide by the number of GPUs)
+    # N > 1: the grouping leg runs in the form the product's compute_dist(..., group=, grouping='auto') would choose (VERDICT r5 #5a)
+    grouping_form = sdist.choose_grouping(args.N, world, args.grouping)
+    g_group = group if grouping_form == "shard" else None
+    row0, row1 = sdist.shard_bounds(args.N, rank, world) if g_group is not None else (0, args.N)      # ragged row blocks (N need not divide by the number of GPUs)
     nrows = row1 - row0
 
     class TimedLoader(evaluators.TensorBatchLoader):
@@ -305,7 +315,7 @@ def main():
         # alone -- the product default (the source term on a second stream beside the k-reciprocal kernels) is what the other steps time
         os.environ["SSG_RERANK_OVERLAP"] = "0" if (group_events and timer.on) else "1"
         h = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
-                                     row0=row0, nrows=nrows, group=group)
+                                     row0=row0, nrows=nrows, group=g_group)
         ev[2].record()
         # eps rule + DBSCAN as the product's generate_selflabel runs them at iteration 0 (selftraining.py:289-306): one device chain, one read
         eps, cnt, top, labels, _ = cluster.eps_rule_dbscan(h, args.rho, min_samples=4)
@@ -322,7 +332,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_barrier()
-    timer.on = os.environ.get("SSG_BENCH_NO_KERNEL_EVENTS", "0") != "1"   # dev switch: measure the cost of the per-launch events
+    timer.on = os.environ.get("SSG_BENCH_NO_KERNEL_EVENTS", "0") != "1" and not args.uniform   # (--uniform: no per-launch events at all)
     legs = []
     with_events = [si % 2 == 0 for si in range(args.steps)]        # steps 0, 2, 4, ..: grouping launches bracketed by events (roofline figures)
     t0 = time.perf_counter()
@@ -445,7 +455,7 @@ def main():
     # rank, at any world size (the sharded path adds its own blocking reads: sizes of the ragged candidate / edge blocks)
     with CollectiveCounter() as cc, SyncCounter() as sc:
         h_ = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
-                                      row0=row0, nrows=nrows, group=group)
+                                      row0=row0, nrows=nrows, group=g_group)
         n_rr = sc.n
         cluster.eps_rule_dbscan(h_, args.rho, min_samples=4)
         n_ed = sc.n - n_rr
@@ -491,8 +501,14 @@ def main():
         roof["peak_is"] = "fp16 dense MFMA peak %.1f / 3 products per fp32 multiply" % PEAK_FP16_MFMA_TF
         roof["executed_fp16_tflops"] = round(3.0 * conv_tf, 1)
         roof["vs_fp32_mfma_peak"] = round(conv_tf / PEAK_FP32_MFMA_TF, 3)
-    hbm, k5_k12 = grouping_roofline(tot, args.N, nrows, args.Ns, world, max(n_ev_steps, 1))
-    hbm_ms = k5_k12["kernel_ms"]
+    if args.uniform:
+        # no per-launch events were recorded: nothing to divide by -- the line carries the wall-clock figures only
+        note = "--uniform: the timed region ran the product default only (no per-launch HIP events); run without the switch for the roofline objects"
+        roof.update(achieved=None, frac=None, launches=0, avg_launch_ms=None, launches_by_abi={}, traffic=None, note=note)
+        hbm, k5_k12, hbm_ms = {"note": note}, {"note": note, "kernel_ms": None}, None
+    else:
+        hbm, k5_k12 = grouping_roofline(tot, args.N, nrows, args.Ns, world, max(n_ev_steps, 1))
+        hbm_ms = k5_k12["kernel_ms"]
     out = {
         "metric": "images/s embed + s/iter for NxN rerank+DBSCAN, N=16k, 1/2/4/8 GPU",
         "value": round(n_img / (ms_step * 1e-3), 2), "unit": "images/s (embedded + grouped per wall second, whole iteration)",
@@ -506,7 +522,15 @@ def main():
         "config": {"workload": "BASELINE configs[1]+[2]: N=%d target + Ns=%d source images -> ResNet-50 2048-d embed (orig+flip) -> "
                                "k-reciprocal re-rank (k1=20,k2=6,lambda=%.1f) -> eps rule (rho=%.1e) -> DBSCAN(min_samples=4), 1 feature split"
                                % (args.N, args.Ns, args.lambda_value, args.rho),
-                   "N": args.N, "Ns": args.Ns, "d": 2048, "embed_batch": args.batch, "parallelism": "images + NxN row blocks sharded over %d GPU(s)" % world,
+                   "N": args.N, "Ns": args.Ns, "d": 2048, "embed_batch": args.batch,
+                   "parallelism": ("images sharded over %d GPU(s); grouping leg: %s" % (world, "NxN row blocks sharded, small tables all-gathered" if g_group is not None
+                                   else ("the whole leg on every rank, no collective (dist.choose_grouping)" if world > 1 else "one GPU"))),
+                   "grouping_form": grouping_form,
+                   "timed_region": ("product default only (--uniform): no per-launch events" if args.uniform else
+                                    "the K timed steps ALTERNATE two instrumentation modes: even steps bracket every grouping launch with HIP events and keep the "
+                                    "re-rank on one stream, odd steps run the product default (source term on a second stream); in every step each 8th "
+                                    "embedding batch runs its two forwards on one stream with per-launch events, the others on two streams -- ms_per_step "
+                                    "is the blend (the modes differ by ~0.3 ms of ~1100); `--uniform` times the product default alone"),
                    "legs": "two synthetic tracks (SURVEY.md 8d): the embed leg embeds N(0,1) images; the grouping leg re-ranks resident clustered "
                            "embeddings of the same shape, NOT the embed leg's output (random-init features hit reid/rerank.py:40's NaN path); the "
                            "hand-off embed -> grouping is covered by tests/test_gpu_chain.py",
@@ -521,7 +545,7 @@ def main():
         "roofline_k5_k12": k5_k12,
     }
     out.update(extras)
-    if "rank_mode" in extras and "ssg_topk_rank_introsort" in tot:
+    if "rank_mode" in extras and "ssg_topk_rank_introsort" in tot and hbm_ms is not None:
         alt_ms = hbm_ms - tot["ssg_topk_rank_introsort"][1] / max(n_ev_steps, 1) + extras["rank_mode"]["stable_kernel_ms"]
         out["roofline_k5_k12"]["frac_with_stable_order"] = round(8.0 * nrows * args.N / (alt_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
     if not args.no_cpu_baseline and world == 1:

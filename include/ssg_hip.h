@@ -233,6 +233,12 @@ int ssg_region_query_s_dev(const void* M, const uint16_t* v, int N, int row0, in
                            const int64_t* seg_off, const int32_t* seg_len, int nseg, const uint64_t* s_cursor, const uint32_t* vmin,
                            uint16_t jp0_half, uint8_t* rowmask, int32_t* cnt, int32_t* edges, uint64_t cap_edges, uint64_t* cursor2,
                            ssg_stream_t stream);
+/* round 6 (sharded eps rule + DBSCAN as one device chain): nseg fixed-capacity segments of 8-byte items -- the all-gathered
+ * candidate-key or edge buffers of the ranks; segment s holds min(counts[s * count_stride], seg_cap) valid items at in + s * seg_stride -- are
+ * written to `out` back to back in segment order without the host seeing the counts.  total2[0] = items written, total2[1] = 1 when a
+ * segment's count exceeded seg_cap (its owner's buffer overflowed).  out holds nseg * seg_cap items. */
+int ssg_concat_segments_u64(const uint64_t* in, int nseg, uint64_t seg_cap, uint64_t seg_stride, const uint64_t* counts, int count_stride,
+                            uint64_t* out, uint64_t* total2, ssg_stream_t stream);
 size_t ssg_dbscan_cc_workspace_bytes(int N);
 /* cnt is the FULL [N] table, edges the concatenated edge list: labels[N] int64, -1 = noise */
 int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,

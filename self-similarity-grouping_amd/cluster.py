@@ -204,11 +204,13 @@ def eps_rule(X, rho):
     return eps, count, top
 
 
-_EPS_TREES = {}     # (top, device index) -> workspace with the pairwise-summation tables of `top` summands already uploaded (they depend on top only)
+# (top, device index, stream) -> workspace with the pairwise-summation tables of `top` summands already uploaded (they depend on top
+# only).  The workspace also holds the node values of a run: calls on two streams must not share it, hence the stream in the key.
+_EPS_TREES = {}
 
 
 def _eps_tree(L, top, dev, st):
-    key = (int(top), dev.index)
+    key = (int(top), dev.index, int(getattr(st, "value", 0) or 0))
     ws = _EPS_TREES.get(key)
     if ws is None:
         ws_bytes = int(L.ssg_eps_mean_workspace_bytes(top))
@@ -220,12 +222,139 @@ def _eps_tree(L, top, dev, st):
     return ws
 
 
+def _triangle_share(N, lo, hi):
+    """fraction of the strict upper triangle of an N x N matrix that lies in rows [lo, hi)"""
+    tot = N * (N - 1) // 2
+    part = sum(N - 1 - i for i in (lo, hi - 1)) * (hi - lo) // 2 if hi > lo else 0       # arithmetic series
+    return part / max(tot, 1)
+
+
+def _eps_rule_dbscan_sharded(L, h, rho, min_samples, two_calls):
+    """`eps_rule_dbscan` on row-sharded handles (round 6): the same device chain with TWO collectives and ONE blocking read per split
+    (the two-call form: five collectives -- two histogram all-reduces, the status table, the candidates, the edge table -- and four reads).
+
+      1. every rank samples ITS OWN rows and picks its own float32 threshold at the 1.3 * rho quantile (no histogram all-reduce: the
+         a-posteriori check below only needs every uncollected key to lie above the SMALLEST of the ranks' thresholds), compacts the
+         keys below it into a buffer of the capacity all ranks share;
+      2. collective 1: the fixed-capacity buffers + (count, zeros) + threshold of every rank in one flat all-gather; every rank
+         concatenates them on the device (`ssg_concat_segments_u64`: the counts never reach the host), sorts, sums numpy's pairwise tree
+         and runs `ssg_eps_check` against the minimum threshold -- identical inputs, identical eps on every rank;
+      3. region query of the local rows with eps read from device memory;
+      4. collective 2: edge count + neighbour counts + fixed-capacity edge list + the re-rank's status words of every rank; concatenated
+         on the device, components and labels on every rank (redundant: N-sized, ~20 us);
+      5. THE read: labels, neighbour counts, eps, check words, every rank's status words.
+    Any failed check is seen identically by every rank (all of them decide from the same gathered words) and the two-call form answers."""
+    import torch.distributed as dist
+    from .dist import gather_packed, shard_bounds
+    import os
+    g = h.group
+    world, rk = dist.get_world_size(g), dist.get_rank(g)
+    dev, st, N = h.device, stream(), h.N
+    upper_total = N * (N - 1) // 2
+    top_guess = int(np.round(rho * upper_total))
+    args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
+    stride = max(1, h.nrows // 192)
+    z = torch.zeros(2 * 4097 + 5 + 3 + 6 + 2 + 2 + 1 + 2 + 2 + 2 + 1, dtype=torch.int64, device=dev)
+    hist1, hist2 = z[:4097], z[4097:8194]
+    thr3, cursor, status6, ecur, eps2 = z[8194:8199], z[8199:8202], z[8202:8208], z[8208:8210], z[8210:8212].view(torch.float64)
+    sort_fail, ktot, gcur, etot, thrg = z[8212:8213], z[8213:8215], z[8215:8217], z[8217:8219], z[8219:8220]
+    # the LOCAL quantile is taken wider than the one-GPU chain's 1.3 * rho: a rank whose rows hold more small distances than the average
+    # (big identities) would otherwise cut below the global top-th key and fail the check -- 1.6 tolerates a 60 % denser block
+    qf = float(os.environ.get("SSG_EPS_SHARD_QUANTILE", "1.6"))
+    check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist1), st), "ssg_eps_sample_hist")
+    check(L.ssg_eps_select_threshold(ptr(hist1), qf * rho, ptr(thr3), st), "ssg_eps_select_threshold")
+    check(L.ssg_eps_sample_hist(*args, stride, ptr(thr3), ptr(hist2), st), "ssg_eps_sample_hist")
+    check(L.ssg_eps_refine_threshold(ptr(hist2), ptr(thr3), st), "ssg_eps_refine_threshold")
+    # one capacity for every rank (the buffers travel in a flat all-gather): twice the expected candidates of the rank with the largest
+    # part of the triangle (rank 0: 15/64 of it on 8 ranks, not 1/8) + a floor
+    share = max(_triangle_share(N, *shard_bounds(N, r, world)) for r in range(world))
+    n_cap = int(2 * qf * top_guess * share) + (1 << 16)
+    buf = torch.empty(n_cap, dtype=torch.int64, device=dev)
+    sp = getattr(h, "sparse", None) if h.mode == 0 else None
+    if sp is not None:
+        check(L.ssg_eps_compact_below_s(ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.lambda_value, ptr(thr3), ptr(buf), n_cap, ptr(cursor), ptr(sp["pool"]),
+                                        ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), st),
+              "ssg_eps_compact_below_s")
+    else:
+        check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
+    # ---- collective 1: candidates + (count, zeros, threshold) of every rank
+    g_head, g_buf = gather_packed([torch.cat([cursor[:2], thr3[:1]]), buf], g)          # [world, 3], [world, n_cap] (strided views of the receive buffer)
+    cap_all = world * n_cap
+    n_pow2 = max(2048, 1 << (cap_all - 1).bit_length())
+    allk = torch.empty(n_pow2, dtype=torch.int64, device=dev)
+    check(L.ssg_concat_segments_u64(ptr(g_buf), world, n_cap, g_buf.stride(0), ptr(g_head), g_head.stride(0), ptr(allk), ptr(ktot), st), "ssg_concat_segments_u64")
+    # the words the check reads: candidates (pushed past the capacity when a rank's buffer overflowed), zeros of the whole triangle,
+    # the smallest threshold (positive float32 bit patterns order like the integers)
+    gcur[0:1] = ktot[0:1] + ktot[1:2] * (1 << 62)
+    gcur[1:2] = g_head[:, 1].sum()
+    thrg[0:1] = g_head[:, 2].min()
+    tree = _eps_tree(L, top_guess, dev, st)
+    if os.environ.get("SSG_EPS_SORT", "sample") == "bitonic" or qf * top_guess > 4.0e5:
+        check(L.ssg_sort_u64_dev(ptr(allk), n_pow2, ptr(ktot), st), "ssg_sort_u64_dev")
+        sf = None
+    else:
+        sws_bytes = int(L.ssg_samplesort_u64_workspace_bytes(n_pow2))
+        sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
+        check(L.ssg_samplesort_u64_dev(ptr(allk), n_pow2, ptr(ktot), ptr(sws), sws_bytes, ptr(sort_fail), st), "ssg_samplesort_u64_dev")
+        sf = sort_fail
+    check(L.ssg_eps_mean_run(ptr(allk), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), st), "ssg_eps_mean_run")
+    check(L.ssg_eps_check(ptr(allk), ptr(gcur), ptr(thrg), rho, upper_total, top_guess, cap_all, ptr(eps2), ptr(status6), ptr(sf), st), "ssg_eps_check")
+    # ---- region query of the local rows with eps read from the device
+    mx_rows = -(-N // world)
+    cnt = torch.zeros(mx_rows, dtype=torch.int32, device=dev)                             # (padded to the longest block: one shape on every rank)
+    ecap = max(64 * mx_rows, 1 << 16)
+    edges = torch.empty((ecap, 2), dtype=torch.int32, device=dev)
+    if sp is not None:
+        check(L.ssg_region_query_s_dev(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.lambda_value, ptr(eps2), ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]),
+                                       sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(sp["rowmask"]), ptr(cnt), ptr(edges), ecap, ptr(ecur), st),
+              "ssg_region_query_s_dev")
+    else:
+        check(L.ssg_region_query_dev(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, ptr(eps2), ptr(cnt), ptr(edges), ecap, ptr(ecur), st),
+              "ssg_region_query_dev")
+    # ---- collective 2: edge count, neighbour counts, edge list and the re-rank's status words of every rank
+    pend = h.take_pending() if hasattr(h, "take_pending") else None
+    npend = int(pend.numel()) if pend is not None else 0
+    words = torch.cat([ecur[:1]] + ([pend.to(torch.int64)] if pend is not None else []))
+    g_words, g_cnt, g_edges = gather_packed([words, cnt, edges.view(torch.int64).view(-1)], g)    # [world, 1 + npend], [world, mx_rows], [world, ecap]
+    edges_all = torch.empty(world * ecap, dtype=torch.int64, device=dev)
+    check(L.ssg_concat_segments_u64(ptr(g_edges), world, ecap, g_edges.stride(0), ptr(g_words), g_words.stride(0), ptr(edges_all), ptr(etot), st),
+          "ssg_concat_segments_u64")
+    rows = [shard_bounds(N, r, world) for r in range(world)]
+    cnt_all = torch.cat([g_cnt[r, :hi - lo] for r, (lo, hi) in enumerate(rows)])
+    ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
+    ws_buf = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    labels = torch.empty(N, dtype=torch.int64, device=dev)
+    check(L.ssg_dbscan_cc_dev(ptr(cnt_all), ptr(edges_all), ptr(etot), world * ecap, N, int(min_samples), ptr(ws_buf), ws_bytes, ptr(labels), st), "ssg_dbscan_cc_dev")
+    host = torch.cat([etot, status6, eps2.view(torch.int64), g_words.reshape(-1), labels, cnt_all.to(torch.int64)]).cpu().numpy()   # THE read
+    e_over, ok, zeros, top = int(host[1]), int(host[2]), int(host[4]), int(host[5])
+    eps_f64, eps_hbits = float(host[8:9].view(np.float64)[0]), int(host[9:10].view(np.float64)[0]) if ok else 0
+    o = 10
+    table = host[o:o + world * (1 + npend)].reshape(world, 1 + npend)
+    o += world * (1 + npend)
+    if pend is not None:
+        vals = h.global_status(None, table=[[int(x) for x in r] for r in table], first=1)
+        if h.resolve_pending(vals):
+            return eps_rule_dbscan(h, rho, min_samples)      # the query expansion had run on too small a guess: the matrix was rebuilt (by every rank), run again (once)
+        h.validate()
+    if not ok:
+        return two_calls()                                    # zeros in the triangle, a full buffer, or a sample that missed: the two-call path decides (exactly)
+    count = upper_total - zeros
+    eps = np.uint16(eps_hbits).view(np.float16) if h.mode == 1 else eps_f64
+    if e_over:                                                # an edge list was too small on some rank: eps is known, the two-call region query sizes it exactly
+        est = DBSCAN(eps=eps, min_samples=min_samples, metric="precomputed").fit(h)
+        return eps, count, top, est.labels_, est.core_sample_indices_
+    lab = host[o:o + N].copy()
+    core = np.nonzero(host[o + N:o + 2 * N] >= int(min_samples))[0]
+    return eps, count, top, lab, core
+
+
 def eps_rule_dbscan(X, rho, min_samples=4):
     """selftraining.py:289-306 in ONE device-resident chain (round 5): eps rule -> region query -> connected components with eps, the
     candidate count and the edge count left on the device, and ONE blocking read at the end (labels, neighbour counts, eps, the check
     words and the re-rank's status words).  Returns (eps, count, top, labels, core_sample_indices) -- exactly what
     `eps_rule(X, rho)` followed by `DBSCAN(eps, min_samples, metric='precomputed').fit(X)` returns; that two-call form stays the
-    API (and the fallback of every case this chain does not cover: sharded rows, the radix-select path, a failed check).
+    API (and the fallback of every case this chain does not cover: the radix-select path, a failed check).  Sharded rows run the same
+    chain with two collectives (`_eps_rule_dbscan_sharded`).
 
     What the host decides BEFORE the data is seen, and the device verifies: the number of summands top = round(rho * count) assumes no
     zero entry in the strict upper triangle (count = N(N-1)/2; a zero -- duplicate images -- makes `ssg_eps_check` fail and the
@@ -245,9 +374,11 @@ def eps_rule_dbscan(X, rho, min_samples=4):
     N = h.N
     upper_total = N * (N - 1) // 2
     top_guess = int(np.round(rho * upper_total))
-    if (h.group is not None or os.environ.get("SSG_EPS_PATH", "sampled") != "sampled" or os.environ.get("SSG_EPS_FUSED", "1") == "0" or not rho > 0
+    if (os.environ.get("SSG_EPS_PATH", "sampled") != "sampled" or os.environ.get("SSG_EPS_FUSED", "1") == "0" or not rho > 0
             or N < 64 or top_guess <= 0):
         return two_calls()
+    if h.group is not None:
+        return _eps_rule_dbscan_sharded(L, h, rho, min_samples, two_calls)
     dev, st = h.device, stream()
     args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
     # ---- the sampled threshold and the one full pass, exactly as _eps_rule_sampled queues them

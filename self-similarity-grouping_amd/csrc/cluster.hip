@@ -1235,6 +1235,43 @@ extern "C" int ssg_fill_u64(uint64_t* buf, uint64_t n0, uint64_t n1, uint64_t va
   return SSG_OK;
 }
 
+// ---- round 6: fixed-capacity segments (the all-gathered candidate / edge buffers of the ranks) -> one list, counts left on the device ----
+// Segment s holds min(counts[s * count_stride], seg_cap) valid 8-byte items at in + s * seg_stride; they go to out back to back in segment
+// order.  total2[0] = the number written, total2[1] = 1 when a segment's count exceeded seg_cap (its owner's buffer overflowed: the caller's
+// check must fail).  One workgroup per (segment, 4096-item chunk); every workgroup re-derives its segment's base from the <= 64 counts.
+namespace ssg {
+__global__ __launch_bounds__(256) void concat_segments_kernel(const unsigned long long* __restrict__ in, int nseg, unsigned long long seg_cap,
+                                                              unsigned long long seg_stride, const unsigned long long* __restrict__ counts, int count_stride,
+                                                              unsigned long long* __restrict__ out, unsigned long long* __restrict__ total2, int chunks_per_seg) {
+  const int s = (int)blockIdx.x / chunks_per_seg, ch = (int)blockIdx.x % chunks_per_seg;
+  unsigned long long base = 0, mine = 0, over = 0, sum = 0;
+  for (int r = 0; r < nseg; r++) {
+    unsigned long long c = counts[(size_t)r * count_stride];
+    if (c > seg_cap) { c = seg_cap; over = 1; }
+    if (r < s) base += c;
+    if (r == s) mine = c;
+    sum += c;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { total2[0] = sum; total2[1] = over; }
+  const unsigned long long i0 = (unsigned long long)ch * 4096;
+  const unsigned long long* src = in + (size_t)s * seg_stride;
+#pragma unroll 4
+  for (unsigned long long i = i0 + threadIdx.x; i < i0 + 4096 && i < mine; i += 256) out[base + i] = src[i];
+}
+}  // namespace ssg
+extern "C" int ssg_concat_segments_u64(const uint64_t* in, int nseg, uint64_t seg_cap, uint64_t seg_stride, const uint64_t* counts, int count_stride,
+                                       uint64_t* out, uint64_t* total2, hipStream_t stream) {
+  if (!in || !counts || !out || !total2 || nseg <= 0 || nseg > 4096 || seg_stride < seg_cap || count_stride < 1) {
+    ssg_set_error("ssg_concat_segments_u64: bad arguments (nseg=%d)", nseg);
+    return SSG_ERR_INVALID;
+  }
+  const int cps = (int)((seg_cap + 4095) / 4096) > 0 ? (int)((seg_cap + 4095) / 4096) : 1;
+  hipLaunchKernelGGL(ssg::concat_segments_kernel, dim3((unsigned)(nseg * cps)), dim3(256), 0, stream, (const unsigned long long*)in, nseg, (unsigned long long)seg_cap,
+                     (unsigned long long)seg_stride, (const unsigned long long*)counts, count_stride, (unsigned long long*)out, (unsigned long long*)total2, cps);
+  SSG_LAUNCH_CHECK("concat_segments_kernel");
+  return SSG_OK;
+}
+
 // ---- round 5: the eps rule without a host round trip between its full pass and the mean -------------------------------------------
 // The number of collected keys stays on the device (cursor[0] of the compaction pass).  The sort network is LAUNCHED for the capacity
 // n_cap (a power of two) but every kernel works on n_eff = the power of two >= max(*n_dev, SORT_CH) only: merge levels k > n_eff and

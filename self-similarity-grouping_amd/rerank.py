@@ -32,6 +32,11 @@ class DistHandle:
     mode 1: no-rerank: the half euclidean matrix itself (rerank.py:65-66)
     mode 2: an arbitrary float64 matrix uploaded by the caller (sklearn drop-in case)
     Rows [row0, row0+nrows) of the N x N problem are held locally (row-block sharding).
+
+    Sharded handles (group is not None): `validate`, `final_dist`, `cluster.eps_rule`, `cluster.eps_rule_dbscan` and `DBSCAN.fit` are
+    COLLECTIVE calls -- the status words of every rank are gathered so that all ranks take the same decision -- and must be made by
+    every rank of the group, in the same order (a handle created with validate=False and materialised on one rank only would wait
+    for its peers forever).
     """
 
     def __init__(self, N, mode, M, v=None, lambda_value=0.0, euclid=None, row0=0, nrows=None, group=None):
@@ -99,7 +104,8 @@ class DistHandle:
             over, seen = (int(values[2]), int(values[3])) if len(values) >= 4 else (0, 0)
             self._pending = None
             if seen > 0 and self._k1 is not None:
-                _QE_GUESS[self._k1] = max(32, ((seen * 5 // 4) + 7) // 8 * 8)       # + 25 %: the LDS staging (and the occupancy) follows the guess
+                # (sharded rows: `seen` is the maximum over the ranks -- `global_status` -- so every rank stores the same guess)
+                _QE_GUESS[_qe_key(self._k1, self.group)] = max(32, ((seen * 5 // 4) + 7) // 8 * 8)       # + 25 %: the LDS staging (and the occupancy) follows the guess
             if over and self._redo is not None:
                 self._redo(seen)                     # (the sparse copy is rebuilt as well; its consumers gate on its device-side overflow word)
                 redone = True
@@ -354,110 +360,140 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     K = min(max(k1 + 1, k2), N)
     v = torch.empty(N, dtype=torch.float16, device=dev)
     vmax = status[0:1]
-    # One GPU: the source term (two matrix-core passes, ~1.3 ms at the bench's shape) is needed by nothing before the eps rule, and
-    # the kernels between the initial ranking and the Jaccard rows (k-reciprocal sets, query expansion, inverted index: latency-bound,
-    # little LDS) leave the matrix pipes idle -- it runs on a second stream behind the initial ranking and is joined after the Jaccard
-    # rows (`join_source`).  Sharded rows keep the one-stream order: the source minima travel with the rank lists in one collective.
-    overlap = group is None and os.environ.get("SSG_RERANK_OVERLAP", "1") != "0"
-    join_source = None
+    # The source term (two matrix-core passes, ~1.3 ms at the bench's shape) is needed by nothing before the eps rule, and the kernels
+    # between the initial ranking and the Jaccard rows (k-reciprocal sets, query expansion, inverted index: latency-bound, little LDS)
+    # leave the matrix pipes idle -- it runs on a second stream behind the initial ranking.  One GPU: joined after the Jaccard rows.
+    # Sharded rows (round 6): the block's minima travel with the LAST table gather in front of the Jaccard rows (V_qe, or V when k2 == 1)
+    # instead of with the rank lists -- the same number of collectives, and the source term overlaps the k-reciprocal kernels, the V gather
+    # and the query expansion.  SSG_RERANK_OVERLAP=0: everything on one stream, the minima with the rank lists (round 5's order).
+    overlap = os.environ.get("SSG_RERANK_OVERLAP", "1") != "0"
+    rank = initial_rank(D, rowmax, N, nrows, K, rank_mode)
+    main = side = None
+    src_state = {"rowmin": None, "joined": False, "gathered": group is None}
     if overlap:
-        rank = initial_rank(D, rowmax, N, nrows, K, rank_mode)
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            rowmin = source_vector(src, tgt, row0, nrows, stats=stats)
+            src_state["rowmin"] = source_vector(src, tgt, row0, nrows, stats=stats)
+    else:
+        src_state["rowmin"] = source_vector(src, tgt, row0, nrows, stats=stats)
 
-        def join_source():
+    def join_side():
+        """main waits for the source term (idempotent); its result becomes usable on main"""
+        if overlap and not src_state["joined"]:
             main.wait_stream(side)
-            rowmin.record_stream(main)
-            check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
-    else:
-        rowmin, rank = _gather_rows_packed([source_vector(src, tgt, row0, nrows, stats=stats), initial_rank(D, rowmax, N, nrows, K, rank_mode)], group, N)
-        check(L.ssg_source_vec_finish(ptr(rowmin), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
+            src_state["rowmin"].record_stream(main)
+        src_state["joined"] = True
 
-    # ---- k-reciprocal encoding (rerank.py:74-92)
-    capV = int(L.ssg_krecip_row_capacity(k1))
-    v_idx = torch.empty((nrows, capV), dtype=torch.int32, device=dev)
-    v_val = torch.empty((nrows, capV), dtype=torch.float16, device=dev)
-    v_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
-    check(L.ssg_krecip(ptr(D), ptr(rowmax), ptr(rank), N, row0, nrows, K, k1, capV, ptr(v_idx), ptr(v_val), ptr(v_nnz), st), "ssg_krecip")
-    v_idx, v_val, v_nnz = _gather_rows_packed([v_idx, v_val, v_nnz], group, N)       # (index / value / length rows: one collective)
-    om = L.ssg_double_to_half_bits(1.0 - float(lambda_value))
-    Jp = torch.empty((nrows, N), dtype=torch.float16, device=dev)
-    tables = {}
-    # sparse copy S of J' (the columns a row's Jaccard walk touches; everything else is the constant J'(0) = half(1 - lambda)): what the
-    # eps rule and the region query walk instead of the N x N matrix while their bound stays below J'(0)
-    sparse = None
-    # (never usable for lambda > 1 -- J' would be negative, bit 15 is the kernel's "touched" marker -- or with the first-generation Jaccard kernel)
-    if os.environ.get("SSG_SPARSE", "1") != "0" and not (om & 0x8000) and os.environ.get("SSG_JACCARD_GEN", "2") == "2":
-        nseg = int(L.ssg_jaccard_segments(N))
-        s_cap = int(nrows) * int(min(N, int(os.environ.get("SSG_SPARSE_ROW_ENTRIES", "1024"))))
-        vmin = torch.empty(1, dtype=torch.int32, device=dev)
-        if join_source is None:
-            check(L.ssg_half_min(ptr(v), N, ptr(vmin), st), "ssg_half_min")      # the row floors J'(0) + lambda * half(v_i + min v) of the sparse passes
-        sparse = dict(pool=torch.empty(max(s_cap, 1), dtype=torch.int32, device=dev), cap=s_cap, cursor=torch.zeros(2, dtype=torch.int64, device=dev),
-                      seg_off=torch.empty(nrows * nseg, dtype=torch.int64, device=dev), seg_len=torch.empty(nrows * nseg, dtype=torch.int32, device=dev),
-                      nseg=nseg, jp0=int(om), vmin=vmin, rowmask=torch.empty(nrows, dtype=torch.uint8, device=dev))
+    def finish_source():
+        join_side()
+        check(L.ssg_source_vec_finish(ptr(src_state["rowmin"]), N, ptr(v), ptr(vmax), st), "ssg_source_vec_finish")
 
-    def tail(mx, over):
-        """local query expansion -> inverted index -> Jaccard rows into Jp, with LDS / row capacities sized for V rows of at most `mx`
-        entries; `over` = the device words that report a longer row (None: mx is exact)"""
-        if k2 != 1:
-            kk = min(k2, N, K)
-            capQ = kk * mx
-            q_idx = torch.empty((nrows, capQ), dtype=torch.int32, device=dev)
-            q_val = torch.empty((nrows, capQ), dtype=torch.float16, device=dev)
-            q_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
-            check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, mx, ptr(q_idx), ptr(q_val),
-                                     ptr(q_nnz), ptr(over), st), "ssg_query_expand")
-            # sharded rows: the fixed-capacity rows travel as they are (k2 * longest V row entries of 6 bytes; trimming them to the longest
-            # V_qe row would cost an all-reduce and a blocking read per split for a few MB over xGMI)
-            q_idx, q_val, q_nnz = _gather_rows_packed([q_idx, q_val, q_nnz], group, N)
+    def gather_with_source(tables):
+        """the row-sharded `tables` in one collective -- together with the source minima of the block when they have not travelled yet"""
+        if src_state["gathered"]:
+            return _gather_rows_packed(tables, group, N)
+        join_side()
+        out = _gather_rows_packed([src_state["rowmin"]] + list(tables), group, N)
+        src_state["rowmin"], src_state["gathered"] = out[0], True
+        return out[1:]
+
+    try:
+        if group is not None:
+            if overlap:
+                rank, = _gather_rows_packed([rank], group, N)
+            else:
+                rank, = gather_with_source([rank])
+                finish_source()
+
+        # ---- k-reciprocal encoding (rerank.py:74-92)
+        capV = int(L.ssg_krecip_row_capacity(k1))
+        v_idx = torch.empty((nrows, capV), dtype=torch.int32, device=dev)
+        v_val = torch.empty((nrows, capV), dtype=torch.float16, device=dev)
+        v_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
+        check(L.ssg_krecip(ptr(D), ptr(rowmax), ptr(rank), N, row0, nrows, K, k1, capV, ptr(v_idx), ptr(v_val), ptr(v_nnz), st), "ssg_krecip")
+        if k2 == 1:
+            v_idx, v_val, v_nnz = gather_with_source([v_idx, v_val, v_nnz])           # (the last gather in front of the Jaccard rows)
         else:
-            capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
-        # ---- inverted index + Jaccard rows (rerank.py:101-122)
-        # the inverted lists hold at most one entry per stored V_qe entry: sized by that bound instead of reading sum(q_nnz) back
-        total = int(N) * int(capQ)
-        colcnt = torch.empty(N, dtype=torch.int32, device=dev)
-        colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
-        inv_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
-        inv_val = torch.empty(max(total, 1), dtype=torch.float16, device=dev)
-        check(L.ssg_invert_index(ptr(q_idx), ptr(q_val), ptr(q_nnz), N, N, capQ, ptr(colcnt), ptr(colptr), ptr(inv_row), ptr(inv_val), st),
-              "ssg_invert_index")
-        colmeta = torch.empty((2, nrows, capQ), dtype=torch.int32, device=dev)
-        if sparse is not None:
-            check(L.ssg_jaccard_rows2(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
-                                      om, ptr(Jp), ptr(sparse["pool"]), sparse["cap"], ptr(sparse["cursor"]), ptr(sparse["seg_off"]), ptr(sparse["seg_len"]), st),
-                  "ssg_jaccard_rows2")
+            v_idx, v_val, v_nnz = _gather_rows_packed([v_idx, v_val, v_nnz], group, N)       # (index / value / length rows: one collective)
+        om = L.ssg_double_to_half_bits(1.0 - float(lambda_value))
+        Jp = torch.empty((nrows, N), dtype=torch.float16, device=dev)
+        tables = {}
+        # sparse copy S of J' (the columns a row's Jaccard walk touches; everything else is the constant J'(0) = half(1 - lambda)): what the
+        # eps rule and the region query walk instead of the N x N matrix while their bound stays below J'(0)
+        sparse = None
+        # (never usable for lambda > 1 -- J' would be negative, bit 15 is the kernel's "touched" marker -- or with the first-generation Jaccard kernel)
+        if os.environ.get("SSG_SPARSE", "1") != "0" and not (om & 0x8000) and os.environ.get("SSG_JACCARD_GEN", "2") == "2":
+            nseg = int(L.ssg_jaccard_segments(N))
+            s_cap = int(nrows) * int(min(N, int(os.environ.get("SSG_SPARSE_ROW_ENTRIES", "1024"))))
+            sparse = dict(pool=torch.empty(max(s_cap, 1), dtype=torch.int32, device=dev), cap=s_cap, cursor=torch.zeros(2, dtype=torch.int64, device=dev),
+                          seg_off=torch.empty(nrows * nseg, dtype=torch.int64, device=dev), seg_len=torch.empty(nrows * nseg, dtype=torch.int32, device=dev),
+                          nseg=nseg, jp0=int(om), vmin=torch.empty(1, dtype=torch.int32, device=dev), rowmask=torch.empty(nrows, dtype=torch.uint8, device=dev))
+
+        def tail(mx, over):
+            """local query expansion -> inverted index -> Jaccard rows into Jp, with LDS / row capacities sized for V rows of at most `mx`
+            entries; `over` = the device words that report a longer row (None: mx is exact)"""
+            if k2 != 1:
+                kk = min(k2, N, K)
+                capQ = kk * mx
+                q_idx = torch.empty((nrows, capQ), dtype=torch.int32, device=dev)
+                q_val = torch.empty((nrows, capQ), dtype=torch.float16, device=dev)
+                q_nnz = torch.empty(nrows, dtype=torch.int32, device=dev)
+                check(L.ssg_query_expand(ptr(v_idx), ptr(v_val), ptr(v_nnz), ptr(rank), N, row0, nrows, K, k2, capV, capQ, mx, ptr(q_idx), ptr(q_val),
+                                         ptr(q_nnz), ptr(over), st), "ssg_query_expand")
+                # sharded rows: the fixed-capacity rows travel as they are (k2 * longest V row entries of 6 bytes; trimming them to the longest
+                # V_qe row would cost an all-reduce and a blocking read per split for a few MB over xGMI)
+                q_idx, q_val, q_nnz = gather_with_source([q_idx, q_val, q_nnz])
+            else:
+                capQ, q_idx, q_val, q_nnz = capV, v_idx, v_val, v_nnz
+            # ---- inverted index + Jaccard rows (rerank.py:101-122)
+            # the inverted lists hold at most one entry per stored V_qe entry: sized by that bound instead of reading sum(q_nnz) back
+            total = int(N) * int(capQ)
+            colcnt = torch.empty(N, dtype=torch.int32, device=dev)
+            colptr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+            inv_row = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+            inv_val = torch.empty(max(total, 1), dtype=torch.float16, device=dev)
+            check(L.ssg_invert_index(ptr(q_idx), ptr(q_val), ptr(q_nnz), N, N, capQ, ptr(colcnt), ptr(colptr), ptr(inv_row), ptr(inv_val), st),
+                  "ssg_invert_index")
+            colmeta = torch.empty((2, nrows, capQ), dtype=torch.int32, device=dev)
+            if sparse is not None:
+                check(L.ssg_jaccard_rows2(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
+                                          om, ptr(Jp), ptr(sparse["pool"]), sparse["cap"], ptr(sparse["cursor"]), ptr(sparse["seg_off"]), ptr(sparse["seg_len"]), st),
+                      "ssg_jaccard_rows2")
+            else:
+                check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
+                                         om, ptr(Jp), st), "ssg_jaccard_rows")
+            if stages is not None:
+                tables.update(q_idx=q_idx, q_val=q_val, q_nnz=q_nnz, colptr=colptr, inv_row=inv_row, inv_val=inv_val)
+
+        # ---- local query expansion (rerank.py:94-99) .. Jaccard rows.  The LDS staging and the row capacity of V_qe follow the longest V
+        # row.  Run on a GUESS (the longest row of the previous call + 25 %, 64 at first) and let the kernel report a longer row
+        # through the status words that the consumer reads anyway (`validate`); a miss redoes this tail with the exact bound (rare; the
+        # result is the same either way).
+        redo = None
+        if k2 == 1:
+            tail(capV, None)
+        elif os.environ.get("SSG_QE_GUESS", "1") != "0":
+            # (sharded rows as well since round 5: every rank runs on the same guess -- kept per group, `_qe_key` -- and the words that report
+            # a miss are combined over the ranks -- maximum -- when they are read, `DistHandle.global_status`, so that all ranks redo
+            # together; round 4 read the gathered v_nnz back here instead: one blocking read per split)
+            guess = min(capV, _QE_GUESS.get(_qe_key(k1, group), 64))
+            tail(guess, status[2:4])
+            # a miss redoes the tail sized by the longest row the kernel REPORTED (status[3]: exact over the rows it staged), not by the worst-case
+            # capacity capV = (k1+1)(round(k1/2)+2) -- that one passes the 160 KB of LDS from k1 ~ 35 on; 0 (no report) falls back to a read of v_nnz
+            redo = lambda seen=0: tail(max(int(seen), 1) if seen else max(int(v_nnz.max().item()), 1), None)      # noqa: E731  (keeps the small tables alive, not D)
         else:
-            check(L.ssg_jaccard_rows(ptr(q_idx), ptr(q_val), ptr(q_nnz), capQ, ptr(colptr), ptr(inv_row), ptr(inv_val), total, ptr(colmeta), N, row0, nrows,
-                                     om, ptr(Jp), st), "ssg_jaccard_rows")
-        if stages is not None:
-            tables.update(q_idx=q_idx, q_val=q_val, q_nnz=q_nnz, colptr=colptr, inv_row=inv_row, inv_val=inv_val)
+            tail(max(int(v_nnz.max().item()), 1), None)  # exact bound: one blocking read (v_nnz is the gathered table: the same on every rank)
 
-    # ---- local query expansion (rerank.py:94-99) .. Jaccard rows.  The LDS staging and the row capacity of V_qe follow the longest V
-    # row.  Run on a GUESS (the longest row of the previous call + 25 %, 64 at first) and let the kernel report a longer row
-    # through the status words that the consumer reads anyway (`validate`); a miss redoes this tail with the exact bound (rare; the
-    # result is the same either way).
-    redo = None
-    if k2 == 1:
-        tail(capV, None)
-    elif os.environ.get("SSG_QE_GUESS", "1") != "0":
-        # (sharded rows as well since round 5: every rank runs on the same guess, and the words that report a miss are combined over the
-        # ranks -- maximum -- when they are read, `DistHandle.global_status`, so that all ranks redo together; round 4 read the gathered
-        # v_nnz back here instead: one blocking read per split)
-        guess = min(capV, _QE_GUESS.get(k1, 64))
-        tail(guess, status[2:4])
-        # a miss redoes the tail sized by the longest row the kernel REPORTED (status[3]: exact over the rows it staged), not by the worst-case
-        # capacity capV = (k1+1)(round(k1/2)+2) -- that one passes the 160 KB of LDS from k1 ~ 35 on; 0 (no report) falls back to a read of v_nnz
-        redo = lambda seen=0: tail(max(int(seen), 1) if seen else max(int(v_nnz.max().item()), 1), None)      # noqa: E731  (keeps the small tables alive, not D)
-    else:
-        tail(max(int(v_nnz.max().item()), 1), None)  # exact bound: one blocking read (v_nnz is the gathered table: the same on every rank)
-
-    if join_source is not None:
-        join_source()
+        if not (group is not None and not overlap):
+            finish_source()                              # (one stream + sharded rows: v was finished with the rank lists)
         if sparse is not None:
-            check(L.ssg_half_min(ptr(v), N, ptr(sparse["vmin"]), st), "ssg_half_min")
+            check(L.ssg_half_min(ptr(v), N, ptr(sparse["vmin"]), st), "ssg_half_min")      # the row floors J'(0) + lambda * half(v_i + min v) of the sparse passes
+    finally:
+        # whatever happened above (e.g. the query expansion's LDS limit at a large k1): main never runs ahead of the side stream, so that
+        # the caller cannot free src / tgt while the source term still reads them (ADVICE r5)
+        if overlap and not src_state["joined"]:
+            main.wait_stream(side)
     h = DistHandle(N, 0, Jp, v=v, lambda_value=lambda_value, euclid=D if keep_euclid else None, row0=row0, nrows=nrows, group=group)
     # the device-side status words (zero source vector -> the reference's NaN path; int8 digit overflow; a V row longer than the guess)
     # are read with the consumer's first host round trip (`validate`: eps_rule / DBSCAN / final_dist), not with one of their own
@@ -472,7 +508,19 @@ def re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.2, no_rerank=False, 
     return h
 
 
-_QE_GUESS = {}      # k1 -> guessed longest V row for the next call (the longest row of the last call + 25 %, a multiple of 8)
+# (k1, members of the group or None) -> guessed longest V row for the next call (the longest row of the last call + 25 %, a multiple
+# of 8).  The guess sizes tables that travel through a flat all-gather, so every rank of a group must hold the SAME number: the sharded
+# entries are written only from status words combined over the ranks (`DistHandle.global_status`) and never shared with the entries of
+# one-GPU calls, whose `seen` is rank-local (a rank that had run an extra one-GPU re-rank would have sent tables of another
+# width into the gather).
+_QE_GUESS = {}
+
+
+def _qe_key(k1, group):
+    if group is None:
+        return (int(k1), None)
+    import torch.distributed as dist
+    return (int(k1), tuple(dist.get_process_group_ranks(group)))
 
 
 def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.2, MemorySave=False, Minibatch=2000, no_rerank=False,

@@ -20,23 +20,29 @@ def _dev():
     return torch.device("cuda", torch.cuda.current_device())
 
 
-def compute_dist(source_features, target_features, lambda_value, no_rerank, num_split=2, materialize=False, group=None):
+def compute_dist(source_features, target_features, lambda_value, no_rerank, num_split=2, materialize=False, group=None, grouping="auto"):
     """selftraining.py:255-277.  Features: torch tensors (CPU or CUDA) or numpy arrays,
     a list of S+1 per-split tensors or a single tensor.  Returns (euclidean_dist_list,
-    rerank_dist_list) with one entry per split."""
+    rerank_dist_list) with one entry per split.
+
+    group (torch.distributed) + grouping: 'shard' = every rank computes its `shard_bounds` row block and the small tables are
+    all-gathered; 'replicate' = every rank runs the whole problem on its own GPU with no collective at all (the features are
+    replicated on every rank anyway) -- identical handles, identical labels on every rank; 'auto' (default) = `dist.choose_grouping`:
+    the form its time model predicts to be faster for this N and world size (small problems replicate)."""
     euclidean_dist_list, rerank_dist_list = [], []
     if not isinstance(source_features, list):
         source_features, target_features = [source_features], [target_features]
     dev = _dev()
     for s, t in zip(source_features, target_features):
         s = torch.as_tensor(s).to(dev, torch.float32); t = torch.as_tensor(t).to(dev, torch.float32)
-        row0, nrows = 0, None
+        row0, nrows, grp = 0, None, None
         if group is not None:
             import torch.distributed as dist
-            from .dist import shard_bounds
-            row0, row1 = shard_bounds(t.shape[0], dist.get_rank(group), dist.get_world_size(group))   # ragged N allowed
-            nrows = row1 - row0
-        h = re_ranking_device(s, t, lambda_value=lambda_value, no_rerank=no_rerank, keep_euclid=no_rerank, row0=row0, nrows=nrows, group=group,
+            from .dist import choose_grouping, shard_bounds
+            if choose_grouping(t.shape[0], dist.get_world_size(group), grouping) == "shard":
+                row0, row1 = shard_bounds(t.shape[0], dist.get_rank(group), dist.get_world_size(group))   # ragged N allowed
+                nrows, grp = row1 - row0, group
+        h = re_ranking_device(s, t, lambda_value=lambda_value, no_rerank=no_rerank, keep_euclid=no_rerank, row0=row0, nrows=nrows, group=grp,
                               validate=materialize)     # fused path: the status words are read by generate_selflabel's first round trip
         if materialize:
             if no_rerank:

@@ -91,37 +91,55 @@ def test_shard_bounds_cover():
             assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
 
 
-def _gpu_worker(rank, world, port, q, N, Ns, d):
+def _gpu_worker(rank, world, port, q, N, Ns, d, grouping="shard"):
     import torch.distributed as dist
     from types import SimpleNamespace
     import ssg_amd  # noqa: F401
     from ssg_amd import compute_dist, generate_selflabel
     from ssg_amd import dist as sd
-    if N == 1533:
-        # round 5: the sharded path runs the query expansion on a guessed row capacity too.  Force a miss (4 entries): the words that
-        # report it are combined over the ranks when the eps rule reads them, every rank redoes the tail together (its collectives stay
-        # matched), and the result equals the unsharded one
-        from ssg_amd import rerank
-        rerank._QE_GUESS[20] = 4
+    # (N == 1533, below) round 5: the sharded path runs the query expansion on a guessed row capacity too.  Force a miss (4 entries): the
+    # words that report it are combined over the ranks when the eps rule reads them, every rank redoes the tail together (its collectives
+    # stay matched), and the result equals the unsharded one
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     g = dist.group.WORLD
+    if N == 1533:
+        from ssg_amd import rerank
+        rerank._QE_GUESS[rerank._qe_key(20, g)] = 4
+        # the guess of a group is kept apart from the one-GPU calls' (whose longest row is rank-local): a rank that
+        # has run a one-GPU re-rank of its own must still size the gathered tables like its peers
+        rerank._QE_GUESS[(20, None)] = 8 * (rank + 1)
     Ns, d = Ns, d
     nsplit = 3
     tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(nsplit)]
     srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(nsplit)]
     lo, hi = sd.shard_bounds(N, rank, world)
     out = {}
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import CollectiveCounter, SyncCounter
+    sd._flat_gather_supported(g)                 # (the one-off probe collective of the group, outside the count)
     for mode, no_rerank in ((("rerank", False), ("norerank", True)) if N < 10000 else (("rerank", False),)):
-        e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2, group=g)
-        args = SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3)
-        labels, clusters = generate_selflabel(e_list, r_list, 0, args, [])
+        with CollectiveCounter() as cc, SyncCounter() as sc:
+            e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2, group=g, grouping=grouping)
+            args = SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3)
+            labels, clusters = generate_selflabel(e_list, r_list, 0, args, [])
+        ncoll = sum(v for k, v in cc.calls.items() if k != "barrier")
+        if grouping == "replicate":
+            assert ncoll == 0, cc.calls
+        elif grouping == "shard" and mode == "rerank" and N in (1536, 1531, 30003):
+            # VERDICT r5 next #5c: <= 6 collectives (3 table gathers of the re-rank + 2 of the eps rule / DBSCAN chain) and <= 3 blocking reads
+            # per split when nothing has to be redone (N = 1533 forces a query-expansion miss and runs its tail twice)
+            assert ncoll <= 6 * nsplit and sc.n <= 3 * nsplit, (cc.calls, sc.n)
         hs = e_list if no_rerank else r_list
-        assert all(h.row0 == lo and h.nrows == hi - lo for h in hs)
+        if grouping == "shard":
+            assert all(h.row0 == lo and h.nrows == hi - lo and h.group is g for h in hs)
+        elif grouping == "replicate" or sd.choose_grouping(N, world) == "replicate":
+            assert all(h.row0 == 0 and h.nrows == N and h.group is None for h in hs)       # the whole problem on every rank, no collective
         import hashlib
         pack = (lambda m: hashlib.sha256(m.tobytes()).hexdigest()) if N > 10000 else (lambda m: m)
-        out[mode] = [(float(c.eps), l, pack(h.M.cpu().numpy().view(np.uint16))) for c, l, h in zip(clusters, labels, hs)]
+        out[mode] = [(float(c.eps), l, pack(h.M.cpu().numpy().view(np.uint16)[(lo - h.row0):(hi - h.row0)])) for c, l, h in zip(clusters, labels, hs)]
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -170,6 +188,62 @@ def test_sharded_pipeline_matches_unsharded(world, N):
                     assert m == hashlib.sha256(np.ascontiguousarray(m0[lo:hi]).tobytes()).hexdigest(), (mode, s, r)
                 else:
                     assert np.array_equal(m, m0[lo:hi]), (mode, s, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grouping", ["replicate", "auto"])
+def test_grouping_forms_give_the_sharded_labels(grouping):
+    """VERDICT r5 next #5a: compute_dist(..., group=, grouping=) -- 'replicate' (every rank runs the whole problem, no collective),
+    'shard' (row blocks + all-gathers) and 'auto' (dist.choose_grouping: N = 1536 on 2 ranks replicates) give the same eps, the
+    same labels and the same distance rows on every rank as the one-GPU run."""
+    from types import SimpleNamespace
+    from ssg_amd import compute_dist, generate_selflabel
+    from ssg_amd.dist import shard_bounds
+    world, N, Ns, d = 2, 1536, 640, 96
+    dev = torch.device("cuda", 0)
+    tgts = [torch.from_numpy(clustered(N, d, 5 + s)).to(dev) for s in range(3)]
+    srcs = [torch.from_numpy(clustered(Ns, d, 60 + s, intra=0.7)).to(dev) for s in range(3)]
+    ref = {}
+    for mode, no_rerank in (("rerank", False), ("norerank", True)):
+        e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2)
+        labels, clusters = generate_selflabel(e_list, r_list, 0, SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3), [])
+        hs = e_list if no_rerank else r_list
+        ref[mode] = [(float(c.eps), l, h.M.cpu().numpy().view(np.uint16)) for c, l, h in zip(clusters, labels, hs)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q, N, Ns, d, grouping)) for r in range(world)]
+    [p.start() for p in procs]
+    res = dict(q.get(timeout=900) for _ in range(world))
+    [p.join(120) for p in procs]
+    for mode in ref:
+        for s in range(3):
+            e0, l0, m0 = ref[mode][s]
+            for r in range(world):
+                e, l, m = res[r][mode][s]
+                lo, hi = shard_bounds(N, r, world)
+                assert e == e0 and np.array_equal(l, l0) and np.array_equal(m, m0[lo:hi]), (mode, s, r)
+
+
+def test_grouping_policy_model():
+    """dist.choose_grouping: a pure function of (N, world) -- every rank takes the same decision --, small problems replicate, large
+    ones shard, a problem that does not fit one GPU shards whatever was asked, the environment overrides 'auto' only."""
+    from ssg_amd import dist as sd
+    assert sd.choose_grouping(16000, 1) == "replicate"
+    assert sd.choose_grouping(2000, 8) == "replicate" and sd.choose_grouping(128000, 8) == "shard"
+    assert sd.choose_grouping(16000, 8, "replicate") == "replicate" and sd.choose_grouping(2000, 8, "shard") == "shard"
+    assert sd.choose_grouping(400000, 8, "replicate") == "shard"           # 5 N^2 bytes > 0.8 x 288 GB
+    forms = [sd.choose_grouping(n, 8) for n in range(1000, 40000, 1000)]
+    assert forms == sorted(forms)                                         # one crossover: 'replicate' ... then 'shard' ...
+    t_rep, t_shard = sd.grouping_time_model(16000, 8)
+    assert 4e-3 < t_rep < 8e-3 and t_shard < t_rep                        # the measured one-GPU leg is ~5.5 ms at N = 16 000
+    os.environ["SSG_GROUPING"] = "replicate"
+    try:
+        assert sd.choose_grouping(128000, 8) == "replicate" and sd.choose_grouping(128000, 8, "shard") == "shard"
+    finally:
+        del os.environ["SSG_GROUPING"]
+    with pytest.raises(ValueError):
+        sd.choose_grouping(1000, 2, "both")
 
 
 # ------------------------------------------------------------------ sharded feature extraction (SURVEY.md 8e-1/2: images split by rank + C1 all-gather)
@@ -329,7 +403,7 @@ def _nccl_world1_worker(port, q):
     for mode, no_rerank in (("rerank", False), ("norerank", True)):
         res = []
         for grp in (g, None):
-            e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2, group=grp)
+            e_list, r_list = compute_dist(srcs, tgts, lambda_value=0.1, no_rerank=no_rerank, num_split=2, group=grp, grouping="shard")
             labels, clusters = generate_selflabel(e_list, r_list, 0, SimpleNamespace(no_rerank=no_rerank, rho=1.6e-3), [])
             hs = e_list if no_rerank else r_list
             res.append([(float(c.eps), l, h.M.cpu().numpy().view(np.uint16)) for c, l, h in zip(clusters, labels, hs)])

@@ -184,7 +184,7 @@ def test_query_expansion_guess_miss_is_redone(golden, dev, ora):
     src, tgt = torch.from_numpy(g["src"]).to(dev), torch.from_numpy(g["tgt"]).to(dev)
     old = dict(rerank._QE_GUESS)
     try:
-        rerank._QE_GUESS[20] = 4
+        rerank._QE_GUESS[(20, None)] = 4
         h = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.3, validate=False)
         assert h._pending is not None and h._redo is not None
         stale = h.M.clone()
@@ -193,9 +193,9 @@ def test_query_expansion_guess_miss_is_redone(golden, dev, ora):
         assert (eps, cnt, top) == (float(g["eps"]), int(g["count"]), int(g["top_num"]))
         assert np.array_equal(h.final_dist().cpu().numpy(), g["final"])
         assert np.array_equal(cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed").fit_predict(h), g["labels"])
-        assert rerank._QE_GUESS[20] >= 32
+        assert rerank._QE_GUESS[(20, None)] >= 32
         # the same miss caught by validate() (DBSCAN / final_dist as the first consumer)
-        rerank._QE_GUESS[20] = 4
+        rerank._QE_GUESS[(20, None)] = 4
         h2 = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.3, validate=False)
         assert np.array_equal(h2.final_dist().cpu().numpy(), g["final"])
         # a sufficient guess: nothing is redone
@@ -280,7 +280,7 @@ def test_eps_rule_dbscan_chain_equals_the_two_calls(dev, monkeypatch):
     # the chain as the FIRST consumer of a handle whose query expansion ran on too small a guess
     old = dict(rerank._QE_GUESS)
     try:
-        rerank._QE_GUESS[20] = 4
+        rerank._QE_GUESS[(20, None)] = 4
         hm = rerank.re_ranking_device(s_d, t_d, lambda_value=0.3, validate=False)
         assert hm._pending is not None
         gm = cluster.eps_rule_dbscan(hm, rho)
