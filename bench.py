@@ -62,7 +62,7 @@ def embed_fingerprint():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_pmc_conv_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r06_pmc_conv_traffic.json")
 
 
 def pmc_traffic(path, build, batch, launches_per_forward):
@@ -434,6 +434,15 @@ def main():
             lab_l, _ = selftraining.generate_selflabel(e_l, r_l, 0, ns_args, [])
         c5 = time.perf_counter()
         del e_l, r_l
+        # (first call: the destination pages are page-locked -- hostio.py's pool -- ; a loop that drops the previous iteration's matrices
+        # re-uses them: the second call is the steady state of selftraining.py's loop)
+        with quiet:
+            eu_np, fin_np = rerank.re_ranking(emb_np[args.track_g][0], emb_np[args.track_g][1], k1=20, k2=6, lambda_value=args.lambda_value)
+        t_rr_first = time.perf_counter() - c5
+        del eu_np, fin_np
+        import gc
+        gc.collect()
+        c5b = time.perf_counter()
         with quiet:
             eu_np, fin_np = rerank.re_ranking(emb_np[args.track_g][0], emb_np[args.track_g][1], k1=20, k2=6, lambda_value=args.lambda_value)
         c6 = time.perf_counter()
@@ -445,7 +454,11 @@ def main():
             "extract_features_dicts_s": round(c1 - c0, 4), "extract_images": args.N + args.Ns,
             "stack_loop_selftraining_197_209_s": round(c2 - c1, 4),
             "compute_dist_from_cpu_tensors_s": round(c4 - c3, 5), "generate_selflabel_s": round(c5 - c4, 5),
-            "re_ranking_numpy_return_s": round(c6 - c5, 4), "re_ranking_numpy_return_bytes": int(eu_np.nbytes + fin_np.nbytes),
+            "re_ranking_numpy_return_s": round(c6 - c5b, 4), "re_ranking_numpy_return_first_call_s": round(t_rr_first, 4),
+            "re_ranking_numpy_return_bytes": int(eu_np.nbytes + fin_np.nbytes),
+            "re_ranking_numpy_return_GBps": round((eu_np.nbytes + fin_np.nbytes) / max(c6 - c5b - t_rerank * 1e-3, 1e-9) / 1e9, 1),
+            "re_ranking_numpy_return_what": "re_ranking() end to end incl. the H2D of the features and the device pipeline; _s = second call of the size (page-locked "
+                                            "destination re-used from hostio's pool: the steady state of a self-training loop), first_call_s = incl. page-locking 2.56 GB",
             "generate_selflabel_on_numpy_final_dist_s": round(c7 - c6, 5),
             "labels_equal_fused": bool(np.array_equal(lab_l[0], labels)) and bool(np.array_equal(lab_n[0], labels)),
             "fused_path_for_comparison_s": {"embed": round(t_embed * 1e-3, 4), "rerank_eps_dbscan": round((t_rerank + t_cluster) * 1e-3, 5)}}

@@ -108,6 +108,10 @@ int ssg_topk_rank(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, i
  * global-arena variant for any N (parity tests).  ws == NULL / fewer bytes than the hand-over records (the pre-round-3 calling
  * convention for LDS-resident rows) is accepted: the replay then runs unsplit in one launch (slower); only the arena is mandatory. */
 size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows);
+/* round 6 (test / diagnostic surface): byte offset, inside a workspace of ssg_topk_rank_introsort_arena_bytes(N, nrows) bytes, of the per-row
+ * int32 flags of the streamed replay (1 = the row was handed to the in-place kernel: a pivot landed inside [0, K)); (size_t)-1 when the
+ * streamed kernel does not run for this N.  Valid after the call that used the workspace. */
+size_t ssg_topk_rank_introsort_flags_offset(int N, int nrows);
 size_t ssg_topk_rank_introsort_arena_bytes(int N, int nrows);
 int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws, size_t ws_bytes,
                             ssg_stream_t stream);

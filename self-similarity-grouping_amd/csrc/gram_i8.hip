@@ -360,7 +360,7 @@ __device__ __forceinline__ void gi_dma3(__amdgpu_buffer_rsrc_t rs, unsigned char
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, SSG_GI_LDSP(l2), 16, g2, 0, 0, 0);
 }
 template <int NL, int NS>
-__global__ __launch_bounds__(256, 4) void gram_i8_dma_kernel(const int8_t* __restrict__ E, unsigned e_bytes, const long long* __restrict__ nA, const long long* __restrict__ nB,
+__global__ __launch_bounds__(256, NS == 3 ? 4 : 3) void gram_i8_dma_kernel(const int8_t* __restrict__ E, unsigned e_bytes, const long long* __restrict__ nA, const long long* __restrict__ nB,
                                                              int M, int N, int nkb, int rowA0, hbits* __restrict__ D, unsigned* __restrict__ rowmax, int symmetric,
                                                              const int* __restrict__ flag, int sb) {
   if (*flag) return;
@@ -382,24 +382,16 @@ __global__ __launch_bounds__(256, 4) void gram_i8_dma_kernel(const int8_t* __res
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, h = lane >> 5;
   // ---- DMA addressing: instruction q = wave * TDMA + j of a stage fills operand q / (2 NL), plane (q % (2 NL)) / 2, rows 32 (q & 1) + lane / 2
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(E), 0, e_bytes, 0x00020000);
+  // planar layout: [panel][k block][digit][row % 64][32].  A lane's LDS slot is row = 32 (q & 1) + lane / 2 of the plane, 16-byte half
+  // `slot`; rows are clamped PER LANE (grow), so a slot may hold another global row's bytes for rows beyond the matrix (their outputs
+  // are never stored) -- the swap bit of the half follows the LDS row, not the global row
   unsigned goff[TDMA]; int loff[TDMA];
 #pragma unroll
   for (int j = 0; j < TDMA; j++) {
     const int q = wave * TDMA + j, op = q / (2 * NL), pl = (q % (2 * NL)) >> 1, row = 32 * (q & 1) + (lane >> 1), slot = lane & 1;
     const int grow = op ? min(tn * GI_T + row, N - 1) : rowA0 + min(tm * GI_T + row, M - 1);
-    const int prow = grow % GI_T;
-    // planar layout: [panel][k block][digit][row % 64][32]; the lane fetches the half that belongs in its (swapped) slot
-    goff[j] = (unsigned)(((int64_t)(grow / GI_T) * nkb * NL + pl) * PLANE + prow * 32 + ((slot ^ ((prow >> 3) & 1)) * 16));
-    loff[j] = op * (NL * PLANE) + pl * PLANE + (q & 1) * 1024;           // (+ 16 * lane: implicit in the DMA)
-  }
-  // NOTE: rows of the tile are clamped PER LANE above (grow), so a lane's LDS slot (row = 32 (q & 1) + lane / 2) may hold another global
-  // row's bytes only for rows beyond the matrix, whose outputs are never stored; the swap bit must then follow the LDS row, not the global
-  // row: recompute it from the LDS row for those lanes
-#pragma unroll
-  for (int j = 0; j < TDMA; j++) {
-    const int q = wave * TDMA + j, op = q / (2 * NL), pl = (q % (2 * NL)) >> 1, row = 32 * (q & 1) + (lane >> 1), slot = lane & 1;
-    const int grow = op ? min(tn * GI_T + row, N - 1) : rowA0 + min(tm * GI_T + row, M - 1);
     goff[j] = (unsigned)(((int64_t)(grow / GI_T) * nkb * NL + pl) * PLANE + (grow % GI_T) * 32 + ((slot ^ ((row >> 3) & 1)) * 16));
+    loff[j] = op * (NL * PLANE) + pl * PLANE + (q & 1) * 1024;           // (+ 16 * lane: implicit in the DMA)
   }
   const unsigned kstep = (unsigned)(NL * PLANE);                          // bytes from k block kb to kb + 1 inside a panel
   int dn = 0;
@@ -458,11 +450,13 @@ __global__ __launch_bounds__(256, 4) void gram_i8_dma_kernel(const int8_t* __res
 using namespace ssg;
 
 // which kernel (and therefore which digit layout) a problem gets: the LDS-DMA kernel for 3 digits when the encoded table fits one buffer
-// resource; SSG_I8_DMA=0: the register-staged kernel of rounds 1-4.  Read per call: the encoder and the multiply must agree.
+// resource; SSG_I8_DMA=0: the register-staged kernel of rounds 1-4.  The switch is read ONCE per process: the encoder and the multiply
+// are two calls and must agree on the layout (a change of the variable between them silently mismatched the two).
 static bool gi_use_dma(int n, int d, int ndigits) {
-  const char* e_ = getenv("SSG_I8_DMA");
+  static int env_on = -1;
+  if (env_on < 0) { const char* e_ = getenv("SSG_I8_DMA"); env_on = (e_ ? atoi(e_) : 1) != 0 ? 1 : 0; }
   const size_t bytes = (size_t)((n + GI_T - 1) / GI_T * GI_T) * (size_t)((d + 31) / 32) * 32 * (size_t)ndigits;
-  return (e_ ? atoi(e_) : 1) != 0 && ndigits == 3 && bytes < 0xfffffff0ull && (d + 31) / 32 >= 4;
+  return env_on != 0 && ndigits == 3 && bytes < 0xfffffff0ull && (d + 31) / 32 >= 4;
 }
 
 extern "C" size_t ssg_gram_i8_encoded_bytes(int n, int d, int ndigits) {       // whole 64-row panels

@@ -1234,6 +1234,14 @@ extern "C" size_t ssg_topk_rank_introsort_ws_bytes(int N, int nrows) {
   return intro::use_stream(N) ? ssg_topk_rank_introsort_arena_bytes(N, nrows) : intro::tail_bytes(nrows);
 }
 
+// byte offset, inside a workspace of ssg_topk_rank_introsort_arena_bytes(N, nrows) bytes, of the per-row int32 flags the streamed kernel
+// sets for the rows it hands to the in-place kernel (a pivot inside [0, K)); (size_t)-1 when the streamed kernel is not used for this N.
+// Test / diagnostic surface: the flagged rows are the rare path of the streamed replay and get their own check against np.argsort.
+extern "C" size_t ssg_topk_rank_introsort_flags_offset(int N, int nrows) {
+  if (N <= 0 || nrows <= 0 || !intro::stream_enabled(N)) return (size_t)-1;
+  return ssg_topk_rank_introsort_arena_bytes(N, nrows) - (size_t)nrows * sizeof(int);
+}
+
 extern "C" int ssg_topk_rank_introsort(const uint16_t* D, const uint32_t* rowmax, int N, int nrows, int K, int32_t* rank, void* ws,
                                        size_t ws_bytes, hipStream_t stream) {
   if (N < 2 || nrows <= 0 || K <= 0 || K > 64 || K > N || N > (1 << intro::IDX_BITS)) {

@@ -295,9 +295,11 @@ def default_rank_mode():
     return mode
 
 
-def initial_rank(D, rowmax, N, nrows, K, rank_mode=None, force_arena=False):
+def initial_rank(D, rowmax, N, nrows, K, rank_mode=None, force_arena=False, diag=None):
     """rerank.py:68-70 for a row block: int32 [nrows, K] = argsort(half(D / rowmax))[:, :K] in the requested tie order.
-    force_arena (tests): run the introsort kernel from its global-memory arena even when a row fits in LDS."""
+    force_arena (tests): run the introsort kernel from its global-memory arena even when a row fits in LDS.
+    diag (tests): a dict that receives 'flagged' = int32 [nrows] device tensor, 1 for the rows the streamed replay handed to the
+    in-place kernel (None when the streamed kernel did not run)."""
     L = _lib.lib()
     rank_mode = default_rank_mode() if rank_mode is None else rank_mode
     rank_blk = torch.empty((nrows, K), dtype=torch.int32, device=D.device)
@@ -307,6 +309,10 @@ def initial_rank(D, rowmax, N, nrows, K, rank_mode=None, force_arena=False):
         nws = int(L.ssg_topk_rank_introsort_arena_bytes(N, nrows) if force_arena else L.ssg_topk_rank_introsort_ws_bytes(N, nrows))
         ws = torch.empty(max(nws, 1), dtype=torch.uint8, device=D.device)
         check(L.ssg_topk_rank_introsort(ptr(D), ptr(rowmax), N, nrows, K, ptr(rank_blk), ptr(ws), nws, stream()), "ssg_topk_rank_introsort")
+        if diag is not None:
+            off = int(L.ssg_topk_rank_introsort_flags_offset(N, nrows))
+            full = int(L.ssg_topk_rank_introsort_arena_bytes(N, nrows))
+            diag["flagged"] = ws[off:off + 4 * nrows].view(torch.int32).clone() if (off != 2 ** 64 - 1 and nws >= full) else None
     else:
         raise ValueError("rank_mode must be one of %r" % (RANK_MODES,))
     return rank_blk
@@ -542,11 +548,15 @@ def re_ranking(input_feature_source, input_feature, k1=20, k2=6, lambda_value=0.
         print('starting re_ranking...')
     h = re_ranking_device(src, tgt, k1=k1, k2=k2, lambda_value=lambda_value, no_rerank=no_rerank, rank_mode=rank_mode,
                           memory_save=MemorySave)
-    euclid = h.euclid.cpu().numpy()
+    # the literal numpy return (rerank.py:127: 2 N^2 + 8 N^2 bytes) at PCIe speed: page-locked destinations from a pool, the float64
+    # matrix produced chunk by chunk while the previous chunk travels (hostio.py); the arrays own their memory like the reference's
+    from . import hostio
     if no_rerank:
-        return euclid, None
-    final = DeviceBackedArray.attach(h.final_dist().cpu().numpy(), h)
-    return euclid, final
+        return hostio.to_host(h.euclid).numpy(), None
+    h.validate()
+    euclid = hostio.to_host(h.euclid, wait=False)
+    final = DeviceBackedArray.attach(hostio.final_dist_to_host(h).numpy(), h)      # (waits for the copy stream: both copies have landed)
+    return euclid.numpy(), final
 
 
 def _init_pipeline(D, nq, k1, k2, lambda_value):

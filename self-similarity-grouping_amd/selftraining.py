@@ -45,10 +45,11 @@ def compute_dist(source_features, target_features, lambda_value, no_rerank, num_
         h = re_ranking_device(s, t, lambda_value=lambda_value, no_rerank=no_rerank, keep_euclid=no_rerank, row0=row0, nrows=nrows, group=grp,
                               validate=materialize)     # fused path: the status words are read by generate_selflabel's first round trip
         if materialize:
+            from . import hostio
             if no_rerank:
-                euclidean_dist_list.append(h.euclid.cpu().numpy()); rerank_dist_list.append(None)
+                euclidean_dist_list.append(hostio.to_host(h.euclid).numpy()); rerank_dist_list.append(None)
             else:
-                f = DeviceBackedArray.attach(h.final_dist().cpu().numpy(), h)
+                f = DeviceBackedArray.attach(hostio.final_dist_to_host(h).numpy(), h)
                 euclidean_dist_list.append([]); rerank_dist_list.append(f)
         else:
             euclidean_dist_list.append(h if no_rerank else [])

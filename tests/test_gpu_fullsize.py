@@ -131,6 +131,14 @@ def test_headline_size_labels_vs_oracle(kind, dev, ora):
     lab = cluster.DBSCAN(eps=eps, min_samples=4, metric="precomputed", n_jobs=8).fit_predict(h)
     olab = ora.dbscan(of, oeps, 4)
     assert np.array_equal(lab, olab), "DBSCAN labels"
+    # the device chain the product's generate_selflabel (and the bench) runs -- eps rule -> region query -> components with ONE read-back --
+    # against the ORACLE at the headline size (its sample sort works at the upper end of its window here)
+    h2 = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), k1=20, k2=6, lambda_value=0.3, validate=False)
+    e2, c2, t2, l2, core2 = cluster.eps_rule_dbscan(h2, 1.6e-3, min_samples=4)
+    assert (e2, c2, t2) == (oeps, ocnt, otop), "fused chain: eps rule vs the oracle"
+    assert np.array_equal(l2, olab), "fused chain: labels vs the oracle"
+    assert np.array_equal(core2, np.nonzero((of <= oeps).sum(axis=1) >= 4)[0]), "fused chain: core samples vs the oracle"
+    del h2
     deg = int((of <= eps).sum())
     print("N=%d %s: oracle re_ranking %.1f s on %d threads; eps %.6f, %d clusters, %d noise, %d region-query hits (%.1f per row)" % (
         N, kind, t_ora, nthr, eps, lab.max() + 1, int((lab < 0).sum()), deg, deg / N))
@@ -183,6 +191,12 @@ def test_config3_three_splits_properties(dev):
         assert bool((Jp >= 0).all()) and bool((Jp.float() <= 1.0).all())
         lab = labels[s]
         assert lab.shape == (N,) and lab.min() >= -1 and 0 < clusters[s].eps < 1.5
+        # the chain's eps (generate_selflabel ran cluster.eps_rule_dbscan: bitonic sort at this size) against the two-call eps rule, and
+        # the chain called directly against both
+        e_two, c_two, t_two = cluster.eps_rule(h, args.rho)
+        assert clusters[s].eps == e_two, "split %d: eps of the chain vs eps_rule" % s
+        e_ch, c_ch, t_ch, l_ch, _ = cluster.eps_rule_dbscan(h, args.rho, min_samples=4)
+        assert (e_ch, c_ch, t_ch) == (e_two, c_two, t_two) and np.array_equal(l_ch, lab)
         # sklearn numbering: cluster ids in order of their smallest core sample
         est = cluster.DBSCAN(eps=clusters[s].eps, min_samples=4, metric="precomputed").fit(h)
         assert np.array_equal(est.labels_, lab)
@@ -207,7 +221,21 @@ def test_config4_n128k_properties(dev):
     tgt = torch.from_numpy(clustered(N, d, 1)).to(dev); src = torch.from_numpy(clustered(Ns, d, 2, intra=0.7)).to(dev)
     st = {}
     h = rerank.re_ranking_device(src, tgt, lambda_value=lam, stages=st)
-    _check_sampled_rows(h, st, [0, 63999, 64000, 127999], 20, lam)
+    rows = sorted(set([0, 63999, 64000, 127999] + [int(r) for r in np.random.default_rng(7).integers(0, N, 64)]))
+    _check_sampled_rows(h, st, rows, 20, lam)
+    # the streamed replay's rare path: EVERY row it flagged for the in-place kernel (a first pivot inside [0, K)) is
+    # checked against np.argsort -- the ranking is re-run with the diagnostic surface to learn which rows those are
+    dg = {}
+    rank2 = rerank.initial_rank(st["D"], st["rowmax"], N, N, 21, diag=dg)
+    assert torch.equal(rank2, st["rank"][:, :21]), "the ranking is deterministic"
+    assert dg["flagged"] is not None, "N = 128 000 runs the streamed kernel"
+    flagged = torch.nonzero(dg["flagged"]).flatten().cpu().numpy()
+    print("N=%d: %d random rows checked; the streamed replay flagged %d rows for the in-place kernel" % (N, len(rows), len(flagged)))
+    rowmax_h = st["rowmax"].cpu().numpy().astype(np.uint16).view(np.float16)
+    for r in flagged[:512]:
+        dn = st["D"][int(r)].cpu().numpy() / rowmax_h[int(r)]
+        assert np.array_equal(np.argsort(dn)[:21].astype(np.int32), rank2[int(r)].cpu().numpy()), "flagged row %d vs np.argsort" % r
+    del rank2, dg
     Jp = h.M
     # symmetry without a second 32 GB matrix: compare row blocks with the matching column blocks
     for lo in range(0, N, 16000):
