@@ -94,6 +94,13 @@ class SyncCounter:
     def __enter__(self):
         self._orig = {k: getattr(torch.Tensor, k) for k in ("item", "tolist", "cpu")}
         me = self
+        # (round 6: the one-GPU eps rule + DBSCAN chain reads back through DMA copies into page-locked memory + ONE stream wait: counted too)
+        self._ssync = torch.cuda.Stream.synchronize
+
+        def ssync(st, *a, **kw):
+            me.n += 1
+            return me._ssync(st, *a, **kw)
+        torch.cuda.Stream.synchronize = ssync
 
         def wrap(name):
             fn = self._orig[name]
@@ -110,6 +117,7 @@ class SyncCounter:
     def __exit__(self, *exc):
         for k, fn in self._orig.items():
             setattr(torch.Tensor, k, fn)
+        torch.cuda.Stream.synchronize = self._ssync
 
 
 class CollectiveCounter:

@@ -178,6 +178,13 @@ int ssg_eps_compact(const void* M, const uint16_t* v, int N, int row0, int nrows
 int ssg_eps_sample_hist(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, int row_stride,
                         const uint64_t* refine, uint64_t* hist, ssg_stream_t stream);
 /* thr = 5 uint64: {threshold float bits, sample size, selected coarse bin, sample elements below that bin, target rank} */
+/* round 6: both sampling levels AND their selections in two launches (instead of four): the workgroup that finishes a level last selects.
+ * hist2x = 2 x 4097 words and tickets2 = 2 words, zeroed by the caller; thr5 (5 words) ends up as ssg_eps_select_threshold followed by
+ * ssg_eps_refine_threshold leave it (the separate calls remain: the sharded two-call form all-reduces the histograms in between) */
+int ssg_eps_sample_threshold(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, int row_stride,
+                             double quantile, uint64_t* hist2x, uint64_t* thr5, uint32_t* tickets2, uint64_t* splitters1023, ssg_stream_t stream);
+/* splitters1023 (nullable): 1023 ascending float64 bit patterns that cut the values below the threshold into 1024 parts of about equal sample
+ * mass (interpolated in the level-1 histogram) -- the splitters of ssg_samplesort_u64_presplit_dev for the keys the compaction pass collects */
 int ssg_eps_select_threshold(const uint64_t* hist, double quantile, uint64_t* thr3, ssg_stream_t stream);
 /* second level: ssg_eps_sample_hist(..., refine = thr, hist2) counts the sample elements of the selected coarse bin in 1024 linear
  * sub-bins (hist2 zeroed by the caller); this replaces thr[0] by the sub-bin edge (one guard sub-bin) */
@@ -210,6 +217,10 @@ int ssg_eps_check(const uint64_t* sorted_keys, const uint64_t* cursor, const uin
  * *fail = 1 when a bucket between two splitters holds more than 16384 keys (buf is then a permutation of the keys, not sorted) */
 size_t ssg_samplesort_u64_workspace_bytes(uint64_t n_cap);
 int ssg_samplesort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, void* ws, size_t ws_bytes, uint64_t* fail, ssg_stream_t stream);
+/* round 6: the same sort on 1023 ascending splitters the caller already holds on the device (any monotone splitters sort correctly; balance is
+ * the caller's business: a bucket beyond 16 384 keys sets *fail): three launches, no sample sort.  gcount2048 (2048 uint32) and *fail: zero on entry */
+int ssg_samplesort_u64_presplit_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, const uint64_t* splitters1023, uint32_t* gcount2048,
+                                    void* ws, size_t ws_bytes, uint64_t* fail, ssg_stream_t stream);
 size_t ssg_eps_mean_workspace_bytes(int64_t top);
 /* out2[0] = mean of the first `top` sorted keys with numpy's pairwise summation (mode 0: f64;
  * mode 1: float32 sum of half values -> half, out2[1] = its bits) */
@@ -218,6 +229,9 @@ int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, s
  * done: call it while the stream is idle), _run launches the summation asynchronously.  ssg_eps_mean = prepare + run. */
 int ssg_eps_mean_prepare(int64_t top, void* ws, size_t ws_bytes, ssg_stream_t stream);
 int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, ssg_stream_t stream);
+/* round 6: ssg_eps_mean_run followed by ssg_eps_check without the check's own launch (same arguments as the two calls; eps2 = out2) */
+int ssg_eps_mean_check(const uint64_t* sorted_keys, int64_t top_guess, int mode, void* ws, size_t ws_bytes, double* eps2, const uint64_t* cursor,
+                       const uint64_t* thr3, double rho, uint64_t upper_total, uint64_t n_cap, uint64_t* status6, const uint64_t* sort_fail, ssg_stream_t stream);
 
 /* ---- K11/K12 DBSCAN (selftraining.py:295,306; sklearn 1.7.2 DBSCAN precomputed) ---------- */
 /* cnt[il] = |{k: d(i,k) <= eps}|; edges[2e],[2e+1] = (i,k) for every hit (cursor counts all) */
@@ -248,7 +262,8 @@ size_t ssg_dbscan_cc_workspace_bytes(int N);
 int ssg_dbscan_cc(const int32_t* cnt, const int32_t* edges, uint64_t nedges, int N, int min_samples, void* ws, size_t ws_bytes,
                   int64_t* labels, ssg_stream_t stream);
 /* the same with the edge count left on the device (the region query's cursor; min(*nedges_dev, cap_edges) edges are read): no host
- * round trip between region query and labels */
+ * round trip between region query and labels.  labels may be NULL (round 6): the int64 conversion launch is skipped and the caller reads
+ * the labels as int32 from the workspace itself -- lab = (int32_t*)ws + N, 0x7fffffff = noise (ws: parent[N] | lab[N] | ...) */
 int ssg_dbscan_cc_dev(const int32_t* cnt, const int32_t* edges, const uint64_t* nedges_dev, uint64_t cap_edges, int N, int min_samples,
                       void* ws, size_t ws_bytes, int64_t* labels, ssg_stream_t stream);
 

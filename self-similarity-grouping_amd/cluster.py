@@ -254,17 +254,14 @@ def _eps_rule_dbscan_sharded(L, h, rho, min_samples, two_calls):
     top_guess = int(np.round(rho * upper_total))
     args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
     stride = max(1, h.nrows // 192)
-    z = torch.zeros(2 * 4097 + 5 + 3 + 6 + 2 + 2 + 1 + 2 + 2 + 2 + 1, dtype=torch.int64, device=dev)
-    hist1, hist2 = z[:4097], z[4097:8194]
+    z = torch.zeros(2 * 4097 + 5 + 3 + 6 + 2 + 2 + 1 + 2 + 2 + 2 + 1 + 1, dtype=torch.int64, device=dev)
+    hist1, tick = z[:8194], z[8220:8221]                           # (both levels' histograms back to back; two uint32 tickets)
     thr3, cursor, status6, ecur, eps2 = z[8194:8199], z[8199:8202], z[8202:8208], z[8208:8210], z[8210:8212].view(torch.float64)
     sort_fail, ktot, gcur, etot, thrg = z[8212:8213], z[8213:8215], z[8215:8217], z[8217:8219], z[8219:8220]
     # the LOCAL quantile is taken wider than the one-GPU chain's 1.3 * rho: a rank whose rows hold more small distances than the average
     # (big identities) would otherwise cut below the global top-th key and fail the check -- 1.6 tolerates a 60 % denser block
     qf = float(os.environ.get("SSG_EPS_SHARD_QUANTILE", "1.6"))
-    check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist1), st), "ssg_eps_sample_hist")
-    check(L.ssg_eps_select_threshold(ptr(hist1), qf * rho, ptr(thr3), st), "ssg_eps_select_threshold")
-    check(L.ssg_eps_sample_hist(*args, stride, ptr(thr3), ptr(hist2), st), "ssg_eps_sample_hist")
-    check(L.ssg_eps_refine_threshold(ptr(hist2), ptr(thr3), st), "ssg_eps_refine_threshold")
+    check(L.ssg_eps_sample_threshold(*args, stride, qf * rho, ptr(hist1), ptr(thr3), ptr(tick), None, st), "ssg_eps_sample_threshold")
     # one capacity for every rank (the buffers travel in a flat all-gather): twice the expected candidates of the rank with the largest
     # part of the triangle (rank 0: 15/64 of it on 8 ranks, not 1/8) + a floor
     share = max(_triangle_share(N, *shard_bounds(N, r, world)) for r in range(world))
@@ -297,8 +294,8 @@ def _eps_rule_dbscan_sharded(L, h, rho, min_samples, two_calls):
         sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
         check(L.ssg_samplesort_u64_dev(ptr(allk), n_pow2, ptr(ktot), ptr(sws), sws_bytes, ptr(sort_fail), st), "ssg_samplesort_u64_dev")
         sf = sort_fail
-    check(L.ssg_eps_mean_run(ptr(allk), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), st), "ssg_eps_mean_run")
-    check(L.ssg_eps_check(ptr(allk), ptr(gcur), ptr(thrg), rho, upper_total, top_guess, cap_all, ptr(eps2), ptr(status6), ptr(sf), st), "ssg_eps_check")
+    check(L.ssg_eps_mean_check(ptr(allk), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), ptr(gcur), ptr(thrg), rho, upper_total, cap_all,
+                               ptr(status6), ptr(sf), st), "ssg_eps_mean_check")
     # ---- region query of the local rows with eps read from the device
     mx_rows = -(-N // world)
     cnt = torch.zeros(mx_rows, dtype=torch.int32, device=dev)                             # (padded to the longest block: one shape on every rank)
@@ -381,19 +378,35 @@ def eps_rule_dbscan(X, rho, min_samples=4):
         return _eps_rule_dbscan_sharded(L, h, rho, min_samples, two_calls)
     dev, st = h.device, stream()
     args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
-    # ---- the sampled threshold and the one full pass, exactly as _eps_rule_sampled queues them
+    # ---- ONE zero-filled allocation holds every small table of the chain AND everything the host reads at the end (round 6: the read-back
+    # needs no concatenation / conversion launches, the components' workspace no initialisation launch of its own), int64 words:
+    #   [hist1 4097 | hist2 4097 | tickets 1 | thr5 5 | cursor 3 | sort_fail 1 | splitters 1024 | bucket counts 1024 || ecur 2 | status6 6 | eps2 2 |
+    #    cnt (int32) | ws: parent, lab (int32), ...]
     stride = max(1, h.nrows // 192)
-    # every small zero-initialised table of the chain out of ONE allocation (one fill kernel instead of six)
-    z = torch.zeros(2 * 4097 + 5 + 3 + 6 + 2 + 2 + 1, dtype=torch.int64, device=dev)
-    hist1, hist2 = z[:4097], z[4097:8194]
-    thr3, cursor, status6, ecur, eps2 = z[8194:8199], z[8199:8202], z[8202:8208], z[8208:8210], z[8210:8212].view(torch.float64)
-    check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist1), st), "ssg_eps_sample_hist")
-    check(L.ssg_eps_select_threshold(ptr(hist1), 1.3 * rho, ptr(thr3), st), "ssg_eps_select_threshold")
-    check(L.ssg_eps_sample_hist(*args, stride, ptr(thr3), ptr(hist2), st), "ssg_eps_sample_hist")
-    check(L.ssg_eps_refine_threshold(ptr(hist2), ptr(thr3), st), "ssg_eps_refine_threshold")
+    ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
+    ncnt = (h.nrows + 1) // 2
+    o_small, o_out = 2 * 4097, 2 * 4097 + 10 + 2048
+    o_cnt = o_out + 10
+    o_ws = o_cnt + ncnt
+    z = torch.zeros(o_ws + (ws_bytes + 7) // 8, dtype=torch.int64, device=dev)
+    hist = z[:o_small]
+    tickets, thr3, cursor, sort_fail = z[o_small:o_small + 1], z[o_small + 1:o_small + 6], z[o_small + 6:o_small + 9], z[o_small + 9:o_small + 10]
+    splitters, gcount = z[o_small + 10:o_small + 1034], z[o_small + 1034:o_small + 2058]
+    ecur, status6, eps2 = z[o_out:o_out + 2], z[o_out + 2:o_out + 8], z[o_out + 8:o_out + 10].view(torch.float64)
+    cnt = z[o_cnt:o_ws].view(torch.int32)[:h.nrows]
+    ws_buf = z[o_ws:].view(torch.uint8)
+    # ---- the sampled threshold (two launches: each level's last workgroup selects) and the one full pass
+    fused = os.environ.get("SSG_EPS_FUSED_LAUNCHES", "1") != "0"      # (0: the separate selection / check launches of round 5 -- A/B switch)
+    if fused:
+        check(L.ssg_eps_sample_threshold(*args, stride, 1.3 * rho, ptr(hist), ptr(thr3), ptr(tickets), ptr(splitters), st), "ssg_eps_sample_threshold")
+    else:
+        check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist[:4097]), st), "ssg_eps_sample_hist")
+        check(L.ssg_eps_select_threshold(ptr(hist[:4097]), 1.3 * rho, ptr(thr3), st), "ssg_eps_select_threshold")
+        check(L.ssg_eps_sample_hist(*args, stride, ptr(thr3), ptr(hist[4097:]), st), "ssg_eps_sample_hist")
+        check(L.ssg_eps_refine_threshold(ptr(hist[4097:]), ptr(thr3), st), "ssg_eps_refine_threshold")
     # the threshold sits at the 1.3 * rho quantile of ~3 M sampled entries (about 1 % sampling error on the count below it): twice the
     # expected top + a floor holds the candidates with a wide margin -- and keeps the launched sort network two levels shorter than the
-    # two-call path's 6x bound (a fuller buffer fails ssg_eps_check and the two-call path answers)
+    # two-call path's 6x bound (a fuller buffer fails the check and the two-call path answers)
     cap = max(2 * top_guess * h.nrows // N + (1 << 16), 1 << 16)
     n_cap = max(2048, 1 << (cap - 1).bit_length())
     buf = torch.empty(n_cap, dtype=torch.int64, device=dev)
@@ -404,28 +417,33 @@ def eps_rule_dbscan(X, rho, min_samples=4):
               "ssg_eps_compact_below_s")
     else:
         check(L.ssg_eps_compact_below(*args, ptr(thr3), ptr(buf), n_cap, ptr(cursor), st), "ssg_eps_compact_below")
-    # ---- sort (device-sized), numpy's pairwise mean of the first top_guess keys, the checks -- no read-back
+    # ---- sort (device-sized), numpy's pairwise mean of the first top_guess keys + the checks in the tree kernel -- no read-back
     tree = _eps_tree(L, top_guess, dev, st)
-    # sample sort (5 launches) while its 1024 sorting buckets stay LDS-sized: ~1.3 * top candidates expected, a bucket may run to 4x the
+    # sample sort (4 launches) while its 1024 sorting buckets stay LDS-sized: ~1.3 * top candidates expected, a bucket may run to 4x the
     # mean, 2048 keys fit -> up to 4e5 candidates (N = 16 000: 2.7e5); above that the bitonic network (25+ launches) as in round 4
     if os.environ.get("SSG_EPS_SORT", "sample") == "bitonic" or 1.3 * top_guess * h.nrows / N > 4.0e5:
         check(L.ssg_sort_u64_dev(ptr(buf), n_cap, ptr(cursor), st), "ssg_sort_u64_dev")
-        sort_fail = None
+        sf = None
     else:
-        # sample sort: 5 launches whatever the count; its fail word (a bucket the sample missed) is one more condition of the check below
         sws_bytes = int(L.ssg_samplesort_u64_workspace_bytes(n_cap))
         sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
-        sort_fail = z[8212:8213]
-        check(L.ssg_samplesort_u64_dev(ptr(buf), n_cap, ptr(cursor), ptr(sws), sws_bytes, ptr(sort_fail), st), "ssg_samplesort_u64_dev")
-    check(L.ssg_eps_mean_run(ptr(buf), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), st), "ssg_eps_mean_run")
-    check(L.ssg_eps_check(ptr(buf), ptr(cursor), ptr(thr3), rho, upper_total, top_guess, n_cap, ptr(eps2), ptr(status6),
-                          ptr(sort_fail), st), "ssg_eps_check")
-    # ---- region query with eps read from the device, components, labels
-    cnt = torch.empty(h.nrows, dtype=torch.int32, device=dev)
+        if fused and os.environ.get("SSG_EPS_PRESPLIT", "0") == "1":
+            # (opt-in, measured and rejected: splitters interpolated in the sample histogram save the 37 us sample sort, but final_dist takes
+            # few distinct values -- half J' plus a half source term -- and thousands of EQUAL keys then share one sorting bucket: the
+            # sorted sample gives such a value a bucket of its own, an interpolated splitter cannot.  20 ms instead of 0.33 at N = 16 000.)
+            check(L.ssg_samplesort_u64_presplit_dev(ptr(buf), n_cap, ptr(cursor), ptr(splitters), ptr(gcount), ptr(sws), sws_bytes, ptr(sort_fail), st),
+                  "ssg_samplesort_u64_presplit_dev")
+        else:
+            check(L.ssg_samplesort_u64_dev(ptr(buf), n_cap, ptr(cursor), ptr(sws), sws_bytes, ptr(sort_fail), st), "ssg_samplesort_u64_dev")
+        sf = sort_fail
+    if fused:
+        check(L.ssg_eps_mean_check(ptr(buf), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), ptr(cursor), ptr(thr3), rho, upper_total, n_cap,
+                                   ptr(status6), ptr(sf), st), "ssg_eps_mean_check")
+    else:
+        check(L.ssg_eps_mean_run(ptr(buf), top_guess, 1 if h.mode == 1 else 0, ptr(tree), tree.numel(), ptr(eps2), st), "ssg_eps_mean_run")
+        check(L.ssg_eps_check(ptr(buf), ptr(cursor), ptr(thr3), rho, upper_total, top_guess, n_cap, ptr(eps2), ptr(status6), ptr(sf), st), "ssg_eps_check")
+    # ---- region query with eps read from the device, components; the labels stay int32 in the workspace (0x7fffffff = noise)
     ecap = max(64 * h.nrows, 1 << 16)
-    ws_bytes = int(L.ssg_dbscan_cc_workspace_bytes(N))
-    ws_buf = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    labels = torch.empty(N, dtype=torch.int64, device=dev)
     edges = torch.empty((ecap, 2), dtype=torch.int32, device=dev)
     if sp is not None:
         check(L.ssg_region_query_s_dev(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.lambda_value, ptr(eps2), ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]),
@@ -434,18 +452,32 @@ def eps_rule_dbscan(X, rho, min_samples=4):
     else:
         check(L.ssg_region_query_dev(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.mode, h.lambda_value, ptr(eps2), ptr(cnt), ptr(edges), ecap, ptr(ecur), st),
               "ssg_region_query_dev")
-    check(L.ssg_dbscan_cc_dev(ptr(cnt), ptr(edges), ptr(ecur), ecap, N, int(min_samples), ptr(ws_buf), ws_bytes, ptr(labels), st), "ssg_dbscan_cc_dev")
-    pend = h.take_pending() if hasattr(h, "take_pending") else None
-    npend = int(pend.numel()) if pend is not None else 0
-    host = torch.cat([ecur[:1], status6, eps2.view(torch.int64)] + ([pend.to(torch.int64)] if pend is not None else []) + [labels, cnt.to(torch.int64)]).cpu().numpy()   # THE read
-    ne, ok, got, zeros, top = int(host[0]), int(host[1]), int(host[2]), int(host[3]), int(host[4])
-    eps_f64, eps_hbits = float(host[7:8].view(np.float64)[0]), int(host[8:9].view(np.float64)[0]) if ok else 0
-    o = 9
-    if pend is not None:
-        if h.resolve_pending([int(x) for x in host[o:o + npend]]):
+    check(L.ssg_dbscan_cc_dev(ptr(cnt), ptr(edges), ptr(ecur), ecap, N, int(min_samples), ptr(ws_buf), ws_bytes, None, st), "ssg_dbscan_cc_dev")
+    # ---- THE read: the contiguous tail of `z` up to the end of the int32 labels, and the re-rank's raw status words, as DMA copies into one
+    # page-locked buffer behind the chain -- no concatenation launch -- and one wait
+    from . import hostio
+    pieces = h.pending_pieces() if hasattr(h, "pending_pieces") else None
+    n_out = (o_ws - o_out) + (2 * N * 4 + 7) // 8                    # ecur .. cnt, then parent[N] + lab[N] of the workspace
+    extra = [p_.reshape(-1).view(torch.uint8) for p_ in (pieces or [])]
+    hostbuf = hostio.pinned_empty((n_out * 8 + sum((e_.numel() + 7) // 8 * 8 for e_ in extra),), torch.uint8)
+    hostbuf[:n_out * 8].copy_(z[o_out:o_out + n_out].view(torch.uint8), non_blocking=True)
+    off_b = n_out * 8
+    for e_ in extra:
+        hostbuf[off_b:off_b + e_.numel()].copy_(e_, non_blocking=True)
+        off_b += (e_.numel() + 7) // 8 * 8
+    torch.cuda.current_stream(dev).synchronize()
+    raw = hostbuf.numpy()
+    host = raw[:n_out * 8].view(np.int64)
+    ne, ok, got, zeros, top = int(host[0]), int(host[2]), int(host[3]), int(host[4]), int(host[5])
+    eps_f64, eps_hbits = float(host[8:9].view(np.float64)[0]), int(host[9:10].view(np.float64)[0]) if ok else 0
+    if pieces is not None:
+        vals, off_b = [], n_out * 8
+        for p_, e_ in zip(pieces, extra):
+            vals += [int(x) for x in raw[off_b:off_b + e_.numel()].view({torch.int32: np.int32, torch.int64: np.int64}[p_.dtype])]
+            off_b += (e_.numel() + 7) // 8 * 8
+        if h.resolve_pending(vals):
             return eps_rule_dbscan(h, rho, min_samples)      # the query expansion had run on too small a guess: the matrix was rebuilt, run again (once)
         h.validate()
-        o += npend
     if not ok:
         return two_calls()                                    # zeros in the triangle, or the sample missed: the two-call path decides (exactly)
     count = upper_total - zeros
@@ -453,8 +485,11 @@ def eps_rule_dbscan(X, rho, min_samples=4):
     if ne > ecap:                                             # the edge list was too small: eps is known now, the region query is redone with the exact size
         est = DBSCAN(eps=eps, min_samples=min_samples, metric="precomputed").fit(h)
         return eps, count, top, est.labels_, est.core_sample_indices_
-    lab = host[o:o + N].copy()
-    core = np.nonzero(host[o + N:o + N + h.nrows] >= int(min_samples))[0]
+    cnt_h = raw[(o_cnt - o_out) * 8:(o_cnt - o_out) * 8 + 4 * h.nrows].view(np.int32)
+    lab32 = raw[(o_ws - o_out) * 8 + 4 * N:(o_ws - o_out) * 8 + 8 * N].view(np.int32)
+    lab = lab32.astype(np.int64)
+    lab[lab32 == 0x7fffffff] = -1
+    core = np.nonzero(cnt_h >= int(min_samples))[0]
     return eps, count, top, lab, core
 
 

@@ -327,9 +327,97 @@ __device__ __forceinline__ void surrogate8(const MatView& mv, const RawChunk& r,
 // that bin's float range (hist[0..1023]); the coarse bins are 0.4 % wide, which on a dense value distribution is far more than
 // the quantile margin and would blow the candidate set up
 constexpr int SPARTS = 8;
+// both selection levels for a 256-thread workgroup (the bodies of eps_select_kernel / eps_select2_kernel below, which stay the two-launch
+// API): level 1 = first bin whose cumulative count reaches ceil(q * sample size), threshold = upper edge of the next bin, sel = {threshold
+// bits, sample size, bin, sample elements below the bin, target}; level 2 = the sub-bin of coarse bin sel[2] where sel[3] + sub-bins reach
+// sel[4], threshold = upper edge of the sub-bin after it.  `part` = 4097 words of LDS scratch.  Histogram words are read with agent-scope loads.
+__device__ __forceinline__ void eps_select_block(const unsigned long long* __restrict__ hist, double q, unsigned long long* __restrict__ sel, bool level2,
+                                                 unsigned int* part, unsigned long long* __restrict__ split_out = nullptr) {
+  const int t = (int)threadIdx.x;
+  auto ld = [&](int b) -> unsigned long long { return __hip_atomic_load(&hist[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+  const int nb = level2 ? 4 : 16, b0 = t * nb;                     // bins per thread: 1024 / 256 or 4096 / 256
+  unsigned long long c[16], mine = 0;
+#pragma unroll
+  for (int u = 0; u < 16; u++) { c[u] = u < nb ? ld(b0 + u) : 0ull; mine += c[u]; }
+  // exclusive prefix of the 256 per-thread sums (counts fit 32 bits: a sample holds < 2^32 elements)
+  __syncthreads();
+  part[t] = (unsigned int)mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned int add = t >= o ? part[t - o] : 0u;
+    __syncthreads();
+    part[t] += add;
+    __syncthreads();
+  }
+  unsigned long long run = (unsigned long long)part[t] - mine;
+  if (!level2) {
+    const unsigned long long total = ld(4096);
+    unsigned long long target = (unsigned long long)ceil(q * (double)total);
+    if (target < 64) target = 64;
+    __shared__ int bsel; __shared__ unsigned long long bbefore;
+    if (t == 0) { bsel = 4096; bbefore = 0; }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const unsigned long long before = run;
+      run += c[u];
+      if (before < target && run >= target) { bsel = b0 + u; bbefore = before; }      // unique
+    }
+    __syncthreads();
+    if (t == 0) {
+      const int b = bsel;
+      float thr = b >= 4094 ? __uint_as_float(0x7f800000u) : sur_bin_upper(b + 1);
+      if (total == 0) thr = __uint_as_float(0x7f800000u);
+      sel[0] = (unsigned long long)__float_as_uint(thr); sel[1] = total; sel[2] = (unsigned long long)b;
+      sel[3] = b >= 4096 ? 0ull : bbefore; sel[4] = target;
+    }
+    if (split_out) {
+      // splitters of the sample sort that will order the collected keys (round 6: ss_splitters_kernel -- one workgroup sorting a sample
+      // of 4096 candidates, 37 us, the longest kernel of the chain -- is not launched): the candidates are the values below the threshold,
+      // i.e. the sample mass (0, target]; splitter s sits at mass s * target / 1024, linearly interpolated inside its histogram bin (~6
+      // sample elements per bucket: the balance of a sorted sample of 4 keys per bucket).  Any monotone splitters sort correctly -- a bad
+      // estimate costs balance (a bucket beyond 16 384 keys raises the sort's fail word and the two-call path answers), never exactness.
+      for (int q_ = t; q_ < 1023; q_ += 256) split_out[q_] = ~0ull;       // (a splitter no bin reaches -- a sample below the 64-element floor -- stays +inf)
+      __syncthreads();
+      unsigned long long before = (unsigned long long)part[t] - mine;
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const unsigned long long after = before + c[u];
+        if (c[u] && before < target) {
+          unsigned long long s_lo = before * 1024ull / target + 1, s_hi = after * 1024ull / target;
+          if (s_hi > 1023) s_hi = 1023;
+          const int b = b0 + u;
+          const double lo = b == 0 ? 0.0 : (double)sur_bin_upper(b - 1), hi = (double)sur_bin_upper(b);
+          for (unsigned long long sidx = s_lo; sidx <= s_hi; sidx++) {
+            const double m = (double)sidx * (double)target * (1.0 / 1024.0);
+            double frac = (m - (double)before) / (double)c[u];
+            frac = frac < 0.0 ? 0.0 : (frac > 1.0 ? 1.0 : frac);
+            split_out[sidx - 1] = (unsigned long long)__double_as_longlong(lo + frac * (hi - lo));
+          }
+        }
+        before = after;
+      }
+    }
+  } else {
+    const int b = (int)sel[2];
+    if (b < 1 || b >= 4094) return;                    // degenerate / open-ended bins keep the coarse threshold
+    const unsigned long long before0 = sel[3], target = sel[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const unsigned long long excl = before0 + run, incl = excl + c[u];
+      run += c[u];
+      if (excl < target && incl >= target) {
+        const float lo = sur_bin_upper(b - 1), hi = sur_bin_upper(b);
+        const float thr = lo + (float)(b0 + u + 2) * ((hi - lo) * (1.f / 1024.f));
+        sel[0] = (unsigned long long)__float_as_uint(thr < sur_bin_upper(b + 1) ? thr : sur_bin_upper(b + 1));
+      }
+    }
+  }
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int stride, const unsigned long long* __restrict__ refine,
-                                                              unsigned long long* __restrict__ hist) {
+                                                              unsigned long long* __restrict__ hist, double q = 0.0, unsigned long long* __restrict__ sel = nullptr,
+                                                              unsigned int* __restrict__ ticket = nullptr, unsigned long long* __restrict__ split_out = nullptr) {
   __shared__ unsigned int lh[4097];
   for (int b = (int)threadIdx.x; b < 4097; b += 256) lh[b] = 0;
   __syncthreads();
@@ -377,6 +465,20 @@ __global__ __launch_bounds__(256) void eps_sample_hist_kernel(MatView mv, int st
   }
   __syncthreads();
   for (int b = (int)threadIdx.x; b < 4097; b += 256) if (lh[b]) atomicAdd(&hist[b], (unsigned long long)lh[b]);
+  if (!sel) return;
+  // ---- round 6: the threshold selection rides in this launch.  The workgroup that draws the last ticket has every other workgroup's
+  // histogram atomics behind it (they are device-scope read-modify-writes at the memory side; the agent-scope loads of the selection
+  // by-pass this CU's L1 and its XCD's L2) and runs what eps_select_kernel / eps_select2_kernel ran as launches of their own.
+  // (no cache maintenance is involved: the histogram words are only ever touched by device-scope atomics and agent-scope loads, both
+  // performed at the memory side -- a wave waits for the acknowledgement of its own atomics, the barrier collects the waves, lane 0 draws
+  // the ticket.  __threadfence() here -- an L2 write-back + invalidate per thread -- cost more than the launches it saved.)
+  __shared__ unsigned int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  eps_select_block(hist, q, sel, refine != nullptr, lh, refine ? nullptr : split_out);
 }
 
 // one workgroup: first bin whose cumulative sample count reaches ceil(q * sample size); threshold = upper edge of the NEXT
@@ -651,6 +753,26 @@ __device__ T pw_leaf(const unsigned long long* keys, long long off, int n) {
   for (; i < n; i++) res += val(i);
   return res;
 }
+// the a-posteriori checks of the sampled eps rule (see eps_check_kernel, which runs them as a launch of its own): one thread
+struct EpsCheckArgs {
+  const unsigned long long* cursor = nullptr; const unsigned long long* thr3 = nullptr; double rho = 0.0; unsigned long long upper_total = 0; long long top_guess = 0;
+  unsigned long long n_cap = 0; unsigned long long* status6 = nullptr; const unsigned long long* sort_fail = nullptr;
+};
+__device__ __forceinline__ void eps_check_one(const unsigned long long* __restrict__ sorted, const EpsCheckArgs& a, double* __restrict__ eps2) {
+  const unsigned long long got = a.cursor[0], zeros = a.cursor[1];
+  const long long count = (long long)(a.upper_total - zeros);
+  const long long top = (long long)rint(a.rho * (double)count);
+  const double thr = (double)__uint_as_float((unsigned)(a.thr3[0] & 0xffffffffull));
+  bool ok = top == a.top_guess && top > 0 && got <= a.n_cap && got >= (unsigned long long)top && isfinite(thr) && !(a.sort_fail && *a.sort_fail);
+  unsigned long long kb = 0;
+  if (ok) {
+    kb = sorted[top - 1];
+    const double key_top = __longlong_as_double((long long)kb);
+    ok = key_top < thr - 1e-6 * (1.0 + fabs(thr));
+  }
+  a.status6[0] = ok ? 1ull : 0ull; a.status6[1] = got; a.status6[2] = zeros; a.status6[3] = (unsigned long long)top; a.status6[4] = kb; a.status6[5] = a.thr3[0];
+  if (!ok) eps2[0] = __longlong_as_double(0x7ff8000000000000ll);
+}
 // leaves of the pairwise tree, 8 lanes per leaf (one lane per accumulator of numpy's unrolled loop), 8 leaves per wave:
 //   r[j] = a[j]; for i = 8, 16, ...: r[j] += a[i + j];  res = ((r0+r1)+(r2+r3)) + ((r4+r5)+(r6+r7));  res += a[tail...]
 template <typename T>
@@ -683,8 +805,8 @@ template <typename T>
 __global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long* __restrict__ keys, long long top, int nleaves, int nlevels,
                                                         const long long* __restrict__ leaf_off, const int* __restrict__ leaf_n,
                                                         const int* __restrict__ node_l, const int* __restrict__ node_r,
-                                                        const int* __restrict__ level_ptr, T* __restrict__ val, double* __restrict__ out) {
-  (void)keys; (void)leaf_off; (void)leaf_n;        // the leaves were summed by eps_leaf_kernel
+                                                        const int* __restrict__ level_ptr, T* __restrict__ val, double* __restrict__ out, EpsCheckArgs chk = EpsCheckArgs()) {
+  (void)leaf_off; (void)leaf_n;        // the leaves were summed by eps_leaf_kernel
   for (int h = 0; h < nlevels; h++) {
     for (int x = level_ptr[h] + (int)threadIdx.x; x < level_ptr[h + 1]; x += (int)blockDim.x) val[nleaves + x] = val[node_l[x]] + val[node_r[x]];
     __syncthreads();
@@ -697,6 +819,7 @@ __global__ __launch_bounds__(1024) void eps_mean_kernel(const unsigned long long
       const hbits e = d2h((double)s / (double)top);   // np.float32 scalar / np.intp -> float64 -> np.float16
       out[0] = (double)h2f(e); out[1] = (double)e;
     }
+    if (chk.status6) eps_check_one(keys, chk, out);     // round 6: the a-posteriori checks in the same launch (ssg_eps_mean_check)
   }
 }
 
@@ -1139,6 +1262,22 @@ extern "C" int ssg_eps_sample_hist(const void* M, const uint16_t* v, int N, int 
   SSG_LAUNCH_CHECK("eps_sample_hist_kernel");
   return SSG_OK;
 }
+// round 6: both sampling levels with their selections in TWO launches instead of four (the workgroup that finishes last selects).
+// hist2x = 2 x 4097 words and tickets = 2 words, zeroed by the caller; thr5 receives what ssg_eps_select_threshold + ssg_eps_refine_threshold leave.
+extern "C" int ssg_eps_sample_threshold(const void* M, const uint16_t* v, int N, int row0, int nrows, int mode, double lambda_value, int row_stride,
+                                        double quantile, uint64_t* hist2x, uint64_t* thr5, uint32_t* tickets2, uint64_t* splitters1023, hipStream_t stream) {
+  int rc = check_view("ssg_eps_sample_threshold", M, v, N, row0, nrows, mode); if (rc) return rc;
+  if (row_stride < 1 || !(quantile > 0.0) || !hist2x || !thr5 || !tickets2) { ssg_set_error("ssg_eps_sample_threshold: bad arguments"); return SSG_ERR_INVALID; }
+  const int nsamp = (nrows + row_stride - 1) / row_stride;
+  const MatView mv = make_view(M, v, N, row0, nrows, mode, lambda_value);
+  const unsigned g = (unsigned)stream_grid(nsamp * SPARTS);
+#define SSG_ST(MD, LVL) hipLaunchKernelGGL(eps_sample_hist_kernel<MD>, dim3(g), dim3(256), 0, stream, mv, row_stride, (LVL) ? (const unsigned long long*)thr5 : nullptr, \
+                     (unsigned long long*)hist2x + (LVL) * 4097, quantile, (unsigned long long*)thr5, (unsigned int*)tickets2 + (LVL), (unsigned long long*)splitters1023)
+  for (int lvl = 0; lvl < 2; lvl++) { if (mode == 0) SSG_ST(0, lvl); else if (mode == 1) SSG_ST(1, lvl); else SSG_ST(2, lvl); }
+#undef SSG_ST
+  SSG_LAUNCH_CHECK("eps_sample_hist_kernel (+ selection)");
+  return SSG_OK;
+}
 extern "C" int ssg_eps_select_threshold(const uint64_t* hist, double quantile, uint64_t* thr3, hipStream_t stream) {
   if (!(quantile > 0.0)) { ssg_set_error("ssg_eps_select_threshold: quantile must be positive"); return SSG_ERR_INVALID; }
   hipLaunchKernelGGL(eps_select_kernel, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)hist, quantile, (unsigned long long*)thr3);
@@ -1485,30 +1624,38 @@ __global__ __launch_bounds__(256) void ss_count_kernel(const unsigned long long*
     cmat[(size_t)blockIdx.x * SS_NBK + q] = c ? atomicAdd(&gcount[q], c) : 0u;       // this workgroup's base inside bucket q
   }
 }
-__global__ __launch_bounds__(1024) void ss_scan_kernel(const unsigned int* __restrict__ gcount, unsigned int* __restrict__ off) {
-  __shared__ unsigned int wsum[16];
-  const int t = (int)threadIdx.x, lane = t & 63, wave = t >> 6;
-  const unsigned int v0 = gcount[2 * t], v1 = gcount[2 * t + 1];
-  unsigned int sc = v0 + v1;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(sc, d, 64); if (lane >= d) sc += o; }
-  if (lane == 63) wsum[wave] = sc;
-  __syncthreads();
-  unsigned int woff = 0;
-  for (int w = 0; w < wave; w++) woff += wsum[w];
-  const unsigned int excl = woff + sc - (v0 + v1);
-  off[2 * t] = excl; off[2 * t + 1] = excl + v0;
-  if (t == 1023) off[SS_NBK] = excl + v0 + v1;
-}
+// (round 6: every workgroup scans the 2048 bucket counts itself -- 8 per thread + a 256-entry LDS scan, ~1 us -- instead of waiting for a
+//  one-workgroup scan launch in between; workgroup 0 also leaves the offsets in `off` for the bucket sort)
 __global__ __launch_bounds__(256) void ss_scatter_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap,
-                                                         const unsigned int* __restrict__ cmat, const unsigned int* __restrict__ off,
+                                                         const unsigned int* __restrict__ cmat, const unsigned int* __restrict__ gcount, unsigned int* __restrict__ off,
                                                          const unsigned short* __restrict__ bid, unsigned long long* __restrict__ tmp) {
   __shared__ unsigned int cur[SS_NBK];
+  __shared__ unsigned int psum[256];
   const unsigned long long n = ss_count_of(n_dev, n_cap);
   const unsigned long long g0 = (unsigned long long)blockIdx.x * SS_CHUNK;
-  if (g0 >= n) return;
+  if (g0 >= n && blockIdx.x != 0) return;
   const int t = (int)threadIdx.x;
-  for (int q = t; q < SS_NBK; q += 256) cur[q] = off[q] + cmat[(size_t)blockIdx.x * SS_NBK + q];
+  static_assert(SS_NBK == 8 * 256, "eight bucket counts per thread");
+  unsigned int gc[8], mine = 0;
+#pragma unroll
+  for (int u = 0; u < 8; u++) { gc[u] = gcount[8 * t + u]; mine += gc[u]; }
+  psum[t] = mine;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const unsigned int add = t >= o ? psum[t - o] : 0u;
+    __syncthreads();
+    psum[t] += add;
+    __syncthreads();
+  }
+  unsigned int run = psum[t] - mine;
+#pragma unroll
+  for (int u = 0; u < 8; u++) {
+    cur[8 * t + u] = run + cmat[(size_t)blockIdx.x * SS_NBK + 8 * t + u];
+    if (blockIdx.x == 0) off[8 * t + u] = run;
+    run += gc[u];
+  }
+  if (blockIdx.x == 0 && t == 255) off[SS_NBK] = run;
+  if (g0 >= n) return;                      // (workgroup 0 of an empty input: only the offsets)
   __syncthreads();
   for (int u = 0; u < SS_CHUNK / 256; u += 4) {
     unsigned long long key[4]; int b[4];
@@ -1568,10 +1715,26 @@ extern "C" int ssg_samplesort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint6
   const unsigned G = (unsigned)((n_cap + SS_CHUNK - 1) / SS_CHUNK);
   hipLaunchKernelGGL(ss_splitters_kernel, dim3(1), dim3(1024), 0, stream, a, nd, (unsigned long long)n_cap, w.split, w.gcount, (unsigned long long*)fail);
   hipLaunchKernelGGL(ss_count_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.split, w.gcount, w.cmat, w.bid);
-  hipLaunchKernelGGL(ss_scan_kernel, dim3(1), dim3(1024), 0, stream, w.gcount, w.off);
-  hipLaunchKernelGGL(ss_scatter_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.cmat, w.off, w.bid, w.tmp);
+  hipLaunchKernelGGL(ss_scatter_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.cmat, w.gcount, w.off, w.bid, w.tmp);
   hipLaunchKernelGGL(ss_bucket_sort_kernel, dim3(SS_NBK), dim3(256), 0, stream, w.tmp, w.off, a, (unsigned long long*)fail);
   SSG_LAUNCH_CHECK("sample sort (device-sized)");
+  return SSG_OK;
+}
+
+// round 6: the same sort on splitters the caller already has on the device (ssg_eps_sample_threshold derives them from its histogram):
+// three launches, no sample.  gcount2048 (2048 uint32) and *fail must be ZERO on entry (the caller's one zero-filled allocation).
+extern "C" int ssg_samplesort_u64_presplit_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, const uint64_t* splitters1023, uint32_t* gcount2048,
+                                               void* ws, size_t ws_bytes, uint64_t* fail, hipStream_t stream) {
+  if (!buf || !n_dev || !ws || !fail || !splitters1023 || !gcount2048 || n_cap == 0 || n_cap > (1ull << 31)) { ssg_set_error("ssg_samplesort_u64_presplit_dev: bad arguments"); return SSG_ERR_INVALID; }
+  SsWs w;
+  if (ss_layout(n_cap, (char*)ws, &w) > ws_bytes) { ssg_set_error("ssg_samplesort_u64_presplit_dev: workspace too small"); return SSG_ERR_INVALID; }
+  unsigned long long* a = (unsigned long long*)buf;
+  const unsigned long long* nd = (const unsigned long long*)n_dev;
+  const unsigned G = (unsigned)((n_cap + SS_CHUNK - 1) / SS_CHUNK);
+  hipLaunchKernelGGL(ss_count_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, (const unsigned long long*)splitters1023, gcount2048, w.cmat, w.bid);
+  hipLaunchKernelGGL(ss_scatter_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.cmat, (const unsigned int*)gcount2048, w.off, w.bid, w.tmp);
+  hipLaunchKernelGGL(ss_bucket_sort_kernel, dim3(SS_NBK), dim3(256), 0, stream, w.tmp, w.off, a, (unsigned long long*)fail);
+  SSG_LAUNCH_CHECK("sample sort (device-sized, given splitters)");
   return SSG_OK;
 }
 
@@ -1586,19 +1749,8 @@ __global__ void eps_check_kernel(const unsigned long long* __restrict__ sorted, 
                                  double rho, unsigned long long upper_total, long long top_guess, unsigned long long n_cap, double* __restrict__ eps2,
                                  unsigned long long* __restrict__ status6, const unsigned long long* __restrict__ sort_fail) {
   if (blockIdx.x || threadIdx.x) return;
-  const unsigned long long got = cursor[0], zeros = cursor[1];
-  const long long count = (long long)(upper_total - zeros);
-  const long long top = (long long)rint(rho * (double)count);
-  const double thr = (double)__uint_as_float((unsigned)(thr3[0] & 0xffffffffull));
-  bool ok = top == top_guess && top > 0 && got <= n_cap && got >= (unsigned long long)top && isfinite(thr) && !(sort_fail && *sort_fail);
-  unsigned long long kb = 0;
-  if (ok) {
-    kb = sorted[top - 1];
-    const double key_top = __longlong_as_double((long long)kb);
-    ok = key_top < thr - 1e-6 * (1.0 + fabs(thr));
-  }
-  status6[0] = ok ? 1ull : 0ull; status6[1] = got; status6[2] = zeros; status6[3] = (unsigned long long)top; status6[4] = kb; status6[5] = thr3[0];
-  if (!ok) eps2[0] = __longlong_as_double(0x7ff8000000000000ll);
+  EpsCheckArgs a; a.cursor = cursor; a.thr3 = thr3; a.rho = rho; a.upper_total = upper_total; a.top_guess = top_guess; a.n_cap = n_cap; a.status6 = status6; a.sort_fail = sort_fail;
+  eps_check_one(sorted, a, eps2);
 }
 extern "C" int ssg_eps_check(const uint64_t* sorted_keys, const uint64_t* cursor, const uint64_t* thr3, double rho, uint64_t upper_total, int64_t top_guess,
                              uint64_t n_cap, double* eps2, uint64_t* status6, const uint64_t* sort_fail, hipStream_t stream) {
@@ -1672,7 +1824,7 @@ extern "C" int ssg_eps_mean_prepare(int64_t top, void* ws, size_t ws_bytes, hipS
   return SSG_OK;
 }
 // Step 2: the summation itself (asynchronous): leaves in parallel (8 lanes per leaf), then one workgroup walks the tree levels
-extern "C" int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
+static int eps_mean_run_impl(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, const EpsCheckArgs& chk, hipStream_t stream) {
   if (top <= 0 || ws_bytes < ssg_eps_mean_workspace_bytes(top)) { ssg_set_error("ssg_eps_mean: top=%lld ws too small", (long long)top); return SSG_ERR_INVALID; }
   PwLayout lay; pw_layout(top, lay, false);
   char* w = (char*)ws;
@@ -1683,16 +1835,27 @@ extern "C" int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mo
                        (const int*)(w + lay.o_n), (double*)(w + lay.o_val));
     hipLaunchKernelGGL(eps_mean_kernel<double>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
                        (const long long*)(w + lay.o_off), (const int*)(w + lay.o_n), (const int*)(w + lay.o_l), (const int*)(w + lay.o_r),
-                       (const int*)(w + lay.o_lp), (double*)(w + lay.o_val), out2);
+                       (const int*)(w + lay.o_lp), (double*)(w + lay.o_val), out2, chk);
   } else {
     hipLaunchKernelGGL(eps_leaf_kernel<float>, dim3(lb), dim3(256), 0, stream, (const unsigned long long*)sorted_keys, L, (const long long*)(w + lay.o_off),
                        (const int*)(w + lay.o_n), (float*)(w + lay.o_val));
     hipLaunchKernelGGL(eps_mean_kernel<float>, dim3(1), dim3(1024), 0, stream, (const unsigned long long*)sorted_keys, (long long)top, L, hroot,
                        (const long long*)(w + lay.o_off), (const int*)(w + lay.o_n), (const int*)(w + lay.o_l), (const int*)(w + lay.o_r),
-                       (const int*)(w + lay.o_lp), (float*)(w + lay.o_val), out2);
+                       (const int*)(w + lay.o_lp), (float*)(w + lay.o_val), out2, chk);
   }
   SSG_LAUNCH_CHECK("eps_mean kernels");
   return SSG_OK;
+}
+extern "C" int ssg_eps_mean_run(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
+  return eps_mean_run_impl(sorted_keys, top, mode, ws, ws_bytes, out2, EpsCheckArgs(), stream);
+}
+// round 6: ssg_eps_mean_run + ssg_eps_check in the launches of the former (the tree kernel's last thread runs the checks)
+extern "C" int ssg_eps_mean_check(const uint64_t* sorted_keys, int64_t top_guess, int mode, void* ws, size_t ws_bytes, double* eps2, const uint64_t* cursor,
+                                  const uint64_t* thr3, double rho, uint64_t upper_total, uint64_t n_cap, uint64_t* status6, const uint64_t* sort_fail, hipStream_t stream) {
+  if (!cursor || !thr3 || !status6 || !eps2) { ssg_set_error("ssg_eps_mean_check: null argument"); return SSG_ERR_INVALID; }
+  EpsCheckArgs a; a.cursor = (const unsigned long long*)cursor; a.thr3 = (const unsigned long long*)thr3; a.rho = rho; a.upper_total = upper_total;
+  a.top_guess = top_guess; a.n_cap = n_cap; a.status6 = (unsigned long long*)status6; a.sort_fail = (const unsigned long long*)sort_fail;
+  return eps_mean_run_impl(sorted_keys, top_guess, mode, ws, ws_bytes, eps2, a, stream);
 }
 extern "C" int ssg_eps_mean(const uint64_t* sorted_keys, int64_t top, int mode, void* ws, size_t ws_bytes, double* out2, hipStream_t stream) {
   const int rc = ssg_eps_mean_prepare(top, ws, ws_bytes, stream);
@@ -1772,7 +1935,8 @@ static int dbscan_cc_impl(const int32_t* cnt, const int32_t* edges, uint64_t ned
   hipLaunchKernelGGL(exscan_kernel, dim3(1), dim3(1024), 0, stream, rootflag, N, rootid);
   if (nedges) hipLaunchKernelGGL(cc_border_kernel, dim3(eb > nb ? eb : nb), dim3(256), 0, stream, edges, (unsigned long long)nedges, ne_dev, cnt, min_samples, parent, rootid, lab, N);
   else hipLaunchKernelGGL(cc_label_core_kernel, dim3(nb), dim3(256), 0, stream, cnt, N, min_samples, parent, rootid, lab);
-  hipLaunchKernelGGL(cc_finalize_kernel, dim3(nb), dim3(256), 0, stream, lab, N, labels);
+  // labels == NULL (round 6): the caller reads lab = (int32*)ws + N itself (0x7fffffff = noise) -- one launch less in a chain that reads the workspace back anyway
+  if (labels) hipLaunchKernelGGL(cc_finalize_kernel, dim3(nb), dim3(256), 0, stream, lab, N, labels);
   SSG_LAUNCH_CHECK("dbscan_cc");
   return SSG_OK;
 }

@@ -94,6 +94,14 @@ class DistHandle:
             words.append(self.sparse["cursor"])
         return torch.cat(words) if len(words) > 1 else words[0]
 
+    def pending_pieces(self):
+        """the same words as `take_pending` as the RAW device tensors ([status int32 x 4] and, with a sparse copy, [S cursor int64 x 2]) --
+        a consumer that copies its results out with DMA transfers adds these pieces to them instead of paying a concatenation launch;
+        the values go to `resolve_pending` in the same order.  None when they were read already."""
+        if self._pending is None:
+            return None
+        return [self._pending] + ([self.sparse["cursor"]] if self.sparse is not None else [])
+
     def resolve_pending(self, values):
         """values = the status words as python numbers (read with the caller's host round trip).  Returns True when the distance
         matrix was REBUILT (a V row was longer than the guessed capacity of the query expansion): kernels the caller queued on the

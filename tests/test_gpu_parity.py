@@ -297,6 +297,63 @@ def test_eps_rule_dbscan_chain_equals_the_two_calls(dev, monkeypatch):
     assert sc.n == 1, sc.n
 
 
+def test_fused_sampling_and_check_launches_equal_the_separate_ones(dev):
+    """round 6: `ssg_eps_sample_threshold` (each sampling level's last workgroup selects the threshold: two launches instead of four) and
+    `ssg_eps_mean_check` (the a-posteriori checks in the tree kernel) against the separate entry points they replace in the chain -- the
+    five threshold words and the six status words bit for bit, 30 times over (a workgroup that read the histogram before another one's
+    atomics had landed would show as a different threshold), at two sizes, with other work in flight."""
+    from ssg_amd import rerank
+    from ssg_amd._lib import check, lib, ptr, stream
+    L = lib()
+    for N, d, seed in ((3000, 96, 31), (6000, 128, 33)):
+        tgt = hard_clustered(N, d, seed); src = hard_clustered(900, d, seed + 1, intra=0.7)
+        h = rerank.re_ranking_device(torch.from_numpy(src).to(dev), torch.from_numpy(tgt).to(dev), lambda_value=0.3)
+        args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
+        stride, rho = max(1, N // 192), 1.6e-3
+        hist = torch.zeros(2 * 4097, dtype=torch.int64, device=dev); thr = torch.zeros(5, dtype=torch.int64, device=dev)
+        check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist[:4097]), stream()), "hist")
+        check(L.ssg_eps_select_threshold(ptr(hist[:4097]), 1.3 * rho, ptr(thr), stream()), "select")
+        check(L.ssg_eps_sample_hist(*args, stride, ptr(thr), ptr(hist[4097:]), stream()), "hist2")
+        check(L.ssg_eps_refine_threshold(ptr(hist[4097:]), ptr(thr), stream()), "refine")
+        ref_thr, ref_hist = thr.cpu().numpy().copy(), hist.cpu().numpy().copy()
+        assert np.isfinite(np.uint32(ref_thr[0]).view(np.float32)) and ref_thr[1] > 1000
+        for rep in range(30):
+            junk = torch.randn(1 << 20, device=dev).sin_()                              # (other work in flight on the stream)
+            z = torch.zeros(2 * 4097 + 5 + 1 + 1024, dtype=torch.int64, device=dev)
+            check(L.ssg_eps_sample_threshold(*args, stride, 1.3 * rho, ptr(z[:8194]), ptr(z[8194:8199]), ptr(z[8199:8200]), ptr(z[8200:]), stream()), "fused")
+            got = z.cpu().numpy()
+            # the splitters derived from the histogram: ascending float64 bit patterns below the (coarse) threshold
+            sp_ = got[8200:8200 + 1023].view(np.uint64)
+            fin = sp_[sp_ != np.uint64(0xFFFFFFFFFFFFFFFF)].view(np.float64)
+            assert len(fin) > 900 and np.all(np.diff(fin) >= 0) and fin[0] > 0 and fin[-1] <= float(np.uint32(ref_thr[0]).view(np.float32)) * 1.01, rep
+            assert np.array_equal(got[:8194], ref_hist), rep
+            assert np.array_equal(got[8194:8199], ref_thr), (rep, got[8194:8199], ref_thr)
+            assert got[8199] == (int(got[8199]) & 0xffffffff) + ((int(got[8199]) >> 32) << 32) and (int(got[8199]) & 0xffffffff) == (int(got[8199]) >> 32) > 0   # both tickets = the grid size
+            del junk
+        # the checks inside the tree kernel: same status words and the same eps as the two launches
+        top = int(np.round(rho * (N * (N - 1) // 2)))
+        n_cap = 1 << 20
+        buf = torch.empty(n_cap, dtype=torch.int64, device=dev); cursor = torch.zeros(3, dtype=torch.int64, device=dev)
+        check(L.ssg_eps_compact_below(*args, ptr(thr), ptr(buf), n_cap, ptr(cursor), stream()), "compact")
+        check(L.ssg_sort_u64_dev(ptr(buf), n_cap, ptr(cursor), stream()), "sort")
+        wsb = int(L.ssg_eps_mean_workspace_bytes(top)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        check(L.ssg_eps_mean_prepare(top, ptr(ws), wsb, stream()), "prepare")
+        outs = []
+        for fused in (False, True):
+            eps2 = torch.zeros(2, dtype=torch.float64, device=dev); st6 = torch.zeros(6, dtype=torch.int64, device=dev)
+            if fused:
+                check(L.ssg_eps_mean_check(ptr(buf), top, 0, ptr(ws), wsb, ptr(eps2), ptr(cursor), ptr(thr), rho, N * (N - 1) // 2, n_cap, ptr(st6), None, stream()), "mean_check")
+            else:
+                check(L.ssg_eps_mean_run(ptr(buf), top, 0, ptr(ws), wsb, ptr(eps2), stream()), "mean")
+                check(L.ssg_eps_check(ptr(buf), ptr(cursor), ptr(thr), rho, N * (N - 1) // 2, top, n_cap, ptr(eps2), ptr(st6), None, stream()), "check")
+            outs.append((eps2.cpu().numpy().view(np.int64).copy(), st6.cpu().numpy().copy()))
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][1][0] == 1
+        # ... and a failing check (a top that is not the tree's) poisons eps in both forms
+        eps2 = torch.zeros(2, dtype=torch.float64, device=dev); st6 = torch.zeros(6, dtype=torch.int64, device=dev)
+        check(L.ssg_eps_mean_check(ptr(buf), top, 0, ptr(ws), wsb, ptr(eps2), ptr(cursor), ptr(thr), 2.0 * rho, N * (N - 1) // 2, n_cap, ptr(st6), None, stream()), "mean_check")
+        assert int(st6[0].item()) == 0 and np.isnan(eps2[0].item())
+
+
 def test_sort_u64_dev_sorts_the_device_count(dev):
     """ssg_sort_u64_dev: buf[0 .. *n_dev) sorted inside a buffer of n_cap entries for counts around the powers of two, 0 and n_cap"""
     from ssg_amd import _lib
