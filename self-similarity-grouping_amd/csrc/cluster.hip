@@ -555,10 +555,20 @@ template <int MODE>
 __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const unsigned long long* __restrict__ thr3, unsigned long long* __restrict__ buf,
                                                               unsigned long long cap, unsigned long long* __restrict__ cursor,
                                                               const unsigned long long* __restrict__ gate, const unsigned char* __restrict__ rowmask) {
-  __shared__ unsigned long long sbuf[4][STAGE_CAP];
+  // key stage (768 keys per wave: the generic path appends up to 512 at once) + candidate-column stage of the fast path (see below):
+  // 33.4 KB per workgroup, four workgroups per CU
+  constexpr int KCAP = 768, CCAP = 64 + 512;
+#ifndef SSG_DENSE_PIPE
+#define SSG_DENSE_PIPE 8
+#endif
+  constexpr int DPIPE = SSG_DENSE_PIPE;          // chunks in flight per wave in the fast path
+  __shared__ unsigned long long sbuf[4][KCAP];
+  __shared__ unsigned int cidx_s[4][CCAP];
   if (gate && *gate == 0ull) return;          // the sparse pass queued in front of this launch has done every row
   const int lane = lane_id();
   WaveStage<unsigned long long> st{sbuf[threadIdx.x >> 6], 0};
+  unsigned int* cidx = cidx_s[threadIdx.x >> 6];
+  int nci = 0;                                 // staged candidate columns of the current row (wave-uniform)
   const float thr = __uint_as_float((unsigned)thr3[0]);
   const float lam32 = (float)mv.lambda_value;
   unsigned long long zeros = 0;
@@ -603,7 +613,24 @@ __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const 
 #pragma unroll
     for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) st.buf[w++] = keys[e];
     st.n += tot;
-    if (st.n > STAGE_CAP - 512) st.flush(buf, cap, cursor, lane);
+    if (st.n > KCAP - 512) st.flush(buf, cap, cursor, lane);
+  };
+  // the top `m` (<= 64) staged candidates (J' half | v_k half << 16) of a row -> exact float64 keys (exact zeros are counted, not kept) -> key stage
+  auto finish = [&](const hbits* __restrict__ Mrow, hbits vi, int m) {
+    (void)Mrow;
+    unsigned long long key = ~0ULL; bool keep = false;
+    if (lane < m) {
+      const unsigned pk = cidx[nci - m + lane];
+      const double d = final_dist_value((hbits)(pk & 0xffffu), vi, (hbits)(pk >> 16), mv.lambda_value);
+      if (d != 0.0) { key = (unsigned long long)__double_as_longlong(d); keep = true; }
+      else zeros++;
+    }
+    const uint64_t bm = __ballot(keep);
+    if (keep) st.buf[st.n + __popcll(bm & lanemask_lt())] = key;
+    st.n += __popcll(bm);
+    nci -= m;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (st.n > KCAP - 512) st.flush(buf, cap, cursor, lane);
   };
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   const bool fast_ok = MODE == 0 && (mv.N & 7) == 0 && thr > 0.f;
@@ -628,16 +655,16 @@ __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const 
       const h2 vi2 = {vi16, vi16};
       const int nfull = mv.N / 512;
       if (c0 < rs.nchunks) generic_chunk(rs, c0, gi, vi, nullptr);
-      for (int cb = c0 + 1; cb < nfull; cb += PIPE) {
-        uint4 xjs[PIPE], xvs[PIPE];
+      for (int cb = c0 + 1; cb < nfull; cb += DPIPE) {
+        uint4 xjs[DPIPE], xvs[DPIPE];
 #pragma unroll
-        for (int u = 0; u < PIPE; u++) {
+        for (int u = 0; u < DPIPE; u++) {
           const int j0 = min(cb + u, nfull - 1) * 512 + lane * 8;
           xjs[u] = *reinterpret_cast<const uint4*>(M + j0);
           xvs[u] = *reinterpret_cast<const uint4*>(mv.v + j0);
         }
 #pragma unroll
-        for (int u = 0; u < PIPE; u++) {
+        for (int u = 0; u < DPIPE; u++) {
           const int c = cb + u;
           if (c >= nfull) break;
           const unsigned wj[4] = {xjs[u].x, xjs[u].y, xjs[u].z, xjs[u].w}, wv[4] = {xvs[u].x, xvs[u].y, xvs[u].z, xvs[u].w};
@@ -649,29 +676,37 @@ __global__ __launch_bounds__(256) void eps_compact_thr_kernel(MatView mv, const 
             const float a = (float)j2.x + (float)s2.x * lam32, b = (float)j2.y + (float)s2.y * lam32;
             cand |= (a < thr ? 1u : 0u) << (2 * q) | (b < thr ? 1u : 0u) << (2 * q + 1);
           }
-          if (!__any(cand != 0)) continue;
-          RawChunk raw; raw.m = xjs[u]; raw.v = xvs[u];
-          double dv[8];
-          decode_raw<0>(mv, raw, vi, dv);
-          unsigned long long keys[8]; int n = 0;
-#pragma unroll
-          for (int e = 0; e < 8; e++) {
-            keys[e] = ~0ULL;
-            if ((cand >> e) & 1u) {
-              if (dv[e] != 0.0) { keys[e] = (unsigned long long)__double_as_longlong(dv[e]); n++; }
-              else zeros++;
+          // Round 6: at the 1.3 rho quantile about two chunks in three hold a candidate, so the "rare" path ran for most chunks -- and it
+          // rebuilt the float64 value of all 8 x 64 elements of the chunk for that one candidate (the pass streamed at 2.4-2.9 TB/s
+          // against 4.5-5.1 with a threshold nothing lies below).  Now a chunk only stages the two HALVES of each candidate (J' and v_k);
+          // the exact float64 keys are built 64 candidates at a time, one per lane (`finish`).
+          const int n = __popc(cand);
+          const uint64_t bm = __ballot(n != 0);
+          if (bm == 0) continue;
+          // (staged: the two halves the key is made of -- J' and v_k --, not the column: `finish` needs no load)
+          if (!__any(n > 1)) {
+            // the usual case, one candidate in each of a few lanes: the slot is the lane's rank among them (two mbcnt instructions, no scan)
+            if (n) {
+              const int e = __ffs((int)cand) - 1, sh = (e & 1) * 16;
+              const unsigned pj = e < 4 ? (e < 2 ? wj[0] : wj[1]) : (e < 6 ? wj[2] : wj[3]), pv = e < 4 ? (e < 2 ? wv[0] : wv[1]) : (e < 6 ? wv[2] : wv[3]);
+              cidx[nci + __popcll(bm & lanemask_lt())] = ((pj >> sh) & 0xffffu) | (((pv >> sh) & 0xffffu) << 16);
             }
-          }
-          int incl = n;
-          for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
-          const int tot = __shfl(incl, 63, 64);
-          int w = st.n + incl - n;
+            nci += __popcll(bm);
+          } else {
+            int incl = n;
+            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(incl, sh, 64); if (lane >= sh) incl += o; }
+            const int tot = __shfl(incl, 63, 64);
+            int w = nci + incl - n;
 #pragma unroll
-          for (int e = 0; e < 8; e++) if (keys[e] != ~0ULL) st.buf[w++] = keys[e];
-          st.n += tot;
-          if (st.n > STAGE_CAP - 512) st.flush(buf, cap, cursor, lane);
+            for (int e = 0; e < 8; e++)
+              if ((cand >> e) & 1u) cidx[w++] = ((wj[e >> 1] >> ((e & 1) * 16)) & 0xffffu) | (((wv[e >> 1] >> ((e & 1) * 16)) & 0xffffu) << 16);
+            nci += tot;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          while (nci >= 64) finish(M, vi, 64);
         }
       }
+      if (nci) finish(M, vi, nci);                      // the row's last few candidates (vi is the row's)
       if (nfull * 512 < mv.N && nfull > c0) generic_chunk(rs, nfull, gi, vi, nullptr);
       continue;
     }
