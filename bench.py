@@ -478,8 +478,9 @@ def main():
         h_ = rerank.re_ranking_device(src_emb, tgt_emb, k1=20, k2=6, lambda_value=args.lambda_value, keep_euclid=False, validate=False,
                                       row0=row0, nrows=nrows, group=g_group)
         n_rr = sc.n
-        cluster.eps_rule_dbscan(h_, args.rho, min_samples=4)
+        res_ = cluster.eps_rule_dbscan(h_, args.rho, min_samples=4)
         n_ed = sc.n - n_rr
+    row_split = cluster.sparse_row_split(h_, args.rho, res_[0]) if g_group is None else None     # which path the rows of the sparse passes took (untimed)
     del h_
     host_syncs = {"rerank": n_rr, "eps_rule_dbscan": n_ed, "per_split": n_rr + n_ed, "world": world,
                   "what": "blocking device->host reads (item/tolist/cpu) of one grouping leg on rank 0: value ranges of the features (re-rank); ONE read for "
@@ -528,7 +529,7 @@ def main():
         roof.update(achieved=None, frac=None, launches=0, avg_launch_ms=None, launches_by_abi={}, traffic=None, note=note)
         hbm, k5_k12, hbm_ms = {"note": note}, {"note": note, "kernel_ms": None}, None
     else:
-        hbm, k5_k12 = grouping_roofline(tot, args.N, nrows, args.Ns, world, max(n_ev_steps, 1))
+        hbm, k5_k12 = grouping_roofline(tot, args.N, nrows, args.Ns, world, max(n_ev_steps, 1), row_split=row_split)
         hbm_ms = k5_k12["kernel_ms"]
     out = {
         "metric": "images/s embed + s/iter for NxN rerank+DBSCAN, N=16k, 1/2/4/8 GPU",

@@ -217,6 +217,11 @@ int ssg_eps_check(const uint64_t* sorted_keys, const uint64_t* cursor, const uin
  * *fail = 1 when a bucket between two splitters holds more than 16384 keys (buf is then a permutation of the keys, not sorted) */
 size_t ssg_samplesort_u64_workspace_bytes(uint64_t n_cap);
 int ssg_samplesort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, void* ws, size_t ws_bytes, uint64_t* fail, ssg_stream_t stream);
+/* round 6: a second geometry of the same sort for 4e5 .. 2.4e7 expected keys (4095 splitters out of a sorted sample of 16 384 keys, sorting
+ * buckets of up to 16 384 keys in 128 KB of LDS, 1024 threads): N = 128 000 collects 1.7e7 candidates, where the bitonic network over the
+ * whole array took 7.1 ms.  Same contract as ssg_samplesort_u64_dev (*fail = 1: a bucket beyond 16 384 keys), its own workspace size. */
+size_t ssg_samplesort_u64_big_workspace_bytes(uint64_t n_cap);
+int ssg_samplesort_u64_big_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, void* ws, size_t ws_bytes, uint64_t* fail, ssg_stream_t stream);
 /* round 6: the same sort on 1023 ascending splitters the caller already holds on the device (any monotone splitters sort correctly; balance is
  * the caller's business: a bucket beyond 16 384 keys sets *fail): three launches, no sample sort.  gcount2048 (2048 uint32) and *fail: zero on entry */
 int ssg_samplesort_u64_presplit_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, const uint64_t* splitters1023, uint32_t* gcount2048,

@@ -222,6 +222,41 @@ def _eps_tree(L, top, dev, st):
     return ws
 
 
+def sparse_row_split(X, rho, eps=None):
+    """Diagnostic (bench.py / tools/run_configs.py, untimed): how many rows of a re-rank handle the eps rule's one full pass and the region
+    query walk through the sparse copy S and how many they hand to the dense pass -> {'eps': (rows_sparse, rows_dense), 'region': (...)}.
+    Runs the two passes once more into scratch buffers and reads their row masks (a blocking read each); None without a sparse copy."""
+    L = _lib.lib()
+    h = as_handle(X)
+    sp = getattr(h, "sparse", None) if h.mode == 0 else None
+    if sp is None:
+        return None
+    h.validate()
+    dev, st, N = h.device, stream(), h.N
+    if not h.sparse_complete():
+        return {"eps": (0, h.nrows), "region": (0, h.nrows)}
+    args = (ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.mode, h.lambda_value)
+    z = torch.zeros(2 * 4097 + 5 + 1 + 3 + 2, dtype=torch.int64, device=dev)
+    thr3, cursor, ecur = z[8194:8199], z[8200:8203], z[8203:8205]
+    check(L.ssg_eps_sample_threshold(*args, max(1, h.nrows // 192), 1.3 * float(rho), ptr(z[:8194]), ptr(thr3), ptr(z[8199:8200]), None, st), "ssg_eps_sample_threshold")
+    n_cap = 1 << 16
+    buf = torch.empty(n_cap, dtype=torch.int64, device=dev)
+    mask = torch.zeros(h.nrows, dtype=torch.uint8, device=dev)
+    check(L.ssg_eps_compact_below_s(ptr(h.M), ptr(h.v), h.N, h.row0, h.nrows, h.lambda_value, ptr(thr3), ptr(buf), n_cap, ptr(cursor), ptr(sp["pool"]),
+                                    ptr(sp["seg_off"]), ptr(sp["seg_len"]), sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(mask), st), "ssg_eps_compact_below_s")
+    dense_e = int(mask.ne(0).sum().item())
+    out = {"eps": (h.nrows - dense_e, dense_e)}
+    if eps is not None:
+        cnt = torch.empty(h.nrows, dtype=torch.int32, device=dev)
+        edges = torch.empty((1 << 16, 2), dtype=torch.int32, device=dev)
+        mask.zero_()
+        check(L.ssg_region_query_s(ptr(h.M), ptr(h.v), N, h.row0, h.nrows, h.lambda_value, float(eps), ptr(sp["pool"]), ptr(sp["seg_off"]), ptr(sp["seg_len"]),
+                                   sp["nseg"], ptr(sp["cursor"]), ptr(sp["vmin"]), sp["jp0"], ptr(mask), ptr(cnt), ptr(edges), 1 << 16, ptr(ecur), st), "ssg_region_query_s")
+        dense_r = int(mask.ne(0).sum().item())
+        out["region"] = (h.nrows - dense_r, dense_r)
+    return out
+
+
 def _triangle_share(N, lo, hi):
     """fraction of the strict upper triangle of an N x N matrix that lies in rows [lo, hi)"""
     tot = N * (N - 1) // 2
@@ -286,9 +321,14 @@ def _eps_rule_dbscan_sharded(L, h, rho, min_samples, two_calls):
     gcur[1:2] = g_head[:, 1].sum()
     thrg[0:1] = g_head[:, 2].min()
     tree = _eps_tree(L, top_guess, dev, st)
-    if os.environ.get("SSG_EPS_SORT", "sample") == "bitonic" or qf * top_guess > 4.0e5:
+    if os.environ.get("SSG_EPS_SORT", "sample") == "bitonic" or qf * top_guess > 2.4e7 or 4.0e5 < qf * top_guess <= 4.0e6:
         check(L.ssg_sort_u64_dev(ptr(allk), n_pow2, ptr(ktot), st), "ssg_sort_u64_dev")
         sf = None
+    elif qf * top_guess > 4.0e6:
+        sws_bytes = int(L.ssg_samplesort_u64_big_workspace_bytes(n_pow2))
+        sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
+        check(L.ssg_samplesort_u64_big_dev(ptr(allk), n_pow2, ptr(ktot), ptr(sws), sws_bytes, ptr(sort_fail), st), "ssg_samplesort_u64_big_dev")
+        sf = sort_fail
     else:
         sws_bytes = int(L.ssg_samplesort_u64_workspace_bytes(n_pow2))
         sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
@@ -421,9 +461,17 @@ def eps_rule_dbscan(X, rho, min_samples=4):
     tree = _eps_tree(L, top_guess, dev, st)
     # sample sort (4 launches) while its 1024 sorting buckets stay LDS-sized: ~1.3 * top candidates expected, a bucket may run to 4x the
     # mean, 2048 keys fit -> up to 4e5 candidates (N = 16 000: 2.7e5); above that the bitonic network (25+ launches) as in round 4
-    if os.environ.get("SSG_EPS_SORT", "sample") == "bitonic" or 1.3 * top_guess * h.nrows / N > 4.0e5:
+    expect = 1.3 * top_guess * h.nrows / N
+    if os.environ.get("SSG_EPS_SORT", "sample") == "bitonic" or expect > 2.4e7 or 4.0e5 < expect <= 4.0e6:
         check(L.ssg_sort_u64_dev(ptr(buf), n_cap, ptr(cursor), st), "ssg_sort_u64_dev")
         sf = None
+    elif expect > 4.0e6:
+        # round 6: 4095 splitters, buckets of up to 16 384 keys sorted in 128 KB of LDS (N = 128 000: 1.7e7 candidates: 3.0 ms against 6.9 of the
+        # network; measured slower than the network below ~4e6 keys -- tools/time_sort.py -- so N = 30 000's 9.4e5 candidates keep the network)
+        sws_bytes = int(L.ssg_samplesort_u64_big_workspace_bytes(n_cap))
+        sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)
+        check(L.ssg_samplesort_u64_big_dev(ptr(buf), n_cap, ptr(cursor), ptr(sws), sws_bytes, ptr(sort_fail), st), "ssg_samplesort_u64_big_dev")
+        sf = sort_fail
     else:
         sws_bytes = int(L.ssg_samplesort_u64_workspace_bytes(n_cap))
         sws = torch.empty(sws_bytes, dtype=torch.uint8, device=dev)

@@ -1547,14 +1547,25 @@ extern "C" int ssg_sort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n
 // (First version, measured: ranking every key against the whole bucket in LDS = 73 us of dependent LDS reads, the sample's bitonic
 //  network with integer divisions in its index arithmetic = 51 us, a (workgroup x bucket) count matrix scanned by one workgroup = 17 us:
 //  171 us, slower than the network it was to replace.)
-constexpr int SS_SAMPLE = 4096, SS_NSPLIT = 1023, SS_NBK = 2 * (SS_NSPLIT + 1), SS_CHUNK = 4096, SS_CAP = 2048, SS_CAP_GLOBAL = 16384;
+// Two geometries (round 6): LB = 10 -- 1023 splitters out of a sorted sample of 4096 keys, chunks of 4096 keys per counting workgroup,
+// sorting buckets of up to 2048 keys (256 threads) -- while the expected number of keys stays below ~4e5 (LDS-sized buckets with a 4x
+// margin); LB = 12 -- 4095 splitters out of a sample of 16 384, chunks of 16 384, buckets of up to 16 384 keys in 128 KB of LDS (1024
+// threads, up to 16 keys per thread in registers) -- up to ~2.4e7 keys (N = 128 000: 1.7e7 candidates, 4.1 k per bucket on average), where
+// the bitonic network over the whole array took 7.1 ms.
+template <int LB> struct SsCfg {
+  static constexpr int NSLOT = 1 << LB, NSPLIT = NSLOT - 1, NBK = 2 * NSLOT, SAMPLE = 4 * NSLOT, CHUNK = LB == 10 ? 4096 : 16384;
+  static constexpr int CAP = LB == 10 ? 2048 : 16384, NTB = LB == 10 ? 256 : 1024;     // largest bucket sorted in LDS, threads of the bucket sort
+  static constexpr int CAP_GLOBAL = 16384;                                              // LB = 10: ranked out of global memory up to here; beyond: fail
+};
 struct SsWs { unsigned long long* tmp; unsigned long long* split; unsigned int* cmat; unsigned int* gcount; unsigned int* off; unsigned short* bid; };
+template <int LB>
 static size_t ss_layout(uint64_t n_cap, char* base, SsWs* w) {
+  using C = SsCfg<LB>;
   size_t o = 0;
-  const size_t G = (size_t)((n_cap + SS_CHUNK - 1) / SS_CHUNK);
+  const size_t G = (size_t)((n_cap + C::CHUNK - 1) / C::CHUNK);
   auto take = [&](size_t bytes) { const size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-  const size_t a_tmp = take((size_t)n_cap * 8), a_split = take(1024 * 8), a_cmat = take(G * SS_NBK * 4), a_gc = take(SS_NBK * 4), a_off = take((SS_NBK + 1) * 4),
-               a_bid = take((size_t)n_cap * 2);
+  const size_t a_tmp = take((size_t)n_cap * 8), a_split = take((size_t)C::NSLOT * 8), a_cmat = take(G * C::NBK * 4), a_gc = take((size_t)C::NBK * 4),
+               a_off = take(((size_t)C::NBK + 1) * 4), a_bid = take((size_t)n_cap * 2);
   if (w) {
     w->tmp = (unsigned long long*)(base + a_tmp); w->split = (unsigned long long*)(base + a_split); w->cmat = (unsigned int*)(base + a_cmat);
     w->gcount = (unsigned int*)(base + a_gc); w->off = (unsigned int*)(base + a_off); w->bid = (unsigned short*)(base + a_bid);
@@ -1607,46 +1618,54 @@ __device__ __forceinline__ void ss_bitonic_reg(unsigned long long (&v)[E], unsig
       }
     }
 }
+template <int LB>
 __global__ __launch_bounds__(1024) void ss_splitters_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap,
                                                             unsigned long long* __restrict__ split, unsigned int* __restrict__ gcount,
                                                             unsigned long long* __restrict__ fail) {
-  __shared__ unsigned long long s[SS_SAMPLE];
+  using C = SsCfg<LB>;
+  constexpr int E = C::SAMPLE / 1024;
+  __shared__ unsigned long long s[C::SAMPLE];
   const unsigned long long n = ss_count_of(n_dev, n_cap);
   const int t = (int)threadIdx.x;
   if (t == 0) *fail = 0ull;
-  gcount[t] = 0u; gcount[t + 1024] = 0u;
+  for (int q = t; q < C::NBK; q += 1024) gcount[q] = 0u;
   if (n == 0) return;
-  unsigned long long v[4];
+  unsigned long long v[E];
 #pragma unroll
-  for (int r = 0; r < 4; r++) v[r] = a[((unsigned long long)(4 * t + r) * n) >> 12];
-  ss_bitonic_reg<4, 1024>(v, s, t);
-  if (t < SS_NSPLIT) split[t] = v[3];                               // sorted sample keys 3, 7, .., 4091
+  for (int r = 0; r < E; r++) v[r] = a[((unsigned long long)(E * t + r) * n) >> (LB + 2)];        // (n < 2^31, sample index < 2^14)
+  ss_bitonic_reg<E, 1024>(v, s, t);
+  // sorted sample keys 3, 7, 11, ...: with E keys per thread the splitters of thread t are its keys 3, 7, ... (E = 4: one, E = 16: four)
+#pragma unroll
+  for (int r = 3; r < E; r += 4) { const int q = (E * t + r) >> 2; if (q < C::NSPLIT) split[q] = v[r]; }
 }
-// sp: 1024 entries in LDS, the 1023 splitters ascending + ~0
+// sp: NSLOT entries in LDS, the NSPLIT splitters ascending + ~0
+template <int NSLOT>
 __device__ __forceinline__ int ss_bucket(const unsigned long long* sp, unsigned long long key) {
   int lo = 0;
 #pragma unroll
-  for (int step = 512; step > 0; step >>= 1) lo += (sp[lo + step - 1] < key) ? step : 0;
+  for (int step = NSLOT / 2; step > 0; step >>= 1) lo += (sp[lo + step - 1] < key) ? step : 0;
   return 2 * lo + (sp[lo] == key ? 1 : 0);
 }
+template <int LB>
 __global__ __launch_bounds__(256) void ss_count_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap,
                                                        const unsigned long long* __restrict__ split, unsigned int* __restrict__ gcount,
                                                        unsigned int* __restrict__ cmat, unsigned short* __restrict__ bid) {
-  __shared__ unsigned long long sp[1024];
-  __shared__ unsigned int cn[SS_NBK];
+  using C = SsCfg<LB>;
+  __shared__ unsigned long long sp[C::NSLOT];
+  __shared__ unsigned int cn[C::NBK];
   const unsigned long long n = ss_count_of(n_dev, n_cap);
-  const unsigned long long g0 = (unsigned long long)blockIdx.x * SS_CHUNK;
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * C::CHUNK;
   if (g0 >= n) return;
   const int t = (int)threadIdx.x;
-  for (int q = t; q < 1024; q += 256) sp[q] = q < SS_NSPLIT ? split[q] : ~0ull;
-  for (int q = t; q < SS_NBK; q += 256) cn[q] = 0u;
+  for (int q = t; q < C::NSLOT; q += 256) sp[q] = q < C::NSPLIT ? split[q] : ~0ull;
+  for (int q = t; q < C::NBK; q += 256) cn[q] = 0u;
   __syncthreads();
-  for (int u = 0; u < SS_CHUNK / 256; u += 4) {
+  for (int u = 0; u < C::CHUNK / 256; u += 4) {
     unsigned long long key[4]; int b[4];
 #pragma unroll
     for (int v = 0; v < 4; v++) { const unsigned long long idx = g0 + (unsigned long long)(u + v) * 256 + t; key[v] = a[idx < n ? idx : n - 1]; }
 #pragma unroll
-    for (int v = 0; v < 4; v++) b[v] = ss_bucket(sp, key[v]);
+    for (int v = 0; v < 4; v++) b[v] = ss_bucket<C::NSLOT>(sp, key[v]);
 #pragma unroll
     for (int v = 0; v < 4; v++) {
       const unsigned long long idx = g0 + (unsigned long long)(u + v) * 256 + t;
@@ -1654,26 +1673,27 @@ __global__ __launch_bounds__(256) void ss_count_kernel(const unsigned long long*
     }
   }
   __syncthreads();
-  for (int q = t; q < SS_NBK; q += 256) {
+  for (int q = t; q < C::NBK; q += 256) {
     const unsigned int c = cn[q];
-    cmat[(size_t)blockIdx.x * SS_NBK + q] = c ? atomicAdd(&gcount[q], c) : 0u;       // this workgroup's base inside bucket q
+    cmat[(size_t)blockIdx.x * C::NBK + q] = c ? atomicAdd(&gcount[q], c) : 0u;       // this workgroup's base inside bucket q
   }
 }
-// (round 6: every workgroup scans the 2048 bucket counts itself -- 8 per thread + a 256-entry LDS scan, ~1 us -- instead of waiting for a
+// (round 6: every workgroup scans the bucket counts itself -- NBK / 256 per thread + a 256-entry LDS scan, ~1 us -- instead of waiting for a
 //  one-workgroup scan launch in between; workgroup 0 also leaves the offsets in `off` for the bucket sort)
+template <int LB>
 __global__ __launch_bounds__(256) void ss_scatter_kernel(const unsigned long long* __restrict__ a, const unsigned long long* __restrict__ n_dev, unsigned long long n_cap,
                                                          const unsigned int* __restrict__ cmat, const unsigned int* __restrict__ gcount, unsigned int* __restrict__ off,
                                                          const unsigned short* __restrict__ bid, unsigned long long* __restrict__ tmp) {
-  __shared__ unsigned int cur[SS_NBK];
+  using C = SsCfg<LB>;
+  constexpr int PT = C::NBK / 256;                      // bucket counts per thread: 8 or 32
+  __shared__ unsigned int cur[C::NBK];
   __shared__ unsigned int psum[256];
   const unsigned long long n = ss_count_of(n_dev, n_cap);
-  const unsigned long long g0 = (unsigned long long)blockIdx.x * SS_CHUNK;
+  const unsigned long long g0 = (unsigned long long)blockIdx.x * C::CHUNK;
   if (g0 >= n && blockIdx.x != 0) return;
   const int t = (int)threadIdx.x;
-  static_assert(SS_NBK == 8 * 256, "eight bucket counts per thread");
-  unsigned int gc[8], mine = 0;
-#pragma unroll
-  for (int u = 0; u < 8; u++) { gc[u] = gcount[8 * t + u]; mine += gc[u]; }
+  unsigned int mine = 0;
+  for (int u = 0; u < PT; u++) mine += gcount[PT * t + u];
   psum[t] = mine;
   __syncthreads();
   for (int o = 1; o < 256; o <<= 1) {
@@ -1683,16 +1703,16 @@ __global__ __launch_bounds__(256) void ss_scatter_kernel(const unsigned long lon
     __syncthreads();
   }
   unsigned int run = psum[t] - mine;
-#pragma unroll
-  for (int u = 0; u < 8; u++) {
-    cur[8 * t + u] = run + cmat[(size_t)blockIdx.x * SS_NBK + 8 * t + u];
-    if (blockIdx.x == 0) off[8 * t + u] = run;
-    run += gc[u];
+  for (int u = 0; u < PT; u++) {
+    const unsigned int gc = gcount[PT * t + u];
+    cur[PT * t + u] = run + (g0 < n ? cmat[(size_t)blockIdx.x * C::NBK + PT * t + u] : 0u);
+    if (blockIdx.x == 0) off[PT * t + u] = run;
+    run += gc;
   }
-  if (blockIdx.x == 0 && t == 255) off[SS_NBK] = run;
+  if (blockIdx.x == 0 && t == 255) off[C::NBK] = run;
   if (g0 >= n) return;                      // (workgroup 0 of an empty input: only the offsets)
   __syncthreads();
-  for (int u = 0; u < SS_CHUNK / 256; u += 4) {
+  for (int u = 0; u < C::CHUNK / 256; u += 4) {
     unsigned long long key[4]; int b[4];
 #pragma unroll
     for (int v = 0; v < 4; v++) {
@@ -1706,71 +1726,80 @@ __global__ __launch_bounds__(256) void ss_scatter_kernel(const unsigned long lon
     }
   }
 }
-__global__ __launch_bounds__(256) void ss_bucket_sort_kernel(const unsigned long long* __restrict__ tmp, const unsigned int* __restrict__ off,
-                                                             unsigned long long* __restrict__ out, unsigned long long* __restrict__ fail) {
-  __shared__ unsigned long long s[SS_CAP];
+template <int LB>
+__global__ __launch_bounds__(SsCfg<LB>::NTB) void ss_bucket_sort_kernel(const unsigned long long* __restrict__ tmp, const unsigned int* __restrict__ off,
+                                                                        unsigned long long* __restrict__ out, unsigned long long* __restrict__ fail) {
+  using C = SsCfg<LB>;
+  constexpr int NTB = C::NTB;
+  __shared__ unsigned long long s[C::CAP];
   const int b = (int)blockIdx.x, t = (int)threadIdx.x;
   const unsigned int s0 = off[b];
   const int len = (int)(off[b + 1] - s0);
   if (len <= 0) return;
-  if ((b & 1) || len == 1 || len > SS_CAP_GLOBAL) {                 // all keys equal (a splitter's own bucket) / one key / hopeless: copy
-    for (int q = t; q < len; q += 256) out[s0 + q] = tmp[s0 + q];
-    if (!(b & 1) && len > SS_CAP_GLOBAL && t == 0) atomicOr(fail, 1ull);
+  const bool hopeless = LB == 10 ? len > C::CAP_GLOBAL : len > C::CAP;
+  if ((b & 1) || len == 1 || hopeless) {                             // all keys equal (a splitter's own bucket) / one key / hopeless: copy
+    for (int q = t; q < len; q += NTB) out[s0 + q] = tmp[s0 + q];
+    if (!(b & 1) && hopeless && t == 0) atomicOr(fail, 1ull);
     return;
   }
-  if (len <= SS_CAP) {
-    // 256 * E keys (E = 1, 2, 4, 8: the power of two that holds the bucket), padded with ~0
+  if (len <= C::CAP) {
+    // NTB * E keys (E = the power of two that holds the bucket), padded with ~0, the network in registers
 #define SS_BUCKET(E_)                                                                                          \
     {                                                                                                          \
       unsigned long long v[E_];                                                                                \
       _Pragma("unroll") for (int r = 0; r < E_; r++) { const int e = t * E_ + r; v[r] = e < len ? tmp[s0 + e] : ~0ull; } \
-      ss_bitonic_reg<E_, 256>(v, s, t);                                                                        \
+      ss_bitonic_reg<E_, NTB>(v, s, t);                                                                        \
       _Pragma("unroll") for (int r = 0; r < E_; r++) { const int e = t * E_ + r; if (e < len) out[s0 + e] = v[r]; }      \
     }
-    if (len <= 256) SS_BUCKET(1) else if (len <= 512) SS_BUCKET(2) else if (len <= 1024) SS_BUCKET(4) else SS_BUCKET(8)
+    if (len <= NTB) SS_BUCKET(1) else if (len <= 2 * NTB) SS_BUCKET(2) else if (len <= 4 * NTB) SS_BUCKET(4) else if (len <= 8 * NTB) SS_BUCKET(8)
+    else if constexpr (C::CAP >= 16 * NTB) SS_BUCKET(16)
 #undef SS_BUCKET
     return;
   }
-  for (int q = t; q < len; q += 256) {                                // an oversized bucket: every key ranked against the bucket out of global memory
+  for (int q = t; q < len; q += NTB) {                                // (LB = 10) an oversized bucket: every key ranked against the bucket out of global memory
     const unsigned long long key = tmp[s0 + q];
     int rank = 0;
     for (int j = 0; j < len; j++) { const unsigned long long kj = tmp[s0 + j]; rank += (kj < key || (kj == key && j < q)) ? 1 : 0; }
     out[s0 + rank] = key;
   }
 }
-extern "C" size_t ssg_samplesort_u64_workspace_bytes(uint64_t n_cap) { return ss_layout(n_cap, nullptr, nullptr); }
+template <int LB>
+static int samplesort_impl(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, const uint64_t* splitters, uint32_t* gcount_ext, void* ws, size_t ws_bytes,
+                           uint64_t* fail, hipStream_t stream) {
+  using C = SsCfg<LB>;
+  SsWs w;
+  if (ss_layout<LB>(n_cap, (char*)ws, &w) > ws_bytes) { ssg_set_error("sample sort: workspace too small"); return SSG_ERR_INVALID; }
+  unsigned long long* a = (unsigned long long*)buf;
+  const unsigned long long* nd = (const unsigned long long*)n_dev;
+  const unsigned G = (unsigned)((n_cap + C::CHUNK - 1) / C::CHUNK);
+  const unsigned long long* sp = splitters ? (const unsigned long long*)splitters : w.split;
+  unsigned int* gc = gcount_ext ? gcount_ext : w.gcount;
+  if (!splitters) hipLaunchKernelGGL(ss_splitters_kernel<LB>, dim3(1), dim3(1024), 0, stream, a, nd, (unsigned long long)n_cap, w.split, w.gcount, (unsigned long long*)fail);
+  hipLaunchKernelGGL(ss_count_kernel<LB>, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, sp, gc, w.cmat, w.bid);
+  hipLaunchKernelGGL(ss_scatter_kernel<LB>, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.cmat, (const unsigned int*)gc, w.off, w.bid, w.tmp);
+  hipLaunchKernelGGL(ss_bucket_sort_kernel<LB>, dim3(C::NBK), dim3(C::NTB), 0, stream, w.tmp, w.off, a, (unsigned long long*)fail);
+  SSG_LAUNCH_CHECK("sample sort (device-sized)");
+  return SSG_OK;
+}
+extern "C" size_t ssg_samplesort_u64_workspace_bytes(uint64_t n_cap) { return ss_layout<10>(n_cap, nullptr, nullptr); }
 // ascending sort of buf[0 .. min(*n_dev, n_cap)) in place (through ws); *fail = 1 when a bucket could not be sorted (more than 16384 keys
 // strictly between two neighbouring splitters: the sample missed the distribution) -- buf then holds a permutation of the keys, not sorted.
 extern "C" int ssg_samplesort_u64_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, void* ws, size_t ws_bytes, uint64_t* fail, hipStream_t stream) {
   if (!buf || !n_dev || !ws || !fail || n_cap == 0 || n_cap > (1ull << 31)) { ssg_set_error("ssg_samplesort_u64_dev: bad arguments"); return SSG_ERR_INVALID; }
-  SsWs w;
-  if (ss_layout(n_cap, (char*)ws, &w) > ws_bytes) { ssg_set_error("ssg_samplesort_u64_dev: workspace too small"); return SSG_ERR_INVALID; }
-  unsigned long long* a = (unsigned long long*)buf;
-  const unsigned long long* nd = (const unsigned long long*)n_dev;
-  const unsigned G = (unsigned)((n_cap + SS_CHUNK - 1) / SS_CHUNK);
-  hipLaunchKernelGGL(ss_splitters_kernel, dim3(1), dim3(1024), 0, stream, a, nd, (unsigned long long)n_cap, w.split, w.gcount, (unsigned long long*)fail);
-  hipLaunchKernelGGL(ss_count_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.split, w.gcount, w.cmat, w.bid);
-  hipLaunchKernelGGL(ss_scatter_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.cmat, w.gcount, w.off, w.bid, w.tmp);
-  hipLaunchKernelGGL(ss_bucket_sort_kernel, dim3(SS_NBK), dim3(256), 0, stream, w.tmp, w.off, a, (unsigned long long*)fail);
-  SSG_LAUNCH_CHECK("sample sort (device-sized)");
-  return SSG_OK;
+  return samplesort_impl<10>(buf, n_cap, n_dev, nullptr, nullptr, ws, ws_bytes, fail, stream);
 }
-
-// round 6: the same sort on splitters the caller already has on the device (ssg_eps_sample_threshold derives them from its histogram):
+// round 6: the LB = 12 geometry (see above) for 4e5 .. 2.4e7 expected keys; same contract, its own workspace size
+extern "C" size_t ssg_samplesort_u64_big_workspace_bytes(uint64_t n_cap) { return ss_layout<12>(n_cap, nullptr, nullptr); }
+extern "C" int ssg_samplesort_u64_big_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, void* ws, size_t ws_bytes, uint64_t* fail, hipStream_t stream) {
+  if (!buf || !n_dev || !ws || !fail || n_cap == 0 || n_cap > (1ull << 31)) { ssg_set_error("ssg_samplesort_u64_big_dev: bad arguments"); return SSG_ERR_INVALID; }
+  return samplesort_impl<12>(buf, n_cap, n_dev, nullptr, nullptr, ws, ws_bytes, fail, stream);
+}
+// round 6: the LB = 10 sort on splitters the caller already has on the device (ssg_eps_sample_threshold derives them from its histogram):
 // three launches, no sample.  gcount2048 (2048 uint32) and *fail must be ZERO on entry (the caller's one zero-filled allocation).
 extern "C" int ssg_samplesort_u64_presplit_dev(uint64_t* buf, uint64_t n_cap, const uint64_t* n_dev, const uint64_t* splitters1023, uint32_t* gcount2048,
                                                void* ws, size_t ws_bytes, uint64_t* fail, hipStream_t stream) {
   if (!buf || !n_dev || !ws || !fail || !splitters1023 || !gcount2048 || n_cap == 0 || n_cap > (1ull << 31)) { ssg_set_error("ssg_samplesort_u64_presplit_dev: bad arguments"); return SSG_ERR_INVALID; }
-  SsWs w;
-  if (ss_layout(n_cap, (char*)ws, &w) > ws_bytes) { ssg_set_error("ssg_samplesort_u64_presplit_dev: workspace too small"); return SSG_ERR_INVALID; }
-  unsigned long long* a = (unsigned long long*)buf;
-  const unsigned long long* nd = (const unsigned long long*)n_dev;
-  const unsigned G = (unsigned)((n_cap + SS_CHUNK - 1) / SS_CHUNK);
-  hipLaunchKernelGGL(ss_count_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, (const unsigned long long*)splitters1023, gcount2048, w.cmat, w.bid);
-  hipLaunchKernelGGL(ss_scatter_kernel, dim3(G), dim3(256), 0, stream, a, nd, (unsigned long long)n_cap, w.cmat, (const unsigned int*)gcount2048, w.off, w.bid, w.tmp);
-  hipLaunchKernelGGL(ss_bucket_sort_kernel, dim3(SS_NBK), dim3(256), 0, stream, w.tmp, w.off, a, (unsigned long long*)fail);
-  SSG_LAUNCH_CHECK("sample sort (device-sized, given splitters)");
-  return SSG_OK;
+  return samplesort_impl<10>(buf, n_cap, n_dev, splitters1023, gcount2048, ws, ws_bytes, fail, stream);
 }
 
 // The a-posteriori checks of the sampled eps rule (ssg_amd/cluster.py _eps_rule_sampled) on the device, one thread:

@@ -400,6 +400,30 @@ def test_samplesort_u64_dev_sorts_the_device_count(dev):
                 assert int(fail.item()) == 0, (name, n_cap, n)
                 assert torch.equal(out[:n], torch.sort(keys[:n]).values), (name, n_cap, n)
                 assert torch.equal(out[n:], keys[n:]), (name, n_cap, n)
+    # round 6: the second geometry (4095 splitters out of a sample of 16 384, buckets of up to 16 384 keys in LDS) on larger lists
+    for n_cap in (1, 40000, 1 << 21):
+        wsb = int(L.ssg_samplesort_u64_big_workspace_bytes(n_cap))
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        fail = torch.full((1,), 5, dtype=torch.int64, device=dev)
+        makers = {
+            "uniform": lambda: torch.randint(0, 1 << 62, (n_cap,), generator=g, dtype=torch.int64),
+            "crowded doubles": lambda: (0.9 - 0.9 * torch.rand(n_cap, generator=g, dtype=torch.float64) ** 8).view(torch.int64),
+            "few distinct": lambda: torch.randint(0, 300, (n_cap,), generator=g, dtype=torch.int64) * 1000003,
+            "all equal": lambda: torch.full((n_cap,), 424242, dtype=torch.int64),
+            "sorted": lambda: torch.arange(n_cap, dtype=torch.int64) * 3,
+        }
+        for name, mk in makers.items():
+            for n in sorted({0, 1, 3, 16383, 16384, 16385, 65537, n_cap - 1, n_cap}):
+                if n < 0 or n > n_cap:
+                    continue
+                keys = mk()
+                buf = keys.to(dev)
+                nd = torch.tensor([n, 7, 9], dtype=torch.int64, device=dev)
+                check(L.ssg_samplesort_u64_big_dev(ptr(buf), n_cap, ptr(nd), ptr(ws), wsb, ptr(fail), stream()), "ssg_samplesort_u64_big_dev")
+                out = buf.cpu()
+                assert int(fail.item()) == 0, (name, n_cap, n)
+                assert torch.equal(out[:n], torch.sort(keys[:n]).values), (name, n_cap, n)
+                assert torch.equal(out[n:], keys[n:]), (name, n_cap, n)
     # a count above the capacity is clamped (the eps check reports it)
     n_cap = 5000
     wsb = int(L.ssg_samplesort_u64_workspace_bytes(n_cap)); ws = torch.empty(wsb, dtype=torch.uint8, device=dev)

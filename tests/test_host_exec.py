@@ -47,7 +47,7 @@ def hx(tmp_path_factory):
             cut("cluster.hip", "__device__ __forceinline__ float sur_bin_upper"),
             cut("topk_intro.hip", "constexpr uint32_t KEY_NAN"),
             cut("topk_intro.hip", "__device__ __forceinline__ uint32_t norm_key"),
-            cut("cluster.hip", "__device__ __forceinline__ int ss_bucket")]
+            "template <int NSLOT>\n" + cut("cluster.hip", "__device__ __forceinline__ int ss_bucket")]
     assert "sqrt_units48_to_half" in text[0]
     (d / "rules_cut.inc").write_text("\n".join(text))
     (d / "preprocess_cut.inc").write_text(cut("preprocess.hip", "__global__ __launch_bounds__(256) void resize_h_u8_kernel") + "\n" +

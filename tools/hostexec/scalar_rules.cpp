@@ -83,7 +83,7 @@ void hx_norm_key(const uint32_t* raw, float fmx, long n, uint32_t* out) { for (l
 void hx_sur_bin(const float* x, long n, int* out) { for (long i = 0; i < n; i++) out[i] = sur_bin(x[i]); }
 float hx_sur_bin_upper(int b) { return sur_bin_upper(b); }
 // bucket rule of the device-sized sample sort (cluster.hip ss_bucket): table = 1023 ascending splitters + ~0
-void hx_ss_bucket(const unsigned long long* table, const unsigned long long* keys, long n, int* out) { for (long i = 0; i < n; i++) out[i] = ss_bucket(table, keys[i]); }
+void hx_ss_bucket(const unsigned long long* table, const unsigned long long* keys, long n, int* out) { for (long i = 0; i < n; i++) out[i] = ss_bucket<1024>(table, keys[i]); }
 // the two resize kernels of preprocess.hip (grid-stride, one thread here): uint8 [B,h,w,3] -> float32 [B,3,H,W]
 void hx_preprocess(const uint8_t* src, int B, int h, int w, int H, int W, const int32_t* xmin, const int32_t* xcnt, const int32_t* kkx, int ksx,
                    const int32_t* ymin, const int32_t* ycnt, const int32_t* kky, int ksy, const float* m, const float* sd, uint8_t* tmp, float* out) {

@@ -12,7 +12,8 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec
 
 K5_K12 = ("ssg_topk_rank", "ssg_topk_rank_introsort", "ssg_krecip", "ssg_query_expand", "ssg_invert_index", "ssg_jaccard_rows", "ssg_jaccard_rows2", "ssg_half_min",
           "ssg_eps_hist", "ssg_eps_compact", "ssg_eps_sample_hist", "ssg_eps_select_threshold", "ssg_eps_refine_threshold", "ssg_eps_compact_below",
-          "ssg_eps_compact_below_s", "ssg_fill_u64", "ssg_sort_u64", "ssg_sort_u64_dev", "ssg_samplesort_u64_dev", "ssg_eps_check", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_region_query_s",
+          "ssg_eps_compact_below_s", "ssg_fill_u64", "ssg_sort_u64", "ssg_sort_u64_dev", "ssg_samplesort_u64_dev", "ssg_samplesort_u64_big_dev", "ssg_samplesort_u64_presplit_dev", "ssg_eps_sample_threshold", "ssg_eps_mean_check",
+          "ssg_concat_segments_u64", "ssg_eps_check", "ssg_eps_mean", "ssg_eps_mean_run", "ssg_region_query", "ssg_region_query_s",
           "ssg_region_query_dev", "ssg_region_query_s_dev", "ssg_dbscan_cc",
           "ssg_dbscan_cc_dev")
 
@@ -43,10 +44,12 @@ class KernelTimer:
 
 
 
-def grouping_roofline(tot, N, nrows, Ns, world, steps, d=2048):
+def grouping_roofline(tot, N, nrows, Ns, world, steps, d=2048, row_split=None):
     """tot = KernelTimer.totals() of `steps` grouping legs on a row block of `nrows` of N rows -> (roofline_kernels list, roofline_k5_k12 dict):
     every N x N streaming kernel against its own 2*N^2 (or N^2) algorithmic bytes, the matrix-core kernels against the peak of
-    the instruction they execute, and K5..K12 together against 8*N^2 bytes."""
+    the instruction they execute, and K5..K12 together against 8*N^2 bytes.
+    row_split: {'eps': (rows through the sparse copy, rows through the dense pass), 'region': (...)} from cluster.sparse_row_split (round 6): the
+    sparse passes' objects then say which path the rows took, and a pass whose rows ALL went dense is listed as the streaming pass it was."""
     nn2 = 2.0 * nrows * N   # bytes of one half row block
     hbm = []
     for k, byt, what in (("ssg_topk_rank", nn2, "reads D (2*N^2 B); canonical (value, column) order, opt-in rank_mode='stable'"),
@@ -68,6 +71,12 @@ def grouping_roofline(tot, N, nrows, Ns, world, steps, d=2048):
         if k in tot:
             n, ms = tot[k]
             gbs = byt * n / (ms * 1e-3) / 1e9
+            split = (row_split or {}).get("eps" if "compact" in k else "region") if (k.endswith("_s") or k.endswith("_s_dev")) else None
+            if split is not None and split[0] == 0 and split[1] > 0:
+                # every row was flagged for the dense pass queued behind the sparse kernel: it WAS the streaming pass -- bandwidth and fraction apply
+                hbm.append({"kernel": k, "bound": "hbm", "what": what + " -- ALL rows took the dense pass here", "launches": n, "avg_launch_ms": round(ms / n, 4),
+                            "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "rows_sparse": 0, "rows_dense": int(split[1])})
+                continue
             if k.endswith("_s") or k.endswith("_s_dev"):
                 # the sparse passes do not stream the matrix: no bandwidth figure, no roofline fraction -- the bytes they no longer move
                 hbm.append({"kernel": k, "bound": "latency (L2 round trips over a few hundred packed words + gathers of v per row)", "what": what, "launches": n,
@@ -75,6 +84,9 @@ def grouping_roofline(tot, N, nrows, Ns, world, steps, d=2048):
                             "dense_pass_time_at_hbm_peak_ms": round(byt / (PEAK_HBM_GBS * 1e9) * 1e3, 4), "frac": None,
                             "note": "walks the sparse copy S instead of the N x N matrix; `bytes_avoided` = the algorithmic bytes of the dense pass it replaces "
                                     "(SURVEY.md 8d); a roofline fraction of bytes that are not moved would be meaningless (it exceeded 1 in round 4)"})
+                if split is not None:
+                    hbm[-1]["rows_sparse"], hbm[-1]["rows_dense"] = int(split[0]), int(split[1])
+                    hbm[-1]["bytes_avoided"] = int(byt * split[0] / max(split[0] + split[1], 1))
                 continue
             hbm.append({"kernel": k, "bound": "hbm", "what": what, "launches": n, "avg_launch_ms": round(ms / n, 4), "achieved": round(gbs, 1),
                         "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)})

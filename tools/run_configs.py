@@ -31,14 +31,15 @@ def group_roofline(src, tgt, lam, rho, splits=1):
         timer.on = True
         os.environ["SSG_RERANK_OVERLAP"] = "0"                  # one stream: an event pair brackets a launch that runs alone
         h = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=lam, keep_euclid=False, validate=False)
-        cluster.eps_rule_dbscan(h, rho, min_samples=4)          # the product's chain (generate_selflabel, iteration 0): one read-back
+        res = cluster.eps_rule_dbscan(h, rho, min_samples=4)    # the product's chain (generate_selflabel, iteration 0): one read-back
         tot = timer.totals()
     finally:
         _lib._lib = real
         os.environ.pop("SSG_RERANK_OVERLAP", None)
+    split = cluster.sparse_row_split(h, rho, res[0])            # (untimed) which path the rows of the two sparse passes took
     del h
     N, Ns = tgt.shape[0], src.shape[0]
-    kernels, k5 = grouping_roofline(tot, N, N, Ns, 1, 1, d=tgt.shape[1])
+    kernels, k5 = grouping_roofline(tot, N, N, Ns, 1, 1, d=tgt.shape[1], row_split=split)
     table = {k: {"launches": n, "ms": round(ms, 3)} for k, (n, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1])}
     return {"roofline_kernels": kernels, "roofline_k5_k12": k5, "abi_launch_ms": table, "all_abi_ms": round(sum(ms for _, ms in tot.values()), 3)}
 
