@@ -494,6 +494,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
   const float* __restrict__ resp = p.x + gpix0 * C;        // residual (identity blocks only)
   float* __restrict__ outp = p.out + gpix0 * C;
   float4 rr[2][ITS], b3r[2], cs3r[2];
+#ifdef SSG_BN_ABL_NORES                                  // ablation build (tools/micro/bneck_prof.hip): no residual read, wrong results
+#define SSG_BN_RESLOAD(P_) make_float4(0.f, 0.f, 0.f, 0.f)
+#else
+#define SSG_BN_RESLOAD(P_) (*reinterpret_cast<const float4*>(P_))
+#endif
   SSG_BN_STORE3(0, 0)
   SSG_BN_STORE3(1, 1)
   if constexpr (K::NK3 > 2) { SSG_BN_LOAD3(2, 0) SSG_BN_LOAD3(3, 1) }
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
       if constexpr ((R_) + 2 < K::NK3 / 2) { SSG_BN_LOAD3(2 * (R_) + 4, 0) SSG_BN_LOAD3(2 * (R_) + 5, 1) }           \
       else {                                 /* last round ahead: the W3 staging registers are free for the epilogue's first operands */ \
         if constexpr (!DS) {                                                                                         \
-          _Pragma("unroll") for (int it = 0; it < ITS; it++) rr[0][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + cb3 * 32 + chunk * 4); \
+          _Pragma("unroll") for (int it = 0; it < ITS; it++) rr[0][it] = SSG_BN_RESLOAD(resp + (int64_t)(it * RPI + prow) * C + cb3 * 32 + chunk * 4); \
         }                                                                                                            \
         b3r[0] = *reinterpret_cast<const float4*>(p.b3 + cb3 * 32 + chunk * 4); cs3r[0] = *reinterpret_cast<const float4*>(p.cs3 + cb3 * 32 + chunk * 4); \
       }                                                                                                              \
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
     if (j + 1 < NT3) {
       if constexpr (!DS) {
 #pragma unroll
-        for (int it = 0; it < ITS; it++) rr[(j + 1) & 1][it] = *reinterpret_cast<const float4*>(resp + (int64_t)(it * RPI + prow) * C + col + 32);
+        for (int it = 0; it < ITS; it++) rr[(j + 1) & 1][it] = SSG_BN_RESLOAD(resp + (int64_t)(it * RPI + prow) * C + col + 32);
       }
       b3r[(j + 1) & 1] = *reinterpret_cast<const float4*>(p.b3 + col + 32); cs3r[(j + 1) & 1] = *reinterpret_cast<const float4*>(p.cs3 + col + 32);
     }

@@ -23,6 +23,7 @@
 // k-step is permuted identically for A and W (the reduction does not care).
 #include "ssg_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace ssg {
 
@@ -83,7 +84,13 @@ struct ConvParams {
   // 1 = only the hi x hi product of the split-half operands (a plain fp16 GEMM: 1/3 of the matrix work, error 2^-10 |x||y|;
   // used by the source-term bound pass, whose tolerance covers it); 3 = the fp32-class three-product form
   int products = 3;
+  unsigned long long* prof = nullptr;   // SSG_DMA_PROF builds (tools/micro/conv_prof.hip): 8 s_memtime stamps per workgroup of conv_dma_kernel
 };
+#ifdef SSG_DMA_PROF
+#define SSG_DMA_STAMP(I_) { if (p.prof && threadIdx.x == 0) p.prof[(size_t)blockIdx.x * 8 + (I_)] = __builtin_readcyclecounter(); }
+#else
+#define SSG_DMA_STAMP(I_)
+#endif
 
 constexpr int CLD32 = 36;   // LDS row pitch in floats for BK=32 (BK=16 uses 20): pitch/4 odd -> conflict-free b128
 
@@ -566,6 +573,7 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
   const int tile = conv_xcd_remap((int)blockIdx.x, tiles_m * tiles_n);
   const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (scalar: LDS-DMA destinations go to M0)
+  SSG_DMA_STAMP(0)
   const int wm = wave / WCOLS, wn = wave % WCOLS, l32 = lane & 31, h = lane >> 5;
 
   // ---- DMA addressing: this wave fills A rows [16*ABLK*w, +16*ABLK) and W rows [32w, 32w+32) of every stage
@@ -805,6 +813,7 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
     SSG_DMA_NEXT(st2)
     if constexpr (NS == 4) SSG_DMA_NEXT(st3)
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(TDMA * (NS - 1)) : "memory");     // tile 0 landed for everybody
+    SSG_DMA_STAMP(1)
     for (int kt = 0; kt < nfull; kt += NS) {
       SSG_STEP(st0)
       SSG_STEP(st1)
@@ -823,7 +832,9 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
 #undef SSG_STEP
 #undef SSG_LAST
   }
+  SSG_DMA_STAMP(2)
   __syncthreads();                        // drains the (clamped, redundant) tail DMAs before the stages become epilogue patches
+  SSG_DMA_STAMP(3)
 #undef SSG_PUBLISH
 #undef SSG_DMA_NEXT
 #undef SSG_DMA_A
@@ -866,6 +877,79 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
   const int chunk = lane % CPR, prow = lane / CPR, odd = lane & 1;
   const float* __restrict__ resp = p.res;
   float* __restrict__ outp = p.out;
+#ifndef SSG_DMA_FAST_EPI
+#define SSG_DMA_FAST_EPI 1
+#endif
+  // Round 6: the epilogue of the embedding's own launches (split-half in and out, ReLU, per-channel scales) as straight-line code.  The
+  // general loop below tests five run-time switches per 16-byte piece (residual? encoded? ReLU? encode? range flag?): hipcc turns them
+  // into ~100 scalar branches with a full s_waitcnt in front of the first use, the residual pieces of a patch are requested right before
+  // they are needed and nothing of the next patch is in flight meanwhile -- four exposed HBM round trips per wave, with every wave of the CU
+  // in them at the same time.  Here the switches are compile-time, the residual pieces (and the bias / scale vectors) of patch n + 1 are
+  // requested BEFORE patch n is turned through LDS (two patches = 8 KB per wave in flight), the lane-pair exchanges are selects instead of
+  // divergent branches, and the range flag is OR-accumulated and tested once.  Same operations on the same values in the same order:
+  // bit-identical output (tests/test_gpu_parity.py::test_conv_fast_epilogue_matches_the_general_one).
+  if (SSG_DMA_FAST_EPI && p.variant != 7 && p.out_split && p.relu && p.cscale != nullptr && (resp == nullptr || p.res_split) &&
+      (int64_t)p.M * p.Cout * 4 < (int64_t)0xffffffff) {
+    constexpr int NP = MT * NT;
+    unsigned ovf = 0u;
+    // residual / output through buffer resources: a lane's address is one constant byte offset + a wave-uniform one, rows behind M are
+    // out of range (loads return 0, stores are dropped) -- no 64-bit address registers, no row predicates
+    const unsigned tbytes = (unsigned)((int64_t)p.M * p.Cout * 4), rowb = (unsigned)p.Cout * 4u;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(resp ? resp : outp), 0, resp ? tbytes : 0u, 0x00020000);
+    const unsigned lane_off = (unsigned)prow * rowb + (unsigned)chunk * 16u;
+    const unsigned ubase = (unsigned)(tm * BM + wm * WM) * rowb + (unsigned)(tn * BN + wn * WN) * 4u;
+    // patch n = (j = n / MT, i = n % MT): one bias / scale vector pair per j
+    auto poff = [&](const int n, const int it) { return ubase + (unsigned)((n % MT) * 32 + it * RPI) * rowb + (unsigned)(n / MT) * 128u + lane_off; };
+    auto run = [&](auto RES_) {
+      constexpr bool RES = decltype(RES_)::value;
+      v4u rr[ITS];                                            // (ext-vector types: arrays of HIP's float4 struct stay in scratch memory)
+      v4f bias = *reinterpret_cast<const v4f*>(p.bias + tn * BN + wn * WN + chunk * 4), cs = *reinterpret_cast<const v4f*>(p.cscale + tn * BN + wn * WN + chunk * 4);
+      v4f bias_n = bias, cs_n = cs;
+      if constexpr (RES) {
+#pragma unroll
+        for (int it = 0; it < ITS; it++) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, poff(0, it), 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NP; n++) {
+        const int j = n / MT, i = n % MT;
+        if (n % MT == MT - 1 && j + 1 < NT) {                 // the next j's vectors, one patch ahead
+          bias_n = *reinterpret_cast<const v4f*>(p.bias + tn * BN + wn * WN + (j + 1) * 32 + chunk * 4);
+          cs_n = *reinterpret_cast<const v4f*>(p.cscale + tn * BN + wn * WN + (j + 1) * 32 + chunk * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          *reinterpret_cast<float4*>(patch + l32 * EP + 8 * q + 4 * h) = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int it = 0; it < ITS; it++) {
+          float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + chunk * 4);
+          v.x = v.x * cs[0] + bias[0]; v.y = v.y * cs[1] + bias[1]; v.z = v.z * cs[2] + bias[2]; v.w = v.w * cs[3] + bias[3];
+          if constexpr (RES) {
+            // even lane holds hi0..7 of the 8-channel group, odd lane lo0..7; each needs hi and lo of ITS four channels
+            const unsigned a0 = rr[it][0], a1 = rr[it][1], a2 = rr[it][2], a3 = rr[it][3];
+            if (n + 1 < NP) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, poff(n + 1, it), 0, 0);   // the next patch's piece, a whole patch ahead of its use
+            const unsigned g0 = lane_xor1(odd ? a0 : a2), g1 = lane_xor1(odd ? a1 : a3);
+            const float4 r4 = split_decode4(make_uint2(odd ? g0 : a0, odd ? g1 : a1), make_uint2(odd ? a2 : g0, odd ? a3 : g1));
+            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+          }
+          v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+          uint2 hp, lp;
+          split_encode4(v, hp, lp);
+          ovf |= ((hp.x & 0x7c007c00u) + 0x04000400u) | ((hp.y & 0x7c007c00u) + 0x04000400u);   // bits 15 / 31: a hi half with an all-ones exponent
+          const unsigned rx = lane_xor1(odd ? hp.x : lp.x), ry = lane_xor1(odd ? hp.y : lp.y);
+          const v4u stv = {odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry};
+          __builtin_amdgcn_raw_buffer_store_b128(stv, out_rsrc, poff(n, it), 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (n % MT == MT - 1) { bias = bias_n; cs = cs_n; }
+      }
+    };
+    if (resp) run(std::true_type{}); else run(std::false_type{});
+    if ((ovf & 0x80008000u) && p.overflow) *p.overflow = 1;
+    SSG_DMA_STAMP(4)
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; i++) {
     const int mbase = tm * BM + wm * WM + i * 32;

@@ -336,9 +336,10 @@ class ResNet:
                   "ssg_bottleneck_ds_nhwc_x")
         return out
 
-    def _fmap(self, x, flip=False):
+    def _fmap(self, x, flip=False, hooks=None):
         """-> (layer4 map [B,h,w,2048], is_split): with precision='split' the float32 tensor is a container of
-        h8l8 split halves (decode with ssg_h8l8_decode)."""
+        h8l8 split halves (decode with ssg_h8l8_decode).  hooks: {block index: callable} run on the host in front of that block's
+        launches (the staggered two-stream schedule records / waits for its events there)."""
         L = _lib.lib()
         net = self._prepare()
         sp = net["split"]
@@ -367,7 +368,9 @@ class ResNet:
             else:
                 check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
             y = p
-        for blk in net["blocks"]:
+        for bi, blk in enumerate(net["blocks"]):
+            if hooks and bi in hooks:
+                hooks[bi]()
             if sp:
                 fused = self._bottleneck(L, y, blk, ovf)
                 if fused is not None:

@@ -933,6 +933,59 @@ def test_conv_tile_shapes_agree_bitwise(cfg, L, dev):
 
 
 @pytest.mark.parametrize("cfg", [
+    (400, 16, 8, 256, 1024, 1, 1, 0, True),        # layer3 conv3 + residual: 128 x 256 tiles
+    (401, 8, 4, 512, 2048, 1, 1, 0, True),         # layer4 conv3 + residual, ragged last tile (M = 12 832 = 100.25 x 128)
+    (403, 8, 4, 2048, 512, 1, 1, 0, False),        # layer4 conv1: 256 x 256 tiles, ragged (M = 12 896 = 50.4 x 256)
+    (400, 16, 8, 256, 256, 3, 1, 1, False),        # layer3 3x3: 256 x 256 tiles
+    (400, 32, 16, 128, 512, 1, 1, 0, True),        # layer2 conv3 + residual
+])
+def test_conv_fast_epilogue_matches_the_general_one(cfg, L, dev):
+    """Round 6: the LDS-DMA kernels finish the embedding's own launches (split-half in / out, ReLU, per-channel scales) through a
+    straight-line epilogue with compile-time switches, buffer-resource addressing and the residual pieces of the next patch in flight;
+    a large batch (that epilogue) must equal the same images in small batches (register-staged kernel, general epilogue) bit for bit,
+    twice in a row, ragged last tiles included; an activation beyond the half range must raise the range flag on either path."""
+    from ssg_amd._lib import check, ptr, stream
+    from ssg_amd.resnet import _h8l8, _row_scales, pack_weight_khwc
+    B, H, W, Cin, Cout, k, stride, pad, use_res = cfg
+    g = torch.Generator().manual_seed(7 * B + Cin + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5 * (10.0 ** torch.randint(-2, 2, (Cout, 1, 1, 1), generator=g).float())
+    wk = pack_weight_khwc(w.permute(0, 2, 3, 1))
+    sc = _row_scales(wk)
+    ws = _h8l8(wk * sc.view(-1, 1)).to(dev)
+    cs = (1.0 / sc).contiguous().to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    xs = torch.empty_like(x); check(L.ssg_h8l8_encode(ptr(x), ptr(xs), x.numel(), 1.0, stream()), "enc")
+    OH = (H + 2 * pad - k) // stride + 1; OW = (W + 2 * pad - k) // stride + 1
+    rs = None
+    if use_res:
+        r = torch.randn(B, OH, OW, Cout, generator=g).to(dev)
+        rs = torch.empty_like(r); check(L.ssg_h8l8_encode(ptr(r), ptr(rs), r.numel(), 1.0, stream()), "enc")
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(lo, hi, b=bias):
+        out = torch.empty(hi - lo, OH, OW, Cout, device=dev)
+        check(L.ssg_conv2d_nhwc_x(ptr(xs[lo:hi]), ptr(ws), ptr(b), ptr(rs[lo:hi]) if use_res else None, ptr(out), hi - lo, H, W, Cin, Cout, k, k, stride, pad, 1, 3,
+                                  1.0, ptr(cs), ptr(flag), stream()), "convx")
+        return out
+    big = run(0, B)
+    small = torch.cat([run(lo, min(lo + 8, B)) for lo in range(0, B, 8)], 0)
+    assert torch.equal(big.view(torch.int32), small.view(torch.int32))
+    assert torch.equal(run(0, B).view(torch.int32), big.view(torch.int32))
+    assert int(flag.item()) == 0
+    dec = torch.empty_like(big[:2]); check(L.ssg_h8l8_decode(ptr(big[:2].contiguous()), ptr(dec), dec.numel(), 1.0, stream()), "dec")
+    ref = torch.nn.functional.conv2d(x[:2].cpu().permute(0, 3, 1, 2).double(), w.double(), bias.cpu().double(), stride, pad)
+    if use_res:
+        ref = ref + r[:2].cpu().permute(0, 3, 1, 2).double()
+    ref = torch.relu(ref)
+    assert (dec.cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # one channel pushed out of the half range: the flag goes up (large batch = this epilogue)
+    hot = bias.clone(); hot[Cout // 2 + 3] = 1.0e5
+    run(0, B, hot)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("cfg", [
     (400, 32, 16, 128, 64, 32, 256, 2, 512),       # layer2 first block: conv3 (128 ch) | downsample (256 ch at stride 2) -> 512
     (400, 16, 8, 256, 32, 16, 512, 2, 1024),       # layer3 first block
     (400, 8, 4, 512, 16, 8, 1024, 2, 2048),        # layer4 first block
