@@ -438,7 +438,11 @@ def eps_rule_dbscan(X, rho, min_samples=4):
     # ---- the sampled threshold (two launches: each level's last workgroup selects) and the one full pass
     fused = os.environ.get("SSG_EPS_FUSED_LAUNCHES", "1") != "0"      # (0: the separate selection / check launches of round 5 -- A/B switch)
     if fused:
-        check(L.ssg_eps_sample_threshold(*args, stride, 1.3 * rho, ptr(hist), ptr(thr3), ptr(tickets), ptr(splitters), st), "ssg_eps_sample_threshold")
+        # (the interpolated sort splitters are only computed for the rejected SSG_EPS_PRESPLIT experiment: one thread may own hundreds of them,
+        # 33 us in the selecting workgroup -- round 6 measured the chain at 0.39 instead of 0.31 ms while they were always written)
+        presplit = os.environ.get("SSG_EPS_PRESPLIT", "0") == "1"
+        check(L.ssg_eps_sample_threshold(*args, stride, 1.3 * rho, ptr(hist), ptr(thr3), ptr(tickets), ptr(splitters) if presplit else None, st),
+              "ssg_eps_sample_threshold")
     else:
         check(L.ssg_eps_sample_hist(*args, stride, None, ptr(hist[:4097]), st), "ssg_eps_sample_hist")
         check(L.ssg_eps_select_threshold(ptr(hist[:4097]), 1.3 * rho, ptr(thr3), st), "ssg_eps_select_threshold")
