@@ -12,7 +12,16 @@ dev = torch.device("cuda", 0)
 N = int(os.environ.get("N", 16000)); Ns = 12936 * N // 16000
 src = torch.from_numpy(synth.hard_clustered(Ns, 2048, 2, intra=0.7)).to(dev); tgt = torch.from_numpy(synth.hard_clustered(N, 2048, 1)).to(dev)
 h = rerank.re_ranking_device(src, tgt, k1=20, k2=6, lambda_value=0.3, keep_euclid=False, validate=False)
+pend0 = h._pending.clone() if h._pending is not None else None
 ref = cluster.eps_rule_dbscan(h, 1.6e-3, min_samples=4)
+# PIECES=1: every timed call finds the re-rank's status words still unread, as the bench's step does (they travel with the chain's read)
+PIECES = os.environ.get("PIECES", "0") == "1"
+_orig = cluster.eps_rule_dbscan
+def _with_pieces(hh, *a, **kw):
+    if PIECES and pend0 is not None:
+        hh._pending = pend0
+    return _orig(hh, *a, **kw)
+cluster.eps_rule_dbscan = _with_pieces
 R = 20
 # (a) queue kept full: a long filler kernel in front, then the chain; events around the chain only
 filler = torch.empty(1 << 28, dtype=torch.float32, device=dev)
