@@ -523,6 +523,10 @@ def main():
         roof["peak_is"] = "fp16 dense MFMA peak %.1f / 3 products per fp32 multiply" % PEAK_FP16_MFMA_TF
         roof["executed_fp16_tflops"] = round(3.0 * conv_tf, 1)
         roof["vs_fp32_mfma_peak"] = round(conv_tf / PEAK_FP32_MFMA_TF, 3)
+        # informational (not `peak`): what the same three-product MFMA loop sustains on this part with nothing else running, on the convolutions'
+        # operand statistics, under the 1400 W limit -- tools/micro/mfma_peak.hip, profiles/r06_mfma_sustained.txt (1954 TFLOP/s fp16 at 1.86 GHz)
+        roof["sustained_mfma_only_tflops_fp32_equiv"] = 651.0
+        roof["frac_of_sustained"] = round(conv_tf / 651.0, 4)
     if args.uniform:
         # no per-launch events were recorded: nothing to divide by -- the line carries the wall-clock figures only
         note = "--uniform: the timed region ran the product default only (no per-launch HIP events); run without the switch for the roofline objects"
