@@ -797,16 +797,28 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fbh[j], fah[i], acc[i][j], 0, 0, 0); }
     // one tile: fragments, the first MFMA groups, publish (tile t + 1 landed for everybody, everybody done reading this stage),
     // refill this stage with tile t + NS, the rest of the multiply
+#ifndef SSG_DMA_SETPRIO
+#define SSG_DMA_SETPRIO 0      /* 1: s_setprio 1 around the MFMA groups (round 6 A/B, MI355X guide T5) */
+#endif
+#if SSG_DMA_SETPRIO
+#define SSG_PRIO(P_) __builtin_amdgcn_s_setprio(P_);
+#else
+#define SSG_PRIO(P_)
+#endif
 #define SSG_STEP(ST)                                                                                                 \
     { SSG_READS(ST)                                                                                                  \
+      SSG_PRIO(1)                                                                                                    \
       SSG_G1                                                                                                         \
       if constexpr (BPOS == 2) SSG_G2                                                                                \
+      SSG_PRIO(0)                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TDMA * (NS - 2)) : "memory");                  \
       SSG_DMA_NEXT(ST)                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
+      SSG_PRIO(1)                                                                                                    \
       if constexpr (BPOS == 1) SSG_G2                                                                                \
-      SSG_G3 }
+      SSG_G3                                                                                                         \
+      SSG_PRIO(0) }
 #define SSG_LAST(ST) { SSG_READS(ST) SSG_G1 SSG_G2 SSG_G3 }
     SSG_DMA_NEXT(st0)
     SSG_DMA_NEXT(st1)
