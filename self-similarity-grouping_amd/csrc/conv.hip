@@ -901,7 +901,7 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
   // divergent branches, and the range flag is OR-accumulated and tested once.  Same operations on the same values in the same order:
   // bit-identical output (tests/test_gpu_parity.py::test_conv_fast_epilogue_matches_the_general_one).
   if (SSG_DMA_FAST_EPI && p.variant != 7 && p.out_split && p.relu && p.cscale != nullptr && (resp == nullptr || p.res_split) &&
-      (int64_t)p.M * p.Cout * 4 < (int64_t)0xffffffff) {
+      ((int64_t)p.M + BM) * p.Cout * 4 < (int64_t)0xffffffff) {      // (+ BM: the byte offsets of the rows behind M in the last tile must not wrap)
     constexpr int NP = MT * NT;
     unsigned ovf = 0u;
     // residual / output through buffer resources: a lane's address is one constant byte offset + a wave-uniform one, rows behind M are
