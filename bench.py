@@ -494,7 +494,7 @@ def main():
     host_syncs = {"rerank": n_rr, "eps_rule_dbscan": n_ed, "per_split": n_rr + n_ed, "world": world,
                   "what": "blocking device->host reads (item/tolist/cpu) of one grouping leg on rank 0: value ranges of the features (re-rank); ONE read for "
                           "eps rule + DBSCAN on one GPU (labels, neighbour counts, eps, check words, the re-rank's status words -- cluster.eps_rule_dbscan); "
-                          "sharded rows run the two-call form: status table + eps (eps rule), edge counts + labels (DBSCAN)"}
+                          "sharded rows (round 6) run the same chain with two all-gathers inside and the same ONE read (labels + counts + check words + every rank's status words); a failed check falls back to the two-call form"}
     collectives = cc.summary()
     collectives["what"] = ("torch.distributed collectives of one grouping leg on rank 0 (all-gathers of the row-block tables: source minima, rank lists, V, V_qe, "
                            "eps candidates, neighbour counts, edges; all-reduces of the eps histograms / counters); bytes = this rank's contribution / what it receives")
