@@ -304,6 +304,15 @@ int ssg_conv2d_nhwc_x(const void* in, const void* w, const float* bias, const vo
 int ssg_conv1x1_dual_nhwc_x(const void* in, const void* in2, const void* w, const float* bias, void* out, int B, int H, int W, int Cin,
                             int H2, int W2, int Cin2, int stride2, int Cout, int relu, int flags, float acc_scale, const float* ch_scale,
                             int32_t* overflow, ssg_stream_t stream);
+/* Round 6, experimental (opt-in through SSG_CONV_PAIR=1 in the Python layer): the tail of one identity bottleneck block and the head of the
+ * next as ONE launch -- out [M,C] = relu(conv3_1x1(y2 [M,K1]) + b3 + res [M,C]) (base.py:84-90) and y1n [M,N2] = relu(conv1_1x1(out) + b1n)
+ * (base.py:76-78 of the next block); every tensor h8l8, weights as ssg_conv2d_nhwc_x takes them (w3 [C][K1], w1n [N2][C], rows
+ * pre-multiplied by the powers of two cs3 / cs1n undo).  Bit-identical to the two ssg_conv2d_nhwc_x launches it replaces; out is still
+ * written (the next block's residual) but not read back.  ssg_conv_pair_supported: 1 for the layer3 shape (K1 256, C 1024, N2 256). */
+int ssg_conv_pair_supported(int K1, int C, int N2);
+int ssg_conv_pair_nhwc_x(const void* y2, const void* w3, const float* b3, const float* cs3, const void* res, void* out,
+                         const void* w1n, const float* b1n, const float* cs1n, void* y1n, int M, int K1, int C, int N2,
+                         int32_t* overflow, ssg_stream_t stream);
 /* One identity bottleneck block (base.py:57-90 without a downsample branch, stride 1) in ONE launch, split-half tensors:
  * out = relu(conv3(relu(conv2_3x3(relu(conv1(x))))) + x).  x / out [B,H,W,C] h8l8 (out must not alias x); w1 [MID][C],
  * w2 [MID][9*MID] (k = (32-channel chunk, tap, channel)), w3 [C][MID] as ssg_conv2d_nhwc_x takes them, rows pre-multiplied by

@@ -368,7 +368,11 @@ class ResNet:
             else:
                 check(L.ssg_maxpool3x3s2_nhwc(ptr(y), ptr(p), B, H2, W2, 64, stream()), "ssg_maxpool3x3s2_nhwc")
             y = p
-        for bi, blk in enumerate(net["blocks"]):
+        # SSG_CONV_PAIR=1 (round 6, experimental, off by default: measured in DESIGN.md section 11): conv3 + residual of an identity block and
+        # conv1 of the next block as one launch (ssg_conv_pair_nhwc_x) where a kernel exists (layer3) and the tiles fill the chip
+        pair = sp and os.environ.get("SSG_CONV_PAIR", "0") == "1"
+        blocks, o1_next = net["blocks"], None
+        for bi, blk in enumerate(blocks):
             if hooks and bi in hooks:
                 hooks[bi]()
             if sp:
@@ -376,13 +380,30 @@ class ResNet:
                 if fused is not None:
                     y = fused
                     continue
-            o = self._conv(L, y, blk["c1"], out_split=sp, ovf=ovf)
+            o = o1_next if o1_next is not None else self._conv(L, y, blk["c1"], out_split=sp, ovf=ovf)
+            o1_next = None
             o = self._conv(L, o, blk["c2"], out_split=sp, ovf=ovf)
             if blk["ds"] is not None:
                 y = self._conv_dual(L, o, y, blk["c3"], blk["ds"], out_split=sp, ovf=ovf)
+                continue
+            nxt = blocks[bi + 1]["c1"] if bi + 1 < len(blocks) else None
+            Bo, Ho, Wo, _ = o.shape
+            if (pair and nxt is not None and nxt.k == 1 and nxt.stride == 1 and nxt.cin == blk["c3"].cout and Bo * Ho * Wo >= 128 * 256
+                    and L.ssg_conv_pair_supported(blk["c3"].cin, blk["c3"].cout, nxt.cout)):
+                y, o1_next = self._conv_pair(L, o, blk["c3"], y, nxt, ovf)
             else:
                 y = self._conv(L, o, blk["c3"], res=y, relu=True, out_split=sp, ovf=ovf)
         return y, sp
+
+    @staticmethod
+    def _conv_pair(L, o, c3, res, c1n, ovf=None):
+        """(relu(conv3(o) + res), relu(conv1_next(that))) in one launch (ssg_conv_pair_nhwc_x): split-half tensors, 1x1 convolutions"""
+        B, H, W, _ = o.shape
+        out = torch.empty((B, H, W, c3.cout), dtype=torch.float32, device=o.device)
+        y1n = torch.empty((B, H, W, c1n.cout), dtype=torch.float32, device=o.device)
+        check(L.ssg_conv_pair_nhwc_x(ptr(o), ptr(c3.w), ptr(c3.bias), ptr(c3.cscale), ptr(res), ptr(out), ptr(c1n.w), ptr(c1n.bias), ptr(c1n.cscale),
+                                     ptr(y1n), B * H * W, c3.cin, c3.cout, c1n.cout, ptr(ovf), stream()), "ssg_conv_pair_nhwc_x")
+        return out, y1n
 
     # ---- split-half range guard: activations are half pairs, |v| >= 65520 cannot be stored.  Every convolution raises a
     # device flag when it has to encode such a value; the public entry points read it once per call and recompute the batch

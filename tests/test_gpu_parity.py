@@ -985,6 +985,55 @@ def test_conv_fast_epilogue_matches_the_general_one(cfg, L, dev):
     assert int(flag.item()) == 1
 
 
+@pytest.mark.parametrize("M", [51200, 25664, 128 * 257 + 37])
+def test_conv_pair_matches_the_two_launches(M, L, dev):
+    """Round 6 (experimental kernel, SSG_CONV_PAIR=1): conv3 + residual of a layer3 identity block and conv1 of the next block as ONE launch
+    (ssg_conv_pair_nhwc_x: `out` walked in 128-channel chunks, the chunk re-encoded into an LDS stash that is the second GEMM's pixel operand)
+    must equal the two ssg_conv2d_nhwc_x launches bit for bit -- both tensors, twice in a row, ragged last tiles included -- and raise the range
+    flag for an activation beyond the half range."""
+    from ssg_amd._lib import check, ptr, stream
+    from ssg_amd.resnet import _h8l8, _row_scales
+    K1, C, N2 = 256, 1024, 256
+    assert L.ssg_conv_pair_supported(K1, C, N2)
+    g = torch.Generator().manual_seed(M)
+    y2 = torch.relu(torch.randn(M, K1, generator=g)).to(dev)
+    res = torch.relu(torch.randn(M, C, generator=g)).to(dev)
+    w3 = torch.randn(C, K1, generator=g) * (2.0 / K1) ** 0.5 * (10.0 ** torch.randint(-2, 2, (C, 1), generator=g).float())
+    w1 = torch.randn(N2, C, generator=g) * (2.0 / C) ** 0.5 * (10.0 ** torch.randint(-2, 2, (N2, 1), generator=g).float())
+    s3, s1 = _row_scales(w3), _row_scales(w1)
+    w3s, w1s = _h8l8(w3 * s3.view(-1, 1)).to(dev), _h8l8(w1 * s1.view(-1, 1)).to(dev)
+    cs3, cs1 = (1.0 / s3).contiguous().to(dev), (1.0 / s1).contiguous().to(dev)
+    b3, b1 = torch.randn(C, generator=g).to(dev), torch.randn(N2, generator=g).to(dev)
+    y2s = torch.empty_like(y2); check(L.ssg_h8l8_encode(ptr(y2), ptr(y2s), y2.numel(), 1.0, stream()), "enc")
+    rs = torch.empty_like(res); check(L.ssg_h8l8_encode(ptr(res), ptr(rs), res.numel(), 1.0, stream()), "enc")
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def two(bias3):
+        out = torch.empty(M, C, device=dev); y1 = torch.empty(M, N2, device=dev)
+        check(L.ssg_conv2d_nhwc_x(ptr(y2s), ptr(w3s), ptr(bias3), ptr(rs), ptr(out), M, 1, 1, K1, C, 1, 1, 1, 0, 1, 3, 1.0, ptr(cs3), ptr(flag), stream()), "conv3")
+        check(L.ssg_conv2d_nhwc_x(ptr(out), ptr(w1s), ptr(b1), None, ptr(y1), M, 1, 1, C, N2, 1, 1, 1, 0, 1, 3, 1.0, ptr(cs1), ptr(flag), stream()), "conv1")
+        return out, y1
+
+    def one(bias3):
+        out = torch.empty(M, C, device=dev); y1 = torch.empty(M, N2, device=dev)
+        check(L.ssg_conv_pair_nhwc_x(ptr(y2s), ptr(w3s), ptr(bias3), ptr(cs3), ptr(rs), ptr(out), ptr(w1s), ptr(b1), ptr(cs1), ptr(y1), M, K1, C, N2, ptr(flag), stream()), "pair")
+        return out, y1
+    o2, y2l = two(b3)
+    for _ in range(2):
+        o1, y1l = one(b3)
+        assert torch.equal(o1.view(torch.int32), o2.view(torch.int32))
+        assert torch.equal(y1l.view(torch.int32), y2l.view(torch.int32))
+    assert int(flag.item()) == 0
+    # values: float64 on a few rows
+    dec = torch.empty(4, N2, device=dev); check(L.ssg_h8l8_decode(ptr(y1l[:4].contiguous()), ptr(dec), dec.numel(), 1.0, stream()), "dec")
+    o64 = torch.relu(y2[:4].cpu().double() @ w3.double().t() + b3.cpu().double() + res[:4].cpu().double())
+    r64 = torch.relu(o64 @ w1.double().t() + b1.cpu().double())
+    assert (dec.cpu().double() - r64).abs().max().item() < 3e-5 * max(1.0, r64.abs().max().item())
+    hot = b3.clone(); hot[C // 2 + 5] = 1.0e5
+    one(hot)
+    assert int(flag.item()) == 1
+
+
 @pytest.mark.parametrize("cfg", [
     (400, 32, 16, 128, 64, 32, 256, 2, 512),       # layer2 first block: conv3 (128 ch) | downsample (256 ch at stride 2) -> 512
     (400, 16, 8, 256, 32, 16, 512, 2, 1024),       # layer3 first block

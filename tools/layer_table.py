@@ -61,6 +61,11 @@ def work(name, a, B):
         flop = 2.0 * B_ * H * W * (CIN * MID + 9 * MID * MID + (MID + CIN) * C)
         byt = 4.0 * (B_ * H * W * (CIN + C) + CIN * MID + 9 * MID * MID + (MID + CIN) * C)
         return flop, byt, "bottleneck+ds %dx%d %d->%d mid=%d" % (H, W, CIN, C, MID)
+    if name == "ssg_conv_pair_nhwc_x":
+        M, K1, C, N2 = [v(x) for x in a[10:14]]
+        flop = 2.0 * M * C * (K1 + N2)
+        byt = 4.0 * (M * (K1 + 2 * C + N2) + C * (K1 + N2))
+        return flop, byt, "pair conv3+res | next conv1 M=%d %d->%d->%d" % (M, K1, C, N2)
     return 0.0, 0.0, name
 
 
