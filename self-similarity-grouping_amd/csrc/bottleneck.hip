@@ -34,6 +34,17 @@
 #include "ssg_common.h"
 #include <cstdlib>
 
+// Round 6: cache policy of the block's two streams that nobody re-reads from the L2 -- the stores of `out` (1-2 GB per launch at B = 1000)
+// and the residual re-read of x (its last use).  With the default policy they push the lines that ARE re-read (the x rows a neighbouring
+// workgroup needs as its halo and this one as its residual, the weights) out of the 4 MB L2s; with `nt` the layer1 identity blocks
+// run 1.48 -> 1.30-1.35 ms and the layer2 ones 1.22 -> 1.12 ms (profiles/r06_ab_nt_policy.txt).  Same values, same order: bit-identical.
+#ifndef SSG_BN_NT_STORE
+#define SSG_BN_NT_STORE 1
+#endif
+#ifndef SSG_BN_NT_RES
+#define SSG_BN_NT_RES 1
+#endif
+
 namespace ssg {
 namespace bneck {
 
@@ -496,6 +507,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
   float4 rr[2][ITS], b3r[2], cs3r[2];
 #ifdef SSG_BN_ABL_NORES                                  // ablation build (tools/micro/bneck_prof.hip): no residual read, wrong results
 #define SSG_BN_RESLOAD(P_) make_float4(0.f, 0.f, 0.f, 0.f)
+#elif SSG_BN_NT_RES                                      // the residual re-read is x's last use: nt cache policy (see SSG_BN_NT_STORE above)
+#define SSG_BN_RESLOAD(P_) ([&]() { const v4f t_ = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(P_)); return make_float4(t_[0], t_[1], t_[2], t_[3]); }())
 #else
 #define SSG_BN_RESLOAD(P_) (*reinterpret_cast<const float4*>(P_))
 #endif
@@ -576,7 +589,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void bottleneck_kernel(Pa
       ovf |= hi_nonfinite_bits(hp);
       const unsigned rx = lane_xor1((odd ? hp.x : lp.x)), ry = lane_xor1((odd ? hp.y : lp.y));
       const uint4 stv = make_uint4(odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry);
-#ifdef SSG_BN_NT_STORE
+#if SSG_BN_NT_STORE
       { const v4u sv_ = {stv.x, stv.y, stv.z, stv.w}; __builtin_nontemporal_store(sv_, reinterpret_cast<v4u*>(outp + (int64_t)pr * C + col)); }
 #else
       *reinterpret_cast<uint4*>(outp + (int64_t)pr * C + col) = stv;

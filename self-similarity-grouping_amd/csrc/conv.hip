@@ -466,7 +466,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
           const uint2 send = odd ? hp : lp;
           const uint2 recv = make_uint2(lane_xor1(send.x), lane_xor1(send.y));
           const uint4 st = odd ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
+#ifdef SSG_IGEMM_NT_STORE       // A/B knob: the register-staged kernel's split-half stores with the nt cache policy
+          if (m < p.M) { const v4u sv_ = {st.x, st.y, st.z, st.w}; __builtin_nontemporal_store(sv_, reinterpret_cast<v4u*>(outp + (int64_t)m * p.Cout + col)); }
+#else
           if (m < p.M) *reinterpret_cast<uint4*>(outp + (int64_t)m * p.Cout + col) = st;
+#endif
         } else if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
       }
     }
@@ -527,7 +531,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, (BM / WM) * (BN / WN) =
           const uint2 send = h ? hp : lp;
           const uint2 recv = make_uint2((unsigned)__shfl_xor((int)send.x, 32, 64), (unsigned)__shfl_xor((int)send.y, 32, 64));
           const uint4 st = h ? make_uint4(recv.x, recv.y, lp.x, lp.y) : make_uint4(hp.x, hp.y, recv.x, recv.y);
+#ifdef SSG_IGEMM_NT_STORE       // A/B knob: the register-staged kernel's split-half stores with the nt cache policy
+          if (m < p.M) { const v4u sv_ = {st.x, st.y, st.z, st.w}; __builtin_nontemporal_store(sv_, reinterpret_cast<v4u*>(outp + (int64_t)m * p.Cout + col)); }
+#else
           if (m < p.M) *reinterpret_cast<uint4*>(outp + (int64_t)m * p.Cout + col) = st;
+#endif
         } else if (m < p.M) *reinterpret_cast<float4*>(outp + (int64_t)m * p.Cout + col) = v;
       }
     }
@@ -892,6 +900,19 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
 #ifndef SSG_DMA_FAST_EPI
 #define SSG_DMA_FAST_EPI 1
 #endif
+  // cache-policy bits (gfx950: 1 = sc0, 2 = nt, 16 = sc1) of the straight-line epilogue's residual loads / output stores, with and without a residual.
+  // A conv3 + residual launch streams its residual (last use) and its 0.5 GB output once: with `nt` they do not evict the pixel tile its four
+  // column tiles share or the weights (layer3: 0.326 -> 0.306 ms, layer4: 0.231 -> 0.219; profiles/r06_ab_nt_policy.txt).  Stores of the
+  // launches WITHOUT a residual stay cached: their 0.13 GB outputs are the next launch's operand (nt there: conv3 + residual 0.307 -> 0.318).
+#ifndef SSG_DMA_RES_AUX
+#define SSG_DMA_RES_AUX 2
+#endif
+#ifndef SSG_DMA_OUT_AUX_RES
+#define SSG_DMA_OUT_AUX_RES 2
+#endif
+#ifndef SSG_DMA_OUT_AUX
+#define SSG_DMA_OUT_AUX 0
+#endif
   // Round 6: the epilogue of the embedding's own launches (split-half in and out, ReLU, per-channel scales) as straight-line code.  The
   // general loop below tests five run-time switches per 16-byte piece (residual? encoded? ReLU? encode? range flag?): hipcc turns them
   // into ~100 scalar branches with a full s_waitcnt in front of the first use, the residual pieces of a patch are requested right before
@@ -920,7 +941,7 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
       v4f bias_n = bias, cs_n = cs;
       if constexpr (RES) {
 #pragma unroll
-        for (int it = 0; it < ITS; it++) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, poff(0, it), 0, 0);
+        for (int it = 0; it < ITS; it++) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, poff(0, it), 0, SSG_DMA_RES_AUX);
       }
 #pragma unroll
       for (int n = 0; n < NP; n++) {
@@ -940,7 +961,7 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
           if constexpr (RES) {
             // even lane holds hi0..7 of the 8-channel group, odd lane lo0..7; each needs hi and lo of ITS four channels
             const unsigned a0 = rr[it][0], a1 = rr[it][1], a2 = rr[it][2], a3 = rr[it][3];
-            if (n + 1 < NP) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, poff(n + 1, it), 0, 0);   // the next patch's piece, a whole patch ahead of its use
+            if (n + 1 < NP) rr[it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, poff(n + 1, it), 0, SSG_DMA_RES_AUX);   // the next patch's piece, a whole patch ahead of its use
             const unsigned g0 = lane_xor1(odd ? a0 : a2), g1 = lane_xor1(odd ? a1 : a3);
             const float4 r4 = split_decode4(make_uint2(odd ? g0 : a0, odd ? g1 : a1), make_uint2(odd ? a2 : g0, odd ? a3 : g1));
             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
@@ -951,7 +972,7 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
           ovf |= ((hp.x & 0x7c007c00u) + 0x04000400u) | ((hp.y & 0x7c007c00u) + 0x04000400u);   // bits 15 / 31: a hi half with an all-ones exponent
           const unsigned rx = lane_xor1(odd ? hp.x : lp.x), ry = lane_xor1(odd ? hp.y : lp.y);
           const v4u stv = {odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry};
-          __builtin_amdgcn_raw_buffer_store_b128(stv, out_rsrc, poff(n, it), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(stv, out_rsrc, poff(n, it), 0, RES ? SSG_DMA_OUT_AUX_RES : SSG_DMA_OUT_AUX);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (n % MT == MT - 1) { bias = bias_n; cs = cs_n; }

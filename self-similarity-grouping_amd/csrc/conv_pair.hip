@@ -20,7 +20,13 @@ struct PairParams {
   const float* y2; const float* w3; const float* b3; const float* cs3; const float* res; float* out;
   const float* w1n; const float* b1n; const float* cs1n; float* y1n;
   int M; int* overflow;
+  unsigned long long* prof = nullptr;   // SSG_PAIR_PROF builds (tools/micro/pair_prof.hip): ticks per workgroup -- total, GEMM1, chunk epilogues, GEMM2, last epilogue
 };
+#ifdef SSG_PAIR_PROF
+#define SSG_PAIR_STAMP(ACC_) { const unsigned long long t_ = __builtin_readcyclecounter(); ACC_ += t_ - tprev; tprev = t_; }
+#else
+#define SSG_PAIR_STAMP(ACC_)
+#endif
 
 __device__ __forceinline__ void dma16(const __amdgpu_buffer_rsrc_t r, unsigned lds_addr, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(uintptr_t)lds_addr, 16, voff, 0, 0, 0);
@@ -100,10 +106,32 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
       acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_[j], ah_[i], acc2[i][j], 0, 0, 0);                      \
     _Pragma("unroll") for (int i = 0; i < 2; i++) _Pragma("unroll") for (int j = 0; j < 2; j++)                      \
       acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_[j], ah_[i], acc2[i][j], 0, 0, 0); }
+#ifdef SSG_PAIR_ABL_NOMMA        // ablation build (tools/micro/pair_prof.hip): the DMA stream, barriers and epilogues without a multiply -- wrong results
+#undef PAIR_MMA1
+#undef PAIR_MMA2
+#define PAIR_MMA1(ST)
+#define PAIR_MMA2(ST, KT)
+#endif
   // publish tile t: VM = vector-memory operations of this wave that are younger than the tile's DMA; lgkmcnt(0): "I am done reading the
   // stage the next DMA overwrites" (conv_dma_kernel's protocol)
 #define PAIR_PUBLISH(VM) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
 #define PAIR_STAGE(T) ((T) % 3 == 0 ? st0 : ((T) % 3 == 1 ? st1 : st2))
+#if defined(SSG_PAIR_ABL_NOEPI) || defined(SSG_PAIR_ABL_NORES)
+#define PAIR_VML(N_, ABL_) ABL_    // ablation builds: without the epilogue's 10 loads in the queue
+#else
+#define PAIR_VML(N_, ABL_) N_
+#endif
+#if defined(SSG_PAIR_ABL_NOEPI) || defined(SSG_PAIR_ABL_NOSTORE)
+#define PAIR_VMS(N_, ABL_) ABL_    // ... without its 8 stores
+#else
+#define PAIR_VMS(N_, ABL_) N_
+#endif
+#ifndef SSG_PAIR_AUX
+#define SSG_PAIR_AUX 2             // cache-policy bits of the residual loads and the stores of `out`: nt (streamed once; they must not push the
+#endif                             // re-read y2 tile and the weights out of the L2: 0.631 -> 0.470 ms, profiles/r06_conv_pair_phases.txt)
+#ifndef SSG_PAIR_AUX_Y1
+#define SSG_PAIR_AUX_Y1 0          // ... of the stores of y1n
+#endif
 
   // ---- epilogue addressing (conv_dma_kernel's straight-line epilogue)
   float* patch = patches + wave * (32 * EP);
@@ -113,6 +141,10 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
   const unsigned ubase1 = (unsigned)(m0 + wm * 64) * rowb + (unsigned)(wn * 32) * 4u;          // + chunk index * 512 + (i * 32 + it * 8) * rowb
   unsigned ovf = 0u;
 
+#ifdef SSG_PAIR_PROF
+  unsigned long long tprev = __builtin_readcyclecounter(), t_g1 = 0, t_ep = 0, t_g2 = 0, t_last = 0;
+  const unsigned long long tstart = tprev;
+#endif
   PAIR_DMA(0, 0)
   PAIR_DMA(1, 0)
   for (int c = 0; c < NCH; c++) {
@@ -137,22 +169,30 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
       {
         const int col = c * 128 + wn * 32 + chunk * 4;
         bias1 = *reinterpret_cast<const v4f*>(p.b3 + col); cs1 = *reinterpret_cast<const v4f*>(p.cs3 + col);
+#ifndef SSG_PAIR_ABL_NOEPI       // ablation build: no chunk epilogue (no residual read, no store of `out`, stale stash) -- wrong results
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int it = 0; it < ITS; it++)
-            rr[i][it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, ubase1 + (unsigned)c * 512u + (unsigned)(i * 32 + it * RPI) * rowb + lane_off, 0, 0);
+#ifdef SSG_PAIR_ABL_NORES
+            rr[i][it] = v4u{0u, 0u, 0u, 0u};
+#else
+            rr[i][it] = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, ubase1 + (unsigned)c * 512u + (unsigned)(i * 32 + it * RPI) * rowb + lane_off, 0, SSG_PAIR_AUX);
+#endif
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
       PAIR_MMA1(PAIR_STAGE(13))
     }
-    PAIR_STEP1(14, 12)
-    PAIR_STEP1(15, 12)
+    PAIR_STEP1(14, PAIR_VML(12, 2))
+    PAIR_STEP1(15, PAIR_VML(12, 2))
 #undef PAIR_STEP1
     // every wave is done with tile 15's stage: tile 18 may land there while the epilogue runs
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    SSG_PAIR_STAMP(t_g1)
     PAIR_DMA(18, c)
     // ======== epilogue of conv3 for this chunk: out -> HBM and -> the stash
+#ifndef SSG_PAIR_ABL_NOEPI
 #pragma unroll
     for (int i = 0; i < 2; i++) {
 #pragma unroll
@@ -175,28 +215,33 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
         ovf |= ((hp.x & 0x7c007c00u) + 0x04000400u) | ((hp.y & 0x7c007c00u) + 0x04000400u);
         const unsigned rx = lane_xor1(odd ? hp.x : lp.x), ry = lane_xor1(odd ? hp.y : lp.y);
         const v4u stv = {odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry};
-        __builtin_amdgcn_raw_buffer_store_b128(stv, out_rsrc, ubase1 + (unsigned)c * 512u + (unsigned)(i * 32 + it * RPI) * rowb + lane_off, 0, 0);
+#ifndef SSG_PAIR_ABL_NOSTORE
+        __builtin_amdgcn_raw_buffer_store_b128(stv, out_rsrc, ubase1 + (unsigned)c * 512u + (unsigned)(i * 32 + it * RPI) * rowb + lane_off, 0, SSG_PAIR_AUX);
+#endif
         // the same 16 bytes as a piece of GEMM2's pixel operand: row R of the tile, k-tile wn * 2 + chunk / 4, logical 16-byte slot chunk % 4
         const int R = wm * 64 + i * 32 + it * RPI + prow;
         *reinterpret_cast<v4u*>(S + (wn * 2 + (chunk >> 2)) * 8192 + R * 64 + (((chunk & 3) ^ ((R >> 2) & 3)) * 16)) = stv;
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+#endif
+    SSG_PAIR_STAMP(t_ep)
     // ======== GEMM2: tiles 16 .. 23 (k-tiles 0 .. 7 of this chunk); the first barrier also publishes the stash
 #define PAIR_STEP2(T, VM, DMA_)                                                                                      \
     { PAIR_PUBLISH(VM)                                                                                               \
       DMA_                                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       PAIR_MMA2(PAIR_STAGE(T), (T) - 16) }
-    PAIR_STEP2(16, 12, {})                           // younger than tile 16: tiles 17, 18 (4) + the 8 stores
-    PAIR_STEP2(17, 10, PAIR_DMA(19, c))              // tile 18 (2) + 8 stores
-    PAIR_STEP2(18, 10, PAIR_DMA(20, c))              // 8 stores + tile 19
+    PAIR_STEP2(16, PAIR_VMS(12, 4), {})                           // younger than tile 16: tiles 17, 18 (4) + the 8 stores
+    PAIR_STEP2(17, PAIR_VMS(10, 2), PAIR_DMA(19, c))              // tile 18 (2) + 8 stores
+    PAIR_STEP2(18, PAIR_VMS(10, 2), PAIR_DMA(20, c))              // 8 stores + tile 19
     PAIR_STEP2(19, 2, PAIR_DMA(21, c))
     PAIR_STEP2(20, 2, PAIR_DMA(22, c))
     PAIR_STEP2(21, 2, PAIR_DMA(23, c))
     PAIR_STEP2(22, 2, PAIR_DMA(0, cn))
     PAIR_STEP2(23, 2, PAIR_DMA(1, cn))
 #undef PAIR_STEP2
+    SSG_PAIR_STAMP(t_g2)
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   // ======== epilogue of the next block's conv1: y1n = relu(acc2 * cs + bias), four 32 x 32 patches per wave
@@ -223,18 +268,27 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
           ovf |= ((hp.x & 0x7c007c00u) + 0x04000400u) | ((hp.y & 0x7c007c00u) + 0x04000400u);
           const unsigned rx = lane_xor1(odd ? hp.x : lp.x), ry = lane_xor1(odd ? hp.y : lp.y);
           const v4u stv = {odd ? rx : hp.x, odd ? ry : hp.y, odd ? lp.x : rx, odd ? lp.y : ry};
-          __builtin_amdgcn_raw_buffer_store_b128(stv, y1_rsrc, ubase2 + (unsigned)(i * 32 + it * RPI) * rowb2 + (unsigned)j * 128u + lane_off2, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(stv, y1_rsrc, ubase2 + (unsigned)(i * 32 + it * RPI) * rowb2 + (unsigned)j * 128u + lane_off2, 0, SSG_PAIR_AUX_Y1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       }
     }
   }
   if ((ovf & 0x80008000u) && p.overflow) *p.overflow = 1;
+#ifdef SSG_PAIR_PROF
+  SSG_PAIR_STAMP(t_last)
+  if (p.prof && tid == 0) {
+    unsigned long long* q = p.prof + (size_t)blockIdx.x * 8;
+    q[0] = tprev - tstart; q[1] = t_g1; q[2] = t_ep; q[3] = t_g2; q[4] = t_last;
+  }
+#endif
 #undef PAIR_DMA
 #undef PAIR_MMA1
 #undef PAIR_MMA2
 #undef PAIR_PUBLISH
 #undef PAIR_STAGE
+#undef PAIR_VML
+#undef PAIR_VMS
 }
 
 }  // namespace pairk

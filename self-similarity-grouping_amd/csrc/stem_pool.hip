@@ -226,8 +226,14 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(const float* __restri
     uint2 ha, la, hb, lb;
     enc4(m0, ha, la); enc4(m1, hb, lb);
     float* o = out + ((((int64_t)b * OHP + pr) * PW + pp) * 64 + cg * 8);
+#ifdef SSG_STEM_NT_STORE        // A/B knob: the pooled map with the nt cache policy
+    { typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+      const v4u_ s0_ = {ha.x, ha.y, hb.x, hb.y}, s1_ = {la.x, la.y, lb.x, lb.y};
+      __builtin_nontemporal_store(s0_, reinterpret_cast<v4u_*>(o)); __builtin_nontemporal_store(s1_, reinterpret_cast<v4u_*>(o + 4)); }
+#else
     *reinterpret_cast<uint4*>(o) = make_uint4(ha.x, ha.y, hb.x, hb.y);
     *reinterpret_cast<uint4*>(o + 4) = make_uint4(la.x, la.y, lb.x, lb.y);
+#endif
     rot = (rot + 4) % RING;
     SSG_STEM_ACC(3)
   }

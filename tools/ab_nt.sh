@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 6: nt cache policy on the straight-line epilogue's residual loads / output stores (variant libraries under _ab/), and the pair kernel
+R=$GRAFT_REPO_ROOT; cd $R; O=$R/gpurun_out/ab_nt; mkdir -p $O
+timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "conv_pair or fast_epilogue" 2>&1 | tail -2 | tee $O/tests.txt
+timeout 600 python tools/ab_inproc.py --reps ${REPS:-6} base=self-similarity-grouping_amd/libssg_hip.so $VARS > $O/ab.txt 2>&1; tail -45 $O/ab.txt
+for r in 1 2; do for pr in 0 1; do
+  SSG_CONV_PAIR=$pr timeout 300 python tools/layer_table.py --reps 3 2>/dev/null | grep -E "^\| (1[3-9]|2[0-7]) |total" | sed "s/^/PAIR=$pr /" | tee -a $O/pair.txt
+done; done
