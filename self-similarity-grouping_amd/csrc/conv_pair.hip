@@ -7,7 +7,7 @@
 // GEMM1 (K = 256) into 32 accumulator registers, the epilogue of conv.hip (scale, bias, residual, ReLU, re-encode) whose 16-byte pieces go to
 // HBM and, in the layout of an LDS-DMA stage, into a 64 KB stash -- and feeds each chunk straight into GEMM2 (K = 128 per chunk, 64
 // accumulator registers that live across the chunks) with the pixel operand read from the stash.  One stream of k-tiles runs through
-// three 16 KB stages across both GEMMs and across the chunk boundary (weights and y2 do not depend on the epilogue), so no pipeline is
+// four 16 KB stages (three tiles in flight) across both GEMMs and across the chunk boundary (weights and y2 do not depend on the epilogue), so no pipeline is
 // refilled; every `vmcnt` literal below counts the vector-memory operations that are YOUNGER than the tile it publishes.
 // Same three-product multiply, same k order and the same epilogue arithmetic as the two launches it replaces: bit-identical
 // (tests/test_gpu_parity.py::test_conv_pair_matches_the_two_launches).  Whether it is FASTER is a measurement: DESIGN.md section 11.
@@ -36,11 +36,12 @@ template <int K1, int C, int N2>
 __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
   static_assert(K1 == 256 && C % 128 == 0 && N2 == 256, "layer3 shape: 16 k-tiles for GEMM1, 8 per chunk for GEMM2, 256 next-conv1 channels");
   constexpr int NCH = C / 128;                       // chunks of 128 `out` channels
-  constexpr int EP = 36, RPI = 8, ITS = 4;
+  constexpr int EP = 32, RPI = 8, ITS = 4;           // epilogue patches unpadded (32 x 32 fp32 = 4 KB per wave), 16-byte slots XOR-swizzled with (row >> 1) & 7
   __shared__ __attribute__((aligned(1024))) unsigned char S[8 * 128 * 64];        // the chunk of `out` as GEMM2's pixel operand: [k-tile][row][64 B], swizzled like a stage
   __shared__ __attribute__((aligned(1024))) unsigned char st0[16384];
   __shared__ __attribute__((aligned(1024))) unsigned char st1[16384];
   __shared__ __attribute__((aligned(1024))) unsigned char st2[16384];
+  __shared__ __attribute__((aligned(1024))) unsigned char st3[16384];             // 64 + 4 x 16 + 32 KB = the CU's 160 KB: one workgroup per CU
   __shared__ __attribute__((aligned(16))) float patches[8 * 32 * EP];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3, l32 = lane & 31, h = lane >> 5;
@@ -59,16 +60,16 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
   const unsigned a_off0 = arow < p.M ? (unsigned)((arow * K1 + lc4) * 4) : 0x80000000u;           // + 64 per k-tile
   const unsigned w3_off0 = (unsigned)(((wave * 16 + drow) * K1 + lc4) * 4);                      // + chunk * 128 * K1 * 4 + 64 per k-tile
   const unsigned w1_off0 = (unsigned)(((wave * 16 + drow) * C + lc4) * 4), w1_off1 = w1_off0 + (unsigned)(128 * C * 4);   // + chunk * 512 + 64 per k-tile
-  const unsigned st_base[3] = {(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)st0, (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)st1,
-                               (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)st2};
-  // tile T of chunk CC (0..15: GEMM1 k-tile T; 16..23: GEMM2 k-tile T - 16) into stage T % 3: two instructions per wave either way
+  const unsigned st_base[4] = {(unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)st0, (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)st1,
+                               (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)st2, (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)st3};
+  // tile T of chunk CC (0..15: GEMM1 k-tile T; 16..23: GEMM2 k-tile T - 16) into stage T % 4: two instructions per wave either way
 #define PAIR_DMA(T, CC)                                                                                              \
   { if constexpr ((T) < 16) {                                                                                        \
-      dma16(y2_rsrc, st_base[(T) % 3] + (unsigned)wave * 1024u, a_off0 == 0x80000000u ? 0x80000000u : a_off0 + (unsigned)(T) * 64u);            \
-      dma16(w3_rsrc, st_base[(T) % 3] + 8192u + (unsigned)wave * 1024u, w3_off0 + (unsigned)(CC) * (unsigned)(128 * K1 * 4) + (unsigned)(T) * 64u); \
+      dma16(y2_rsrc, st_base[(T) % 4] + (unsigned)wave * 1024u, a_off0 == 0x80000000u ? 0x80000000u : a_off0 + (unsigned)(T) * 64u);            \
+      dma16(w3_rsrc, st_base[(T) % 4] + 8192u + (unsigned)wave * 1024u, w3_off0 + (unsigned)(CC) * (unsigned)(128 * K1 * 4) + (unsigned)(T) * 64u); \
     } else {                                                                                                         \
-      dma16(w1_rsrc, st_base[(T) % 3] + (unsigned)wave * 1024u, w1_off0 + (unsigned)(CC) * 512u + (unsigned)((T) - 16) * 64u);                  \
-      dma16(w1_rsrc, st_base[(T) % 3] + (unsigned)(wave + 8) * 1024u, w1_off1 + (unsigned)(CC) * 512u + (unsigned)((T) - 16) * 64u);            \
+      dma16(w1_rsrc, st_base[(T) % 4] + (unsigned)wave * 1024u, w1_off0 + (unsigned)(CC) * 512u + (unsigned)((T) - 16) * 64u);                  \
+      dma16(w1_rsrc, st_base[(T) % 4] + (unsigned)(wave + 8) * 1024u, w1_off1 + (unsigned)(CC) * 512u + (unsigned)((T) - 16) * 64u);            \
     } }
 
   // ---- fragment addressing (as conv_dma_kernel): lane = (row l32 of a 32-row MFMA tile, k half h), swizzle by (row >> 2) & 3
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
   // publish tile t: VM = vector-memory operations of this wave that are younger than the tile's DMA; lgkmcnt(0): "I am done reading the
   // stage the next DMA overwrites" (conv_dma_kernel's protocol)
 #define PAIR_PUBLISH(VM) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VM) : "memory");
-#define PAIR_STAGE(T) ((T) % 3 == 0 ? st0 : ((T) % 3 == 1 ? st1 : st2))
+#define PAIR_STAGE(T) ((T) % 4 == 0 ? st0 : ((T) % 4 == 1 ? st1 : ((T) % 4 == 2 ? st2 : st3)))
 #if defined(SSG_PAIR_ABL_NOEPI) || defined(SSG_PAIR_ABL_NORES)
 #define PAIR_VML(N_, ABL_) ABL_    // ablation builds: without the epilogue's 10 loads in the queue
 #else
@@ -136,6 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
   // ---- epilogue addressing (conv_dma_kernel's straight-line epilogue)
   float* patch = patches + wave * (32 * EP);
   const int chunk = lane & 7, prow = lane >> 3, odd = lane & 1;
+  const int psw = (l32 >> 1) & 7;                     // patch swizzle of the row this lane writes (rows r: slot ^ ((r >> 1) & 7))
   const unsigned rowb = (unsigned)C * 4u;
   const unsigned lane_off = (unsigned)prow * rowb + (unsigned)chunk * 16u;
   const unsigned ubase1 = (unsigned)(m0 + wm * 64) * rowb + (unsigned)(wn * 32) * 4u;          // + chunk index * 512 + (i * 32 + it * 8) * rowb
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
 #endif
   PAIR_DMA(0, 0)
   PAIR_DMA(1, 0)
+  PAIR_DMA(2, 0)
   for (int c = 0; c < NCH; c++) {
     const int cn = c + 1 < NCH ? c + 1 : c;            // the chunk whose first tiles are requested at the end of this one (clamped: a harmless re-fetch)
 #pragma unroll
@@ -155,16 +158,16 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
       for (int r = 0; r < 16; r++) acc1[i][r] = 0.f;
     v4u rr[2][ITS];
     v4f bias1, cs1;
-    // ======== GEMM1: tiles 0 .. 15
+    // ======== GEMM1: tiles 0 .. 15.  Step t publishes tile t and requests tile t + 3 into the stage of tile t - 1 (three tiles in flight)
 #define PAIR_STEP1(T, VM)                                                                                            \
     { PAIR_PUBLISH(VM)                                                                                               \
-      PAIR_DMA((T) + 2, c)                                                                                           \
+      PAIR_DMA((T) + 3, c)                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       PAIR_MMA1(PAIR_STAGE(T)) }
-    PAIR_STEP1(0, 2) PAIR_STEP1(1, 2) PAIR_STEP1(2, 2) PAIR_STEP1(3, 2) PAIR_STEP1(4, 2) PAIR_STEP1(5, 2) PAIR_STEP1(6, 2) PAIR_STEP1(7, 2)
-    PAIR_STEP1(8, 2) PAIR_STEP1(9, 2) PAIR_STEP1(10, 2) PAIR_STEP1(11, 2) PAIR_STEP1(12, 2)
-    {   // tile 13: behind its DMA, the epilogue's operands (8 residual pieces, bias, scale: 10 loads that stay in flight over tiles 13 .. 15)
-      PAIR_PUBLISH(2)
+    PAIR_STEP1(0, 4) PAIR_STEP1(1, 4) PAIR_STEP1(2, 4) PAIR_STEP1(3, 4) PAIR_STEP1(4, 4) PAIR_STEP1(5, 4) PAIR_STEP1(6, 4) PAIR_STEP1(7, 4)
+    PAIR_STEP1(8, 4) PAIR_STEP1(9, 4) PAIR_STEP1(10, 4) PAIR_STEP1(11, 4)
+    {   // tile 12: behind its DMA, the epilogue's operands (8 residual pieces, bias, scale: 10 loads that stay in flight over tiles 12 .. 15)
+      PAIR_PUBLISH(4)
       PAIR_DMA(15, c)
       {
         const int col = c * 128 + wn * 32 + chunk * 4;
@@ -182,26 +185,26 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
-      PAIR_MMA1(PAIR_STAGE(13))
+      PAIR_MMA1(PAIR_STAGE(12))
     }
-    PAIR_STEP1(14, PAIR_VML(12, 2))
-    PAIR_STEP1(15, PAIR_VML(12, 2))
+    PAIR_STEP1(13, PAIR_VML(14, 4))      // younger than tile 13: tiles 14, 15 (4) + the 10 loads
+    PAIR_STEP1(14, PAIR_VML(14, 4))      // tile 15 (2) + 10 loads + tile 16 (2)
+    PAIR_STEP1(15, PAIR_VML(14, 4))      // 10 loads + tiles 16, 17 (4)
 #undef PAIR_STEP1
-    // every wave is done with tile 15's stage: tile 18 may land there while the epilogue runs
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (no barrier here: the stage of tile 15 is next written by the DMA of tile 19, behind the barrier of step 16; the stash was last read
+    // 16 barriers ago)
     SSG_PAIR_STAMP(t_g1)
-    PAIR_DMA(18, c)
     // ======== epilogue of conv3 for this chunk: out -> HBM and -> the stash
 #ifndef SSG_PAIR_ABL_NOEPI
 #pragma unroll
     for (int i = 0; i < 2; i++) {
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        *reinterpret_cast<float4*>(patch + l32 * EP + 8 * q + 4 * h) = make_float4(acc1[i][4 * q], acc1[i][4 * q + 1], acc1[i][4 * q + 2], acc1[i][4 * q + 3]);
+        *reinterpret_cast<float4*>(patch + l32 * EP + (((2 * q + h) ^ psw) * 4)) = make_float4(acc1[i][4 * q], acc1[i][4 * q + 1], acc1[i][4 * q + 2], acc1[i][4 * q + 3]);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
       for (int it = 0; it < ITS; it++) {
-        float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + chunk * 4);
+        float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + ((chunk ^ ((it & 1) * 4 + (prow >> 1))) * 4));
         v.x = v.x * cs1[0] + bias1[0]; v.y = v.y * cs1[1] + bias1[1]; v.z = v.z * cs1[2] + bias1[2]; v.w = v.w * cs1[3] + bias1[3];
         {
           const unsigned a0 = rr[i][it][0], a1 = rr[i][it][1], a2 = rr[i][it][2], a3 = rr[i][it][3];
@@ -232,14 +235,14 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
       DMA_                                                                                                           \
       __builtin_amdgcn_sched_barrier(0);                                                                             \
       PAIR_MMA2(PAIR_STAGE(T), (T) - 16) }
-    PAIR_STEP2(16, PAIR_VMS(12, 4), {})                           // younger than tile 16: tiles 17, 18 (4) + the 8 stores
-    PAIR_STEP2(17, PAIR_VMS(10, 2), PAIR_DMA(19, c))              // tile 18 (2) + 8 stores
-    PAIR_STEP2(18, PAIR_VMS(10, 2), PAIR_DMA(20, c))              // 8 stores + tile 19
-    PAIR_STEP2(19, 2, PAIR_DMA(21, c))
-    PAIR_STEP2(20, 2, PAIR_DMA(22, c))
-    PAIR_STEP2(21, 2, PAIR_DMA(23, c))
-    PAIR_STEP2(22, 2, PAIR_DMA(0, cn))
-    PAIR_STEP2(23, 2, PAIR_DMA(1, cn))
+    PAIR_STEP2(16, PAIR_VMS(12, 4), PAIR_DMA(19, c))      // younger than tile 16: tiles 17, 18 (4) + the 8 stores
+    PAIR_STEP2(17, PAIR_VMS(12, 4), PAIR_DMA(20, c))      // tile 18 (2) + 8 stores + tile 19 (2)
+    PAIR_STEP2(18, PAIR_VMS(12, 4), PAIR_DMA(21, c))      // 8 stores + tiles 19, 20 (4)
+    PAIR_STEP2(19, 4, PAIR_DMA(22, c))
+    PAIR_STEP2(20, 4, PAIR_DMA(23, c))
+    PAIR_STEP2(21, 4, PAIR_DMA(0, cn))
+    PAIR_STEP2(22, 4, PAIR_DMA(1, cn))
+    PAIR_STEP2(23, 4, PAIR_DMA(2, cn))
 #undef PAIR_STEP2
     SSG_PAIR_STAMP(t_g2)
   }
@@ -256,11 +259,11 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
       for (int i = 0; i < 2; i++) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
-          *reinterpret_cast<float4*>(patch + l32 * EP + 8 * q + 4 * h) = make_float4(acc2[i][j][4 * q], acc2[i][j][4 * q + 1], acc2[i][j][4 * q + 2], acc2[i][j][4 * q + 3]);
+          *reinterpret_cast<float4*>(patch + l32 * EP + (((2 * q + h) ^ psw) * 4)) = make_float4(acc2[i][j][4 * q], acc2[i][j][4 * q + 1], acc2[i][j][4 * q + 2], acc2[i][j][4 * q + 3]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int it = 0; it < ITS; it++) {
-          float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + chunk * 4);
+          float4 v = *reinterpret_cast<const float4*>(patch + (it * RPI + prow) * EP + ((chunk ^ ((it & 1) * 4 + (prow >> 1))) * 4));
           v.x = v.x * cs[0] + bias[0]; v.y = v.y * cs[1] + bias[1]; v.z = v.z * cs[2] + bias[2]; v.w = v.w * cs[3] + bias[3];
           v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
           uint2 hp, lp;
