@@ -1207,11 +1207,13 @@ static int launch_conv(const ConvParams& p, hipStream_t stream, bool split = fal
     if constexpr (CIN4) return launch_conv_bk<BM, BN, WM, WN, true, 16, true>(p, stream);   // one k-step = 4 taps
     else {
       static int sbk16 = -1;   // SSG_SPLIT_BK16=<K>: reductions of at most K use BK=16 stages
-      if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 256; }
+      if (sbk16 < 0) { const char* e = getenv("SSG_SPLIT_BK16"); sbk16 = e ? atoi(e) : 0; }     // round 6: 0 (was 256) -- short reductions take the LDS-DMA kernel below too
       if (!p.in2 && p.Kpad <= sbk16) return launch_conv_bk<BM, BN, WM, WN, false, 16, true>(p, stream);
       if constexpr (BM == 128 && BN == 128) {   // long reductions on 128x128 tiles: LDS-DMA kernel (SSG_CONV_DMA bit 1)
         static int dma = -1;
-        if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }   // bit 1 measured neutral (21.42 vs 21.46 k img/s): off by default
+        // bit 1: round 2 measured it neutral (21.42 vs 21.46 k img/s); with the round-6 epilogue the layer2 entry launches gain (256 -> 128 1x1:
+        // 0.723 -> 0.653 ms, 128 -> 128 3x3 stride 2: 0.591 -> 0.523 ms per 1000 images; bit-identical, profiles/r06_ab_nt_policy.txt): on by default
+        if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 3; }
         if ((dma & 2) && p.epi == 0 && !p.in2) {
           const int tiles = ((p.M + 127) / 128) * (p.Cout / 128);
           hipLaunchKernelGGL(conv_dma_kernel<128>, dim3(tiles), dim3(256), 0, stream, p);
@@ -1241,7 +1243,7 @@ static bool conv_prefers_wide(const ConvParams& p, bool split) {
 // launches; 0 = register-staged kernels everywhere)
 static int launch_conv_wide(const ConvParams& p, hipStream_t stream) {
   static int dma = -1;
-  if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 1; }
+  if (dma < 0) { const char* e = getenv("SSG_CONV_DMA"); dma = e ? atoi(e) : 3; }
   if ((dma & 1) && (p.epi == 0 || p.epi == 3) && (int64_t)p.Cout * p.Kpad * 4 < 0x7fffffffLL) {   // (weights go through a 2 GiB buffer resource)
     // 256 x 256 tiles (16 waves, one workgroup per CU): a third fewer global -> LDS bytes per MFMA; taken when they fill the chip
     // (SSG_CONV_TALL_MINTILES = least number of such tiles, 0 = never)

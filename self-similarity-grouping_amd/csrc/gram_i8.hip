@@ -18,6 +18,9 @@
 // the fp64 kernel.  Anything larger than 1 (or non-finite) is left to the fp64-MFMA kernel of pairwise.hip: the
 // caller picks NL from max|feat|; the encoder additionally raises a device flag if a digit does not fit.
 #include "ssg_common.h"
+#ifndef SSG_GI_NT_STORE
+#define SSG_GI_NT_STORE 0          // A/B knob: the stores of D with the nt cache policy
+#endif
 #include <cstdlib>
 
 namespace ssg {
@@ -213,7 +216,13 @@ __device__ __forceinline__ void gi_epilogue(v16i (&acc)[2 * NL - 1], unsigned ch
         unsigned w[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) w[e] = (unsigned)src[2 * e] | ((unsigned)src[2 * e + 1] << 16);
+#if SSG_GI_NT_STORE
+        { typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+          const v4u_ s0_ = {w[0], w[1], w[2], w[3]}, s1_ = {w[4], w[5], w[6], w[7]};
+          __builtin_nontemporal_store(s0_, reinterpret_cast<v4u_*>(dst)); __builtin_nontemporal_store(s1_, reinterpret_cast<v4u_*>(dst) + 1); }
+#else
         reinterpret_cast<uint4*>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]); reinterpret_cast<uint4*>(dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+#endif
       } else {
         for (int e = 0; e < 16; e++) if (gcol + e < ncol_lim) dst[e] = src[e];
       }

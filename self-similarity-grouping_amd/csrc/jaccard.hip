@@ -15,6 +15,9 @@
 #include "ssg_common.h"
 #include <cstdlib>
 
+#ifndef SSG_JAC_NT_STORE
+#define SSG_JAC_NT_STORE 0         // A/B knob: the streaming pass's stores of J' with the nt cache policy
+#endif
 namespace ssg {
 
 __device__ __forceinline__ void wave_sync2() {
@@ -413,7 +416,12 @@ __global__ __launch_bounds__(64) void jaccard_rows2_kernel(const int32_t* __rest
             const int q = q0 + u * 64 + lane;
             if (q < nvec) {
               *reinterpret_cast<uint4*>(t + q * 8) = make_uint4(0, 0, 0, 0);
+#if SSG_JAC_NT_STORE
+              { typedef unsigned int v4u_ __attribute__((ext_vector_type(4)));
+                const v4u_ s_ = {merge(x[u].x), merge(x[u].y), merge(x[u].z), merge(x[u].w)}; __builtin_nontemporal_store(s_, reinterpret_cast<v4u_*>(out + q * 8)); }
+#else
               *reinterpret_cast<uint4*>(out + q * 8) = make_uint4(merge(x[u].x), merge(x[u].y), merge(x[u].z), merge(x[u].w));
+#endif
             }
           }
         }
