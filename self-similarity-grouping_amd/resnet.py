@@ -412,7 +412,10 @@ class ResNet:
         """the two HIP streams `embed_with_flip` runs its two forwards on"""
         st = getattr(self, "_streams", None)
         if st is None or st[0].device != self.device:
-            st = self._streams = (torch.cuda.Stream(self.device), torch.cuda.Stream(self.device))
+            # SSG_FLIP_PRIO=1 (A/B knob, measured in DESIGN.md section 11): the first stream at high priority, so that its launches take the CUs
+            # first and the other forward only fills what they leave -- one kernel's working set in the L2s at a time instead of two
+            prio = -1 if os.environ.get("SSG_FLIP_PRIO", "0") == "1" else 0
+            st = self._streams = (torch.cuda.Stream(self.device, priority=prio), torch.cuda.Stream(self.device))
         return st
 
     def _overflow_flag(self):
