@@ -35,9 +35,10 @@
 #include <cstdlib>
 
 // Round 6: cache policy of the block's two streams that nobody re-reads from the L2 -- the stores of `out` (1-2 GB per launch at B = 1000)
-// and the residual re-read of x (its last use).  With the default policy they push the lines that ARE re-read (the x rows a neighbouring
-// workgroup needs as its halo and this one as its residual, the weights) out of the 4 MB L2s; with `nt` the layer1 identity blocks
-// run 1.48 -> 1.30-1.35 ms and the layer2 ones 1.22 -> 1.12 ms (profiles/r06_ab_nt_policy.txt).  Same values, same order: bit-identical.
+// and the residual re-read of x (its last use).  With the default policy both allocate lines in the 4 MB L2s that the x rows, the halo
+// rows of the neighbouring workgroup and the weights go through; with `nt` the layer1 identity blocks run 1.48 -> 1.30-1.35 ms and the
+// layer2 ones 1.22 -> 1.12 ms at nearly the same fabric traffic (FETCH_SIZE - 3 %: profiles/r06_ab_nt_policy.txt).  Same values, same
+// order: bit-identical.
 #ifndef SSG_BN_NT_STORE
 #define SSG_BN_NT_STORE 1
 #endif

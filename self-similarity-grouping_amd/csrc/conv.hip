@@ -901,8 +901,8 @@ __global__ __launch_bounds__((BM / WM_) * (BN / 64) * 64, BM == 256 ? 1 : (BN ==
 #define SSG_DMA_FAST_EPI 1
 #endif
   // cache-policy bits (gfx950: 1 = sc0, 2 = nt, 16 = sc1) of the straight-line epilogue's residual loads / output stores, with and without a residual.
-  // A conv3 + residual launch streams its residual (last use) and its 0.5 GB output once: with `nt` they do not evict the pixel tile its four
-  // column tiles share or the weights (layer3: 0.326 -> 0.306 ms, layer4: 0.231 -> 0.219; profiles/r06_ab_nt_policy.txt).  Stores of the
+  // A conv3 + residual launch streams its residual (last use) and its 0.5 GB output once: with `nt` they take no line of the L2 that the pixel
+  // tile of its four column tiles and the weights go through (layer3: 0.326 -> 0.306 ms, layer4: 0.231 -> 0.219; profiles/r06_ab_nt_policy.txt).  Stores of the
   // launches WITHOUT a residual stay cached: their 0.13 GB outputs are the next launch's operand (nt there: conv3 + residual 0.307 -> 0.318).
 #ifndef SSG_DMA_RES_AUX
 #define SSG_DMA_RES_AUX 2

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(512, 2) void conv_pair_kernel(PairParams p) {
 #define PAIR_VMS(N_, ABL_) N_
 #endif
 #ifndef SSG_PAIR_AUX
-#define SSG_PAIR_AUX 2             // cache-policy bits of the residual loads and the stores of `out`: nt (streamed once; they must not push the
-#endif                             // re-read y2 tile and the weights out of the L2: 0.631 -> 0.470 ms, profiles/r06_conv_pair_phases.txt)
+#define SSG_PAIR_AUX 2             // cache-policy bits of the residual loads and the stores of `out`: nt -- streamed once, they need no line of the L2
+#endif                             // the k-tile stream goes through (0.631 -> 0.470 ms at nearly equal fabric traffic: profiles/r06_conv_pair_phases.txt)
 #ifndef SSG_PAIR_AUX_Y1
 #define SSG_PAIR_AUX_Y1 0          // ... of the stores of y1n
 #endif

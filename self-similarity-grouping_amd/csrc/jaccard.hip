@@ -16,8 +16,8 @@
 #include <cstdlib>
 
 #ifndef SSG_JAC_NT_STORE
-#define SSG_JAC_NT_STORE 1         // the streaming pass's stores of J' (every line once, 2 N^2 bytes) with the nt cache policy: they must not evict the
-                                   // inverted lists / V rows the walk re-reads (0.613 -> 0.579 ms beside the source term at N = 16 000, 1.54 -> 1.37 at 30 000)
+#define SSG_JAC_NT_STORE 1         // the streaming pass's stores of J' (every line once, 2 N^2 bytes) with the nt cache policy: they need no line of the L2 the
+                                   // inverted lists / V rows of the walk go through (0.613 -> 0.579 ms beside the source term at N = 16 000, 1.54 -> 1.37 at 30 000)
 #endif
 namespace ssg {
 
